@@ -1,0 +1,143 @@
+/*
+ * peakachu_hip.h -- C ABI of the MI355X-native Peakachu scoring hot path.
+ *
+ * The reference (tariks/peakachu v2.3) is pure Python and has no FFI of its
+ * own; this header is the boundary a maintainer would bind with ctypes from
+ * peakachu/scoreUtils.py.  Every entry point names the
+ * reference code it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *  - plain C types only; no C++ / torch types cross this boundary.
+ *  - functions returning int: 0 = success, negative = error (PK_E_*); the
+ *    message is available from pk_last_error() (thread-local).
+ *  - functions returning a handle: NULL = error, message in pk_last_error().
+ *  - host pointers are BORROWED for the duration of the call; outputs are
+ *    caller-allocated; device memory lives in the opaque handles.
+ *  - one HIP stream per handle family on the given device; calls on handles
+ *    of one device are serialised by the library.
+ *  - there is no CPU fallback: without a gfx950 device every compute call
+ *    fails with PK_E_NODEVICE.
+ */
+#ifndef PEAKACHU_HIP_H
+#define PEAKACHU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_ABI_VERSION 1
+
+#define PK_OK 0
+#define PK_E_INVALID (-1)   /* bad argument */
+#define PK_E_NODEVICE (-2)  /* no usable HIP device */
+#define PK_E_HIP (-3)       /* HIP runtime error */
+#define PK_E_NOMEM (-4)     /* allocation failure */
+#define PK_E_UNSUPPORTED (-5)
+#define PK_E_COMM (-6)      /* RCCL error */
+
+typedef struct pk_forest pk_forest;
+typedef struct pk_matrix pk_matrix;
+typedef struct pk_cands pk_cands;
+typedef struct pk_comm pk_comm;
+
+/* ---- library / device --------------------------------------------------- */
+int pk_abi_version(void);
+const char *pk_last_error(void);
+/* number of visible HIP devices; 0 when there is none (never negative) */
+int pk_device_count(void);
+int pk_device_name(int device, char *buf, int buflen);
+int pk_device_synchronize(int device);
+
+/* ---- forest: the model object used at peakachu/scoreUtils.py:109 --------
+ * (model.predict_proba; sklearn RandomForestClassifier trained at
+ * peakachu/trainUtils.py:46-63).  Arrays are sklearn's per-tree node arrays
+ * laid end to end: tree t owns nodes [tree_off[t], tree_off[t+1]); left/right
+ * are child indices relative to tree_off[t] (-1 at a leaf); feat in [0,F);
+ * thr = split threshold (x <= thr goes left); miss_left = where NaN goes;
+ * p1 = value[node,0,1], the class-1 fraction returned at a leaf. */
+pk_forest *pk_forest_create(int device, int T, int F, const int32_t *tree_off,
+                            const int32_t *left, const int32_t *right,
+                            const int32_t *feat, const double *thr,
+                            const uint8_t *miss_left, const double *p1);
+void pk_forest_destroy(pk_forest *);
+int pk_forest_info(const pk_forest *, int *T, int *F, int64_t *n_nodes, int *max_depth);
+
+/* ---- matrix: Chromosome.M / exp_arr (peakachu/scoreUtils.py:16-33) -------
+ * Canonical CSR (sorted column indices, no duplicates) of the already
+ * band-filtered contact matrix plus the expected-by-distance vector.  The
+ * library re-lays it out in HBM as a diagonal-major dense band covering
+ * col-row in [dlo, dhi]; CSR entries outside that range are ignored (they
+ * read as 0, like absent cells at peakachu/scoreUtils.py:81). */
+pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *indptr,
+                            const int32_t *indices, const double *data,
+                            const double *exp_arr, int32_t exp_len,
+                            int32_t dlo, int32_t dhi);
+void pk_matrix_destroy(pk_matrix *);
+
+/* ---- Chromosome.getwindow (peakachu/scoreUtils.py:70-93) and the body of
+ * trainUtils.buildmatrix (peakachu/trainUtils.py:31-42): gather the
+ * (2w+1)^2 window, distance_normalize (peakachu/utils.py:211-237), gaussian
+ * blur (sigma=1), image_normalize (peakachu/utils.py:204-209), ravel.
+ * keep[i] = index into the input of survivor i (input order).
+ * fea64 / fea32: [n_keep, F] row-major, either may be NULL. */
+int pk_extract(pk_matrix *, int w, int64_t N, const int32_t *x, const int32_t *y,
+               double *fea64, float *fea32, int64_t *keep, int64_t *n_keep);
+
+/* ---- model.predict_proba(fea)[:, 1] (peakachu/scoreUtils.py:109) -------- */
+int pk_predict(pk_forest *, int64_t N, const float *fea32, double *p1);
+
+/* ---- Chromosome.score (peakachu/scoreUtils.py:95-125), device-resident ---
+ * pk_cands holds the candidate list (Chromosome.ridx/cidx,
+ * peakachu/scoreUtils.py:68) and all per-candidate outputs in HBM. */
+pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y);
+void pk_cands_destroy(pk_cands *);
+/* extract -> predict -> (p > thre) -> compact, with the reference's batch
+ * rule (a batch of `batch` candidates with fewer than two surviving windows
+ * contributes nothing; peakachu/scoreUtils.py:104-108).  Results stay on the
+ * device, in candidate order.  Returns after the stream has drained. */
+int pk_score_run(pk_matrix *, pk_forest *, pk_cands *, int w, double thre,
+                 int64_t batch, int64_t *n_out);
+/* copy the n_out scored pixels of the last pk_score_run to the host:
+ * (row, col, probability, signal = M[row, col]; peakachu/scoreUtils.py:118-121) */
+int pk_score_fetch(pk_cands *, int32_t *ox, int32_t *oy, double *op, double *osignal);
+/* per-candidate view of the last run (tests, diagnostics): status[i] = 1 if
+ * the window survived the filters, prob[i] = its probability (else 0) */
+int pk_score_fetch_all(pk_cands *, uint8_t *status, double *prob);
+/* host-buffer convenience: create + run + fetch + destroy */
+int pk_score(pk_matrix *, pk_forest *, int w, double thre, int64_t batch,
+             int64_t N, const int32_t *x, const int32_t *y, int32_t *ox,
+             int32_t *oy, double *op, double *osignal, int64_t *n_out);
+
+/* ---- tuning / measurement ------------------------------------------------ */
+/* named integer knobs ("chunk", "forest_ilp", "forest_lds", ...); returns
+ * PK_E_INVALID for an unknown name */
+int pk_set_option(const char *name, int64_t value);
+int64_t pk_get_option(const char *name);
+/* HIP-event timing of the library's own kernels on its own stream */
+int pk_prof_enable(int on);
+int pk_prof_reset(void);
+/* accumulated device time (ms) and launch count of kernel class `name`
+ * ("extract", "forest", "compact", "band") since the last reset */
+int pk_prof_get(const char *name, double *ms_total, int64_t *launches);
+
+/* ---- multi-GPU: one process per GPU, one gather of the scored pixels -----
+ * Chromosomes / candidate blocks are scored independently per rank
+ * (peakachu/score_genome.py:46-84 shares nothing between iterations); the
+ * only exchange is a gather-v of (row, col, prob, signal) to rank 0 over
+ * RCCL.  The 128-byte unique id is created on rank 0 and handed to the other
+ * ranks by the host's own rendezvous. */
+int pk_comm_unique_id(uint8_t id[128]);
+pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8_t id[128]);
+void pk_comm_destroy(pk_comm *);
+/* every rank passes its pk_cands after pk_score_run; on rank 0 `counts`
+ * (nranks entries) and the concatenated outputs (capacity `cap` pixels) are
+ * filled in rank order; other ranks may pass NULL outputs. */
+int pk_comm_gather_scored(pk_comm *, pk_cands *, int64_t *counts, int64_t cap,
+                          int32_t *ox, int32_t *oy, double *op, double *osignal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEAKACHU_HIP_H */

@@ -1,0 +1,263 @@
+"""ctypes binding of libpeakachu_hip.so (include/peakachu_hip.h).
+
+The library is built in-tree by `make -C peakachu_amd/csrc` (or
+__graft_entry__.build()).  There is no CPU fallback: if the shared object is
+missing, or no gfx950 device is visible when a compute call is made, the
+call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpeakachu_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/peakachu_hip.h declares
+SIGNATURES = {
+    "pk_abi_version": (C.c_int, []),
+    "pk_last_error": (C.c_char_p, []),
+    "pk_device_count": (C.c_int, []),
+    "pk_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "pk_device_synchronize": (C.c_int, [C.c_int]),
+    "pk_forest_create": (_vp, [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p,
+                               _u8p, _f64p]),
+    "pk_forest_destroy": (None, [_vp]),
+    "pk_forest_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    "pk_matrix_create": (_vp, [C.c_int, C.c_int32, _i32p, _i32p, _f64p, _f64p, C.c_int32,
+                               C.c_int32, C.c_int32]),
+    "pk_matrix_destroy": (None, [_vp]),
+    "pk_extract": (C.c_int, [_vp, C.c_int, C.c_int64, _i32p, _i32p, _vp, _vp, _i64p,
+                             C.POINTER(C.c_int64)]),
+    "pk_predict": (C.c_int, [_vp, C.c_int64, _f32p, _f64p]),
+    "pk_cands_create": (_vp, [C.c_int, C.c_int64, _i32p, _i32p]),
+    "pk_cands_destroy": (None, [_vp]),
+    "pk_score_run": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64,
+                               C.POINTER(C.c_int64)]),
+    "pk_score_fetch": (C.c_int, [_vp, _i32p, _i32p, _f64p, _f64p]),
+    "pk_score_fetch_all": (C.c_int, [_vp, _u8p, _f64p]),
+    "pk_score": (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int64, _i32p, _i32p,
+                           _i32p, _i32p, _f64p, _f64p, C.POINTER(C.c_int64)]),
+    "pk_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "pk_get_option": (C.c_int64, [C.c_char_p]),
+    "pk_prof_enable": (C.c_int, [C.c_int]),
+    "pk_prof_reset": (C.c_int, []),
+    "pk_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pk_comm_unique_id": (C.c_int, [_u8p]),
+    "pk_comm_create": (_vp, [C.c_int, C.c_int, C.c_int, _u8p]),
+    "pk_comm_destroy": (None, [_vp]),
+    "pk_comm_gather_scored": (C.c_int, [_vp, _vp, _i64p, C.c_int64, _vp, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+class PeakachuHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the C-ABI library (once).  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise PeakachuHipError(
+            "%s not found: build it with `make -C %s` (hipcc, gfx950). "
+            "peakachu_amd has no CPU fallback." % (LIB_PATH, CSRC))
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the header and the .so disagree
+        fn.restype = res
+        fn.argtypes = args
+    if L.pk_abi_version() != 1:
+        raise PeakachuHipError("ABI version mismatch: %d" % L.pk_abi_version())
+    _LIB = L
+    return L
+
+
+def last_error():
+    return load().pk_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise PeakachuHipError("%s failed (%d): %s" % (what, rc, last_error()))
+
+
+def require_device():
+    L = load()
+    if L.pk_device_count() < 1:
+        raise PeakachuHipError("no HIP device visible; peakachu_amd needs an MI355X (gfx950) "
+                               "and has no CPU fallback")
+    return L
+
+
+# ------------------------------------------------------------------ handles
+class HipForest:
+    """Device-resident forest (pk_forest)."""
+
+    def __init__(self, flat, device=0):
+        L = require_device()
+        self._L = L
+        self.T, self.F = int(flat.T), int(flat.F)
+        self.h = L.pk_forest_create(
+            device, self.T, self.F,
+            np.ascontiguousarray(flat.tree_off, np.int32),
+            np.ascontiguousarray(flat.left, np.int32),
+            np.ascontiguousarray(flat.right, np.int32),
+            np.ascontiguousarray(flat.feat, np.int32),
+            np.ascontiguousarray(flat.thr, np.float64),
+            np.ascontiguousarray(flat.miss_left, np.uint8),
+            np.ascontiguousarray(flat.p1, np.float64))
+        if not self.h:
+            raise PeakachuHipError("pk_forest_create: " + last_error())
+        self.device = device
+
+    def info(self):
+        T, F, d = C.c_int(), C.c_int(), C.c_int()
+        nn = C.c_int64()
+        check(self._L.pk_forest_info(self.h, C.byref(T), C.byref(F), C.byref(nn), C.byref(d)),
+              "pk_forest_info")
+        return dict(T=T.value, F=F.value, n_nodes=nn.value, max_depth=d.value)
+
+    def predict(self, fea32):
+        fea32 = np.ascontiguousarray(fea32, np.float32)
+        if fea32.ndim != 2 or fea32.shape[1] != self.F:
+            raise ValueError("features must be [N, %d]" % self.F)
+        N = fea32.shape[0]
+        out = np.empty(max(N, 1), np.float64)
+        check(self._L.pk_predict(self.h, N, fea32.reshape(-1) if N else np.zeros(1, np.float32),
+                                 out), "pk_predict")
+        return out[:N]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.pk_forest_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class HipMatrix:
+    """Device-resident band matrix + expected vector (pk_matrix)."""
+
+    def __init__(self, indptr, indices, data, n, exp_arr, dlo, dhi, device=0):
+        L = require_device()
+        self._L = L
+        exp_arr = np.ascontiguousarray(exp_arr, np.float64)
+        indices = np.ascontiguousarray(indices, np.int32)
+        data = np.ascontiguousarray(data, np.float64)
+        if indices.size == 0:
+            indices = np.zeros(1, np.int32)
+            data = np.zeros(1, np.float64)
+        self.h = L.pk_matrix_create(device, int(n), np.ascontiguousarray(indptr, np.int32),
+                                    indices, data, exp_arr, int(exp_arr.size), int(dlo), int(dhi))
+        if not self.h:
+            raise PeakachuHipError("pk_matrix_create: " + last_error())
+        self.n, self.dlo, self.dhi, self.device = int(n), int(dlo), int(dhi), device
+
+    def extract(self, w, x, y, want64=True, want32=False):
+        x = np.ascontiguousarray(x, np.int32)
+        y = np.ascontiguousarray(y, np.int32)
+        N = x.size
+        F = (2 * w + 1) ** 2
+        keep = np.empty(max(N, 1), np.int64)
+        f64 = np.empty((max(N, 1), F), np.float64) if want64 else None
+        f32 = np.empty((max(N, 1), F), np.float32) if want32 else None
+        nk = C.c_int64(0)
+        if N:
+            check(self._L.pk_extract(self.h, int(w), N, x, y,
+                                     f64.ctypes.data if want64 else None,
+                                     f32.ctypes.data if want32 else None, keep, C.byref(nk)),
+                  "pk_extract")
+        k = nk.value
+        return (f64[:k] if want64 else None), (f32[:k] if want32 else None), keep[:k]
+
+    def score(self, forest, w, thre, x, y, batch=100000):
+        x = np.ascontiguousarray(x, np.int32)
+        y = np.ascontiguousarray(y, np.int32)
+        N = x.size
+        ox = np.empty(max(N, 1), np.int32)
+        oy = np.empty(max(N, 1), np.int32)
+        op = np.empty(max(N, 1), np.float64)
+        osig = np.empty(max(N, 1), np.float64)
+        nout = C.c_int64(0)
+        if N:
+            check(self._L.pk_score(self.h, forest.h, int(w), float(thre), int(batch), N, x, y,
+                                   ox, oy, op, osig, C.byref(nout)), "pk_score")
+        k = nout.value
+        return ox[:k], oy[:k], op[:k], osig[:k]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.pk_matrix_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class HipCands:
+    """Device-resident candidate list and per-candidate outputs (pk_cands)."""
+
+    def __init__(self, x, y, device=0):
+        L = require_device()
+        self._L = L
+        x = np.ascontiguousarray(x, np.int32)
+        y = np.ascontiguousarray(y, np.int32)
+        self.N = int(x.size)
+        self.h = L.pk_cands_create(device, self.N, x if self.N else np.zeros(1, np.int32),
+                                   y if self.N else np.zeros(1, np.int32))
+        if not self.h:
+            raise PeakachuHipError("pk_cands_create: " + last_error())
+        self.n_out = 0
+
+    def run(self, matrix, forest, w, thre, batch=100000):
+        nout = C.c_int64(0)
+        check(self._L.pk_score_run(matrix.h, forest.h, self.h, int(w), float(thre), int(batch),
+                                   C.byref(nout)), "pk_score_run")
+        self.n_out = nout.value
+        return self.n_out
+
+    def fetch(self):
+        k = max(self.n_out, 1)
+        ox = np.empty(k, np.int32)
+        oy = np.empty(k, np.int32)
+        op = np.empty(k, np.float64)
+        osig = np.empty(k, np.float64)
+        check(self._L.pk_score_fetch(self.h, ox, oy, op, osig), "pk_score_fetch")
+        k = self.n_out
+        return ox[:k], oy[:k], op[:k], osig[:k]
+
+    def fetch_all(self):
+        st = np.empty(max(self.N, 1), np.uint8)
+        pr = np.empty(max(self.N, 1), np.float64)
+        check(self._L.pk_score_fetch_all(self.h, st, pr), "pk_score_fetch_all")
+        return st[:self.N], pr[:self.N]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.pk_cands_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def set_option(name, value):
+    check(load().pk_set_option(name.encode(), int(value)), "pk_set_option(%s)" % name)
+
+
+def prof_get(name):
+    ms = C.c_double(0)
+    n = C.c_int64(0)
+    check(load().pk_prof_get(name.encode(), C.byref(ms), C.byref(n)), "pk_prof_get")
+    return ms.value, n.value

@@ -1,0 +1,742 @@
+// pk_api.hip -- host side of the C ABI declared in include/peakachu_hip.h:
+// handle lifetime, forest packing, the chunked extract -> forest pipeline and
+// the result compaction.  Everything runs on one HIP stream per device; no
+// torch, no CPU fallback.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+
+#include "pk_common.h"
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+void pk_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+pk_options g_opt;
+static std::mutex g_mu;
+static std::map<int, pk_device_ctx *> g_ctx;
+
+// --------------------------------------------------------------- profiling
+struct prof_rec {
+    hipEvent_t e0, e1;
+    pk_kclass k;
+    int device;
+};
+static bool g_prof_on = false;
+static std::vector<prof_rec> g_prof_pending;
+static double g_prof_ms[PK_K_NCLASS] = {0, 0, 0, 0};
+static int64_t g_prof_n[PK_K_NCLASS] = {0, 0, 0, 0};
+
+pk_prof_scope::pk_prof_scope(pk_device_ctx *c, pk_kclass kk) : ctx(c), k(kk)
+{
+    if (!g_prof_on) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        e0 = e1 = nullptr;
+        return;
+    }
+    hipEventRecord(e0, ctx->stream);
+}
+pk_prof_scope::~pk_prof_scope()
+{
+    if (!e0) return;
+    hipEventRecord(e1, ctx->stream);
+    g_prof_pending.push_back({e0, e1, k, ctx->device});
+}
+
+static void prof_drain()
+{
+    for (auto &r : g_prof_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess &&
+            hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            g_prof_ms[r.k] += ms;
+            g_prof_n[r.k] += 1;
+        }
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+    }
+    g_prof_pending.clear();
+}
+
+// ------------------------------------------------------------------ context
+pk_device_ctx *pk_ctx(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(device);
+    if (it != g_ctx.end()) {
+        if (hipSetDevice(device) != hipSuccess) {
+            pk_set_error("hipSetDevice(%d) failed", device);
+            return nullptr;
+        }
+        return it->second;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        pk_set_error("no HIP device available (this library has no CPU fallback)");
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) {
+        pk_set_error("device %d out of range (0..%d)", device, ndev - 1);
+        return nullptr;
+    }
+    PK_HIP_NULL(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    PK_HIP_NULL(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        pk_set_error("device %d is %s; this library is built for gfx950 only", device,
+                     prop.gcnArchName);
+        return nullptr;
+    }
+    pk_device_ctx *c = new pk_device_ctx();
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    PK_HIP_NULL(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    g_ctx[device] = c;
+    return c;
+}
+
+int pk_ctx_reserve_tiles(pk_device_ctx *c, size_t bytes)
+{
+    if (bytes <= c->fea_tiles_bytes) return PK_OK;
+    if (c->fea_tiles) {
+        PK_HIP(hipStreamSynchronize(c->stream));
+        PK_HIP(hipFree(c->fea_tiles));
+        c->fea_tiles = nullptr;
+        c->fea_tiles_bytes = 0;
+    }
+    PK_HIP(hipMalloc((void **)&c->fea_tiles, bytes));
+    c->fea_tiles_bytes = bytes;
+    return PK_OK;
+}
+
+int pk_ctx_reserve_scan(pk_device_ctx *c, size_t bytes)
+{
+    if (bytes <= c->scan_scratch_bytes) return PK_OK;
+    if (c->scan_scratch) {
+        PK_HIP(hipStreamSynchronize(c->stream));
+        PK_HIP(hipFree(c->scan_scratch));
+        c->scan_scratch = nullptr;
+        c->scan_scratch_bytes = 0;
+    }
+    bytes = bytes * 2 + 4096;
+    PK_HIP(hipMalloc((void **)&c->scan_scratch, bytes));
+    c->scan_scratch_bytes = bytes;
+    return PK_OK;
+}
+
+// -------------------------------------------------------------- public: misc
+extern "C" int pk_abi_version(void) { return PK_ABI_VERSION; }
+extern "C" const char *pk_last_error(void) { return g_err; }
+
+extern "C" int pk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n < 0 ? 0 : n;
+}
+
+extern "C" int pk_device_name(int device, char *buf, int buflen)
+{
+    if (!buf || buflen <= 0) return PK_E_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        pk_set_error("no HIP device %d", device);
+        return PK_E_NODEVICE;
+    }
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+             prop.multiProcessorCount);
+    return PK_OK;
+}
+
+extern "C" int pk_device_synchronize(int device)
+{
+    pk_device_ctx *c = pk_ctx(device);
+    if (!c) return PK_E_NODEVICE;
+    PK_HIP(hipStreamSynchronize(c->stream));
+    PK_HIP(hipDeviceSynchronize());
+    return PK_OK;
+}
+
+extern "C" int pk_set_option(const char *name, int64_t value)
+{
+    if (!name) return PK_E_INVALID;
+    if (!strcmp(name, "chunk")) {
+        if (value < 64) return PK_E_INVALID;
+        g_opt.chunk = value;
+    } else if (!strcmp(name, "forest_ilp")) {
+        if (value != 1 && value != 2 && value != 4 && value != 8) return PK_E_INVALID;
+        g_opt.forest_ilp = value;
+    } else if (!strcmp(name, "forest_lds")) {
+        if (value < 0) return PK_E_INVALID;
+        g_opt.forest_lds = value;
+    } else if (!strcmp(name, "extract_block")) {
+        g_opt.extract_block = value;
+    } else {
+        pk_set_error("unknown option '%s'", name);
+        return PK_E_INVALID;
+    }
+    return PK_OK;
+}
+
+extern "C" int64_t pk_get_option(const char *name)
+{
+    if (!name) return -1;
+    if (!strcmp(name, "chunk")) return g_opt.chunk;
+    if (!strcmp(name, "forest_ilp")) return g_opt.forest_ilp;
+    if (!strcmp(name, "forest_lds")) return g_opt.forest_lds;
+    if (!strcmp(name, "extract_block")) return g_opt.extract_block;
+    return -1;
+}
+
+extern "C" int pk_prof_enable(int on)
+{
+    g_prof_on = on != 0;
+    return PK_OK;
+}
+extern "C" int pk_prof_reset(void)
+{
+    prof_drain();
+    for (int i = 0; i < PK_K_NCLASS; i++) {
+        g_prof_ms[i] = 0;
+        g_prof_n[i] = 0;
+    }
+    return PK_OK;
+}
+extern "C" int pk_prof_get(const char *name, double *ms_total, int64_t *launches)
+{
+    static const char *names[PK_K_NCLASS] = {"extract", "forest", "compact", "band"};
+    prof_drain();
+    for (int i = 0; i < PK_K_NCLASS; i++)
+        if (name && !strcmp(name, names[i])) {
+            if (ms_total) *ms_total = g_prof_ms[i];
+            if (launches) *launches = g_prof_n[i];
+            return PK_OK;
+        }
+    pk_set_error("unknown kernel class '%s'", name ? name : "(null)");
+    return PK_E_INVALID;
+}
+
+// ------------------------------------------------------------------- forest
+// largest float32 <= t: for float32 x, (double)x <= t  <=>  x <= floor32(t)
+static float floor_to_f32(double t)
+{
+    float f = (float)t;
+    if ((double)f > t) f = nextafterf(f, -INFINITY);
+    return f;
+}
+
+extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *tree_off,
+                                       const int32_t *left, const int32_t *right,
+                                       const int32_t *feat, const double *thr,
+                                       const uint8_t *miss_left, const double *p1)
+{
+    if (T <= 0 || F <= 0 || !tree_off || !left || !right || !feat || !thr || !p1) {
+        pk_set_error("pk_forest_create: bad arguments");
+        return nullptr;
+    }
+    if (F > (1 << PK_NODE_FEAT_BITS)) {
+        pk_set_error("pk_forest_create: F=%d exceeds %d features", F, 1 << PK_NODE_FEAT_BITS);
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(device);
+    if (!ctx) return nullptr;
+
+    std::vector<uint2> nodes;
+    std::vector<int32_t> root(T + 1);
+    std::vector<int32_t> pos, stack, depth;
+    int max_depth = 0, max_tree = 0;
+    auto put_leaf = [&](double v) {
+        uint64_t b;
+        memcpy(&b, &v, 8);
+        nodes.push_back(make_uint2((unsigned)(b & 0xffffffffu), (unsigned)(b >> 32)));
+    };
+    for (int t = 0; t < T; t++) {
+        const int32_t base = tree_off[t], nn = tree_off[t + 1] - base;
+        if (nn <= 0) {
+            pk_set_error("pk_forest_create: tree %d is empty", t);
+            return nullptr;
+        }
+        root[t] = (int32_t)nodes.size();
+        if (left[base] == -1) {
+            // a one-leaf tree: give it a root whose two children are that leaf
+            const unsigned pk = (1u << PK_NODE_MISS_BIT) | (1u << PK_NODE_LLEAF_BIT) |
+                                (1u << PK_NODE_RLEAF_BIT) | (2u << PK_NODE_ROFF_SHIFT);
+            float inf = INFINITY;
+            unsigned tb;
+            memcpy(&tb, &inf, 4);
+            nodes.push_back(make_uint2(tb, pk));
+            put_leaf(p1[base]);
+            put_leaf(p1[base]);
+            if (max_tree < 3) max_tree = 3;
+            continue;
+        }
+        // preorder positions (left child first)
+        pos.assign(nn, -1);
+        depth.assign(nn, 0);
+        stack.clear();
+        stack.push_back(0);
+        int32_t next = 0;
+        while (!stack.empty()) {
+            const int32_t v = stack.back();
+            stack.pop_back();
+            if (v < 0 || v >= nn || pos[v] != -1 || next >= nn) {
+                pk_set_error("pk_forest_create: tree %d is malformed at node %d", t, v);
+                return nullptr;
+            }
+            pos[v] = next++;
+            if (depth[v] > max_depth) max_depth = depth[v];
+            const int32_t l = left[base + v], r = right[base + v];
+            if (l != -1) {
+                if (l < 0 || l >= nn || r < 0 || r >= nn) {
+                    pk_set_error("pk_forest_create: tree %d node %d has bad children", t, v);
+                    return nullptr;
+                }
+                depth[l] = depth[r] = depth[v] + 1;
+                stack.push_back(r);
+                stack.push_back(l);
+            }
+        }
+        const size_t tree_base = nodes.size();
+        nodes.resize(tree_base + (size_t)next);
+        for (int32_t v = 0; v < nn; v++) {
+            if (pos[v] < 0) continue;  // unreachable node
+            const int32_t l = left[base + v], r = right[base + v];
+            if (l == -1) {
+                uint64_t b;
+                memcpy(&b, &p1[base + v], 8);
+                nodes[tree_base + pos[v]] =
+                    make_uint2((unsigned)(b & 0xffffffffu), (unsigned)(b >> 32));
+                continue;
+            }
+            const int32_t f = feat[base + v];
+            if (f < 0 || f >= F) {
+                pk_set_error("pk_forest_create: tree %d node %d feature %d out of range", t, v, f);
+                return nullptr;
+            }
+            const int64_t roff = (int64_t)pos[r] - pos[v];
+            if (pos[l] != pos[v] + 1 || roff <= 0 || roff >= (1 << (32 - PK_NODE_ROFF_SHIFT))) {
+                pk_set_error("pk_forest_create: tree %d too large (right offset %lld)", t,
+                             (long long)roff);
+                return nullptr;
+            }
+            unsigned pk = (unsigned)f;
+            if (miss_left && miss_left[base + v]) pk |= 1u << PK_NODE_MISS_BIT;
+            if (left[base + l] == -1) pk |= 1u << PK_NODE_LLEAF_BIT;
+            if (left[base + r] == -1) pk |= 1u << PK_NODE_RLEAF_BIT;
+            pk |= (unsigned)roff << PK_NODE_ROFF_SHIFT;
+            const float t32 = floor_to_f32(thr[base + v]);
+            unsigned tb;
+            memcpy(&tb, &t32, 4);
+            nodes[tree_base + pos[v]] = make_uint2(tb, pk);
+        }
+        if (next > max_tree) max_tree = next;
+    }
+    root[T] = (int32_t)nodes.size();
+
+    pk_forest *fo = new pk_forest();
+    fo->device = device;
+    fo->T = T;
+    fo->F = F;
+    fo->n_nodes = (int64_t)nodes.size();
+    fo->max_depth = max_depth;
+    fo->max_tree_nodes = max_tree;
+    fo->nodes = nullptr;
+    fo->root = nullptr;
+    fo->h_root = root;
+    if (hipMalloc((void **)&fo->nodes, nodes.size() * sizeof(uint2)) != hipSuccess ||
+        hipMalloc((void **)&fo->root, root.size() * sizeof(int32_t)) != hipSuccess) {
+        pk_set_error("pk_forest_create: device allocation failed");
+        pk_forest_destroy(fo);
+        return nullptr;
+    }
+    if (hipMemcpy(fo->nodes, nodes.data(), nodes.size() * sizeof(uint2), hipMemcpyHostToDevice) !=
+            hipSuccess ||
+        hipMemcpy(fo->root, root.data(), root.size() * sizeof(int32_t), hipMemcpyHostToDevice) !=
+            hipSuccess) {
+        pk_set_error("pk_forest_create: upload failed");
+        pk_forest_destroy(fo);
+        return nullptr;
+    }
+    return fo;
+}
+
+extern "C" void pk_forest_destroy(pk_forest *f)
+{
+    if (!f) return;
+    hipSetDevice(f->device);
+    if (f->nodes) hipFree(f->nodes);
+    if (f->root) hipFree(f->root);
+    delete f;
+}
+
+extern "C" int pk_forest_info(const pk_forest *f, int *T, int *F, int64_t *n_nodes, int *max_depth)
+{
+    if (!f) return PK_E_INVALID;
+    if (T) *T = f->T;
+    if (F) *F = f->F;
+    if (n_nodes) *n_nodes = f->n_nodes;
+    if (max_depth) *max_depth = f->max_depth;
+    return PK_OK;
+}
+
+// ------------------------------------------------------------------- matrix
+extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *indptr,
+                                       const int32_t *indices, const double *data,
+                                       const double *exp_arr, int32_t exp_len, int32_t dlo,
+                                       int32_t dhi)
+{
+    if (n <= 0 || !indptr || !exp_arr || exp_len <= 0 || dhi < dlo) {
+        pk_set_error("pk_matrix_create: bad arguments");
+        return nullptr;
+    }
+    const int64_t nnz = indptr[n];
+    if (nnz < 0 || indptr[0] != 0 || (nnz > 0 && (!indices || !data))) {
+        pk_set_error("pk_matrix_create: malformed CSR");
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(device);
+    if (!ctx) return nullptr;
+    pk_matrix *m = new pk_matrix();
+    m->device = device;
+    m->n = n;
+    m->dlo = dlo;
+    m->dhi = dhi;
+    m->ld = ((int64_t)n + 63) / 64 * 64;
+    m->band = nullptr;
+    m->exp_arr = nullptr;
+    m->exp_len = exp_len;
+    int32_t *d_indptr = nullptr, *d_indices = nullptr;
+    double *d_data = nullptr;
+    const size_t band_bytes = (size_t)(dhi - dlo + 1) * m->ld * sizeof(double);
+    bool ok = hipMalloc((void **)&m->band, band_bytes) == hipSuccess &&
+              hipMalloc((void **)&m->exp_arr, sizeof(double) * (size_t)exp_len) == hipSuccess &&
+              hipMalloc((void **)&d_indptr, sizeof(int32_t) * (size_t)(n + 1)) == hipSuccess &&
+              hipMalloc((void **)&d_indices, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)) == hipSuccess &&
+              hipMalloc((void **)&d_data, sizeof(double) * (size_t)(nnz > 0 ? nnz : 1)) == hipSuccess;
+    if (ok) {
+        ok = hipMemcpyAsync(m->exp_arr, exp_arr, sizeof(double) * (size_t)exp_len,
+                            hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(d_indptr, indptr, sizeof(int32_t) * (size_t)(n + 1),
+                            hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+        if (ok && nnz > 0)
+            ok = hipMemcpyAsync(d_indices, indices, sizeof(int32_t) * (size_t)nnz,
+                                hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                 hipMemcpyAsync(d_data, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice,
+                                ctx->stream) == hipSuccess;
+        if (ok) ok = pk_launch_band_build(ctx, m, d_indptr, d_indices, d_data, nnz) == PK_OK;
+        if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (!ok && !g_err[0]) pk_set_error("pk_matrix_create: upload / band build failed");
+    } else {
+        pk_set_error("pk_matrix_create: device allocation of %zu band bytes failed", band_bytes);
+    }
+    if (d_indptr) hipFree(d_indptr);
+    if (d_indices) hipFree(d_indices);
+    if (d_data) hipFree(d_data);
+    if (!ok) {
+        pk_matrix_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+extern "C" void pk_matrix_destroy(pk_matrix *m)
+{
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->band) hipFree(m->band);
+    if (m->exp_arr) hipFree(m->exp_arr);
+    delete m;
+}
+
+// --------------------------------------------------------------- candidates
+extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y)
+{
+    if (N < 0 || (N > 0 && (!x || !y))) {
+        pk_set_error("pk_cands_create: bad arguments");
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(device);
+    if (!ctx) return nullptr;
+    pk_cands *c = new pk_cands();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->N = N;
+    const size_t n1 = (size_t)(N > 0 ? N : 1);
+    c->n_batches_cap = 0;
+    bool ok = hipMalloc((void **)&c->x, n1 * 4) == hipSuccess &&
+              hipMalloc((void **)&c->y, n1 * 4) == hipSuccess &&
+              hipMalloc((void **)&c->prob, n1 * 8) == hipSuccess &&
+              hipMalloc((void **)&c->status, n1) == hipSuccess &&
+              hipMalloc((void **)&c->ox, n1 * 4) == hipSuccess &&
+              hipMalloc((void **)&c->oy, n1 * 4) == hipSuccess &&
+              hipMalloc((void **)&c->op, n1 * 8) == hipSuccess &&
+              hipMalloc((void **)&c->osig, n1 * 8) == hipSuccess &&
+              hipMalloc((void **)&c->n_out_dev, 8) == hipSuccess;
+    if (ok && N > 0)
+        ok = hipMemcpy(c->x, x, n1 * 4, hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(c->y, y, n1 * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        pk_set_error("pk_cands_create: device allocation / upload failed (N=%lld)", (long long)N);
+        pk_cands_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void pk_cands_destroy(pk_cands *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    void *ptrs[] = {c->x, c->y, c->prob, c->status, c->ox, c->oy, c->op, c->osig, c->n_out_dev,
+                    c->batch_cnt};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    delete c;
+}
+
+// The reference raises on coordinates whose window leaves the matrix in the
+// row direction (scipy fancy indexing) or wraps negative columns; the build
+// requires 0 <= x <= y < n, for which neither can happen.
+static int check_coords(const char *who, int32_t n, int64_t N, const int32_t *x, const int32_t *y)
+{
+    for (int64_t i = 0; i < N; i++)
+        if (x[i] < 0 || y[i] < x[i] || y[i] >= n) {
+            pk_set_error("%s: coordinate %lld = (%d, %d) violates 0 <= x <= y < n=%d", who,
+                         (long long)i, x[i], y[i], n);
+            return PK_E_INVALID;
+        }
+    return PK_OK;
+}
+
+static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands *cd, int w)
+{
+    const int F = (2 * w + 1) * (2 * w + 1);
+    const int blk = pk_forest_tile_width(F);
+    if (blk <= 0) {
+        pk_set_error("w=%d: feature tile does not fit LDS", w);
+        return PK_E_UNSUPPORTED;
+    }
+    int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
+    if (chunk > cd->N) chunk = (cd->N + blk - 1) / blk * blk;
+    int rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
+    if (rc) return rc;
+    for (int64_t c0 = 0; c0 < cd->N; c0 += chunk) {
+        const int64_t cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
+        rc = pk_launch_extract(ctx, m, w, cd->x, cd->y, c0, cn, ctx->fea_tiles, blk, cd->status,
+                               nullptr);
+        if (rc) return rc;
+        rc = pk_launch_forest(ctx, f, ctx->fea_tiles, blk, cd->status, c0, cn, cd->prob);
+        if (rc) return rc;
+    }
+    return PK_OK;
+}
+
+extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, double thre,
+                            int64_t batch, int64_t *n_out)
+{
+    if (!m || !f || !cd || w < 1) {
+        pk_set_error("pk_score_run: bad arguments");
+        return PK_E_INVALID;
+    }
+    if (m->device != f->device || m->device != cd->device) {
+        pk_set_error("pk_score_run: handles live on different devices");
+        return PK_E_INVALID;
+    }
+    const int F = (2 * w + 1) * (2 * w + 1);
+    if (f->F != F) {
+        pk_set_error("pk_score_run: forest has %d features, w=%d needs %d", f->F, w, F);
+        return PK_E_INVALID;
+    }
+    if (batch <= 0) batch = 100000;
+    pk_device_ctx *ctx = pk_ctx(m->device);
+    if (!ctx) return PK_E_NODEVICE;
+    const int64_t nb = (cd->N + batch - 1) / batch + 1;
+    if (nb > cd->n_batches_cap) {
+        if (cd->batch_cnt) PK_HIP(hipFree(cd->batch_cnt));
+        cd->batch_cnt = nullptr;
+        PK_HIP(hipMalloc((void **)&cd->batch_cnt, sizeof(int32_t) * (size_t)nb));
+        cd->n_batches_cap = nb;
+    }
+    int rc = run_pipeline(ctx, m, f, cd, w);
+    if (rc) return rc;
+    rc = pk_launch_compact(ctx, m, cd, thre, batch);
+    if (rc) return rc;
+    PK_HIP(hipMemcpyAsync(&cd->n_out, cd->n_out_dev, sizeof(int64_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_out) *n_out = cd->n_out;
+    return PK_OK;
+}
+
+extern "C" int pk_score_fetch(pk_cands *cd, int32_t *ox, int32_t *oy, double *op, double *osignal)
+{
+    if (!cd) return PK_E_INVALID;
+    pk_device_ctx *ctx = pk_ctx(cd->device);
+    if (!ctx) return PK_E_NODEVICE;
+    const size_t k = (size_t)cd->n_out;
+    if (k == 0) return PK_OK;
+    if (ox) PK_HIP(hipMemcpyAsync(ox, cd->ox, k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (oy) PK_HIP(hipMemcpyAsync(oy, cd->oy, k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (op) PK_HIP(hipMemcpyAsync(op, cd->op, k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (osignal) PK_HIP(hipMemcpyAsync(osignal, cd->osig, k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
+extern "C" int pk_score_fetch_all(pk_cands *cd, uint8_t *status, double *prob)
+{
+    if (!cd) return PK_E_INVALID;
+    pk_device_ctx *ctx = pk_ctx(cd->device);
+    if (!ctx) return PK_E_NODEVICE;
+    if (cd->N == 0) return PK_OK;
+    if (status)
+        PK_HIP(hipMemcpyAsync(status, cd->status, (size_t)cd->N, hipMemcpyDeviceToHost, ctx->stream));
+    if (prob)
+        PK_HIP(hipMemcpyAsync(prob, cd->prob, (size_t)cd->N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
+extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t batch, int64_t N,
+                        const int32_t *x, const int32_t *y, int32_t *ox, int32_t *oy, double *op,
+                        double *osignal, int64_t *n_out)
+{
+    if (!m || !f || !n_out) {
+        pk_set_error("pk_score: bad arguments");
+        return PK_E_INVALID;
+    }
+    int rc = check_coords("pk_score", m->n, N, x, y);
+    if (rc) return rc;
+    pk_cands *cd = pk_cands_create(m->device, N, x, y);
+    if (!cd) return PK_E_HIP;
+    rc = pk_score_run(m, f, cd, w, thre, batch, n_out);
+    if (!rc) rc = pk_score_fetch(cd, ox, oy, op, osignal);
+    pk_cands_destroy(cd);
+    return rc;
+}
+
+// ------------------------------------------------------------ getwindow API
+extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, const int32_t *y,
+                          double *fea64, float *fea32, int64_t *keep, int64_t *n_keep)
+{
+    if (!m || !keep || !n_keep || N < 0 || w < 1 || w > 15) {
+        pk_set_error("pk_extract: bad arguments");
+        return PK_E_INVALID;
+    }
+    *n_keep = 0;
+    if (N == 0) return PK_OK;
+    int rc = check_coords("pk_extract", m->n, N, x, y);
+    if (rc) return rc;
+    pk_device_ctx *ctx = pk_ctx(m->device);
+    if (!ctx) return PK_E_NODEVICE;
+    const int F = (2 * w + 1) * (2 * w + 1);
+    int blk = pk_forest_tile_width(F);
+    if (blk <= 0) blk = 64;
+    pk_cands *cd = pk_cands_create(m->device, N, x, y);
+    if (!cd) return PK_E_HIP;
+    // bounded staging: rows of float64 features for one chunk at a time
+    int64_t chunk = 65536 / blk * blk;
+    if (chunk > N) chunk = (N + blk - 1) / blk * blk;
+    double *d_rows = nullptr;
+    std::vector<double> h_rows((size_t)chunk * F);
+    std::vector<uint8_t> h_status((size_t)chunk);
+    rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
+    if (!rc && hipMalloc((void **)&d_rows, (size_t)chunk * F * sizeof(double)) != hipSuccess) {
+        pk_set_error("pk_extract: staging allocation failed");
+        rc = PK_E_NOMEM;
+    }
+    int64_t nk = 0;
+    for (int64_t c0 = 0; !rc && c0 < N; c0 += chunk) {
+        const int64_t cn = N - c0 < chunk ? N - c0 : chunk;
+        rc = pk_launch_extract(ctx, m, w, cd->x, cd->y, c0, cn, ctx->fea_tiles, blk, cd->status,
+                               d_rows);
+        if (rc) break;
+        if (hipMemcpyAsync(h_rows.data(), d_rows, (size_t)cn * F * 8, hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(h_status.data(), cd->status + c0, (size_t)cn, hipMemcpyDeviceToHost,
+                           ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            pk_set_error("pk_extract: download failed");
+            rc = PK_E_HIP;
+            break;
+        }
+        for (int64_t i = 0; i < cn; i++) {
+            if (!h_status[(size_t)i]) continue;
+            const double *src = h_rows.data() + (size_t)i * F;
+            if (fea64) memcpy(fea64 + (size_t)nk * F, src, sizeof(double) * F);
+            if (fea32)
+                for (int q = 0; q < F; q++) fea32[(size_t)nk * F + q] = (float)src[q];
+            keep[nk++] = c0 + i;
+        }
+    }
+    if (d_rows) hipFree(d_rows);
+    pk_cands_destroy(cd);
+    if (!rc) *n_keep = nk;
+    return rc;
+}
+
+// --------------------------------------------------------- predict_proba API
+extern "C" int pk_predict(pk_forest *f, int64_t N, const float *fea32, double *p1)
+{
+    if (!f || N < 0 || (N > 0 && (!fea32 || !p1))) {
+        pk_set_error("pk_predict: bad arguments");
+        return PK_E_INVALID;
+    }
+    if (N == 0) return PK_OK;
+    pk_device_ctx *ctx = pk_ctx(f->device);
+    if (!ctx) return PK_E_NODEVICE;
+    const int F = f->F;
+    const int blk = pk_forest_tile_width(F);
+    if (blk <= 0) {
+        pk_set_error("pk_predict: F=%d does not fit an LDS tile", F);
+        return PK_E_UNSUPPORTED;
+    }
+    int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
+    if (chunk > N) chunk = (N + blk - 1) / blk * blk;
+    int rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
+    if (rc) return rc;
+    float *d_rows = nullptr;
+    double *d_prob = nullptr;
+    uint8_t *d_status = nullptr;
+    if (hipMalloc((void **)&d_rows, (size_t)chunk * F * 4) != hipSuccess ||
+        hipMalloc((void **)&d_prob, (size_t)chunk * 8) != hipSuccess ||
+        hipMalloc((void **)&d_status, (size_t)chunk) != hipSuccess) {
+        pk_set_error("pk_predict: device allocation failed");
+        rc = PK_E_NOMEM;
+    }
+    if (!rc && hipMemsetAsync(d_status, 1, (size_t)chunk, ctx->stream) != hipSuccess) rc = PK_E_HIP;
+    for (int64_t c0 = 0; !rc && c0 < N; c0 += chunk) {
+        const int64_t cn = N - c0 < chunk ? N - c0 : chunk;
+        if (hipMemcpyAsync(d_rows, fea32 + (size_t)c0 * F, (size_t)cn * F * 4,
+                           hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            pk_set_error("pk_predict: upload failed");
+            rc = PK_E_HIP;
+            break;
+        }
+        rc = pk_launch_tile_rows(ctx, d_rows, cn, F, ctx->fea_tiles, blk);
+        if (rc) break;
+        rc = pk_launch_forest(ctx, f, ctx->fea_tiles, blk, d_status, 0, cn, d_prob);
+        if (rc) break;
+        if (hipMemcpyAsync(p1 + c0, d_prob, (size_t)cn * 8, hipMemcpyDeviceToHost, ctx->stream) !=
+                hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            pk_set_error("pk_predict: download failed");
+            rc = PK_E_HIP;
+        }
+    }
+    if (d_rows) hipFree(d_rows);
+    if (d_prob) hipFree(d_prob);
+    if (d_status) hipFree(d_status);
+    return rc;
+}

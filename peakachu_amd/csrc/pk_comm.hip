@@ -1,0 +1,192 @@
+// pk_comm.hip -- the one multi-GPU exchange of the scoring path: a gather-v
+// of the scored pixels (row, col, prob, signal) to rank 0 over RCCL.
+//
+// The reference scores chromosomes one after another in a single process
+// (peakachu/score_genome.py:46-84) and appends each result to one file
+// (peakachu/scoreUtils.py:127-135).  Here every rank (one process per GPU)
+// scores its own chromosomes / candidate blocks; nothing is exchanged on the
+// data path until the end, when rank 0 collects the pixels with p > thre.
+// xGMI is point-to-point, so the gather is N-1 direct peer->root transfers
+// (grouped ncclSend/ncclRecv), preceded by an all-gather of the counts.
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include "pk_common.h"
+
+struct pk_comm {
+    int device, nranks, rank;
+    ncclComm_t comm;
+    int64_t *d_counts;  // device [nranks]
+};
+
+#define PK_NCCL(call)                                                                  \
+    do {                                                                               \
+        ncclResult_t r__ = (call);                                                     \
+        if (r__ != ncclSuccess) {                                                      \
+            pk_set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r__),      \
+                         __FILE__, __LINE__);                                          \
+            return PK_E_COMM;                                                          \
+        }                                                                              \
+    } while (0)
+
+static_assert(sizeof(ncclUniqueId) == 128, "pk_comm_unique_id assumes a 128-byte id");
+
+extern "C" int pk_comm_unique_id(uint8_t id[128])
+{
+    if (!id) return PK_E_INVALID;
+    ncclUniqueId u;
+    PK_NCCL(ncclGetUniqueId(&u));
+    memcpy(id, &u, 128);
+    return PK_OK;
+}
+
+extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8_t id[128])
+{
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) {
+        pk_set_error("pk_comm_create: bad arguments");
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(device);
+    if (!ctx) return nullptr;
+    pk_comm *c = new pk_comm();
+    c->device = device;
+    c->nranks = nranks;
+    c->rank = rank;
+    c->comm = nullptr;
+    c->d_counts = nullptr;
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+        pk_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(r));
+        delete c;
+        return nullptr;
+    }
+    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * (size_t)nranks) != hipSuccess) {
+        pk_set_error("pk_comm_create: device allocation failed");
+        ncclCommDestroy(c->comm);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void pk_comm_destroy(pk_comm *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->d_counts) hipFree(c->d_counts);
+    if (c->comm) ncclCommDestroy(c->comm);
+    delete c;
+}
+
+extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, int64_t cap,
+                                     int32_t *ox, int32_t *oy, double *op, double *osignal)
+{
+    if (!c || !cd || cd->device != c->device) {
+        pk_set_error("pk_comm_gather_scored: bad arguments");
+        return PK_E_INVALID;
+    }
+    pk_device_ctx *ctx = pk_ctx(c->device);
+    if (!ctx) return PK_E_NODEVICE;
+    hipStream_t s = ctx->stream;
+    const int R = c->nranks;
+    // 1. counts: n_out_dev holds this rank's count after pk_score_run
+    PK_NCCL(ncclAllGather(cd->n_out_dev, c->d_counts, 1, ncclInt64, c->comm, s));
+    std::vector<int64_t> h_counts((size_t)R);
+    PK_HIP(hipMemcpyAsync(h_counts.data(), c->d_counts, sizeof(int64_t) * (size_t)R,
+                          hipMemcpyDeviceToHost, s));
+    PK_HIP(hipStreamSynchronize(s));
+    int64_t total = 0;
+    for (int r = 0; r < R; r++) total += h_counts[(size_t)r];
+    if (counts)
+        for (int r = 0; r < R; r++) counts[r] = h_counts[(size_t)r];
+
+    if (c->rank != 0) {
+        // 2. peer -> root: four typed sends in one group
+        const size_t k = (size_t)h_counts[(size_t)c->rank];
+        if (k > 0) {
+            PK_NCCL(ncclGroupStart());
+            PK_NCCL(ncclSend(cd->ox, k, ncclInt32, 0, c->comm, s));
+            PK_NCCL(ncclSend(cd->oy, k, ncclInt32, 0, c->comm, s));
+            PK_NCCL(ncclSend(cd->op, k, ncclFloat64, 0, c->comm, s));
+            PK_NCCL(ncclSend(cd->osig, k, ncclFloat64, 0, c->comm, s));
+            PK_NCCL(ncclGroupEnd());
+        }
+        PK_HIP(hipStreamSynchronize(s));
+        return PK_OK;
+    }
+
+    // root
+    if (total > cap || (total > 0 && (!ox || !oy || !op || !osignal))) {
+        pk_set_error("pk_comm_gather_scored: %lld pixels exceed the root capacity %lld",
+                     (long long)total, (long long)cap);
+        // still drain the peers' sends into a scratch area to keep ranks in step
+    }
+    const size_t t1 = (size_t)(total > 0 ? total : 1);
+    int32_t *gx = nullptr, *gy = nullptr;
+    double *gp = nullptr, *gs = nullptr;
+    if (hipMalloc((void **)&gx, t1 * 4) != hipSuccess || hipMalloc((void **)&gy, t1 * 4) != hipSuccess ||
+        hipMalloc((void **)&gp, t1 * 8) != hipSuccess || hipMalloc((void **)&gs, t1 * 8) != hipSuccess) {
+        pk_set_error("pk_comm_gather_scored: staging allocation failed");
+        if (gx) hipFree(gx);
+        if (gy) hipFree(gy);
+        if (gp) hipFree(gp);
+        if (gs) hipFree(gs);
+        return PK_E_NOMEM;
+    }
+    int rc = PK_OK;
+    do {
+        const size_t k0 = (size_t)h_counts[0];
+        if (k0 > 0) {
+            if (hipMemcpyAsync(gx, cd->ox, k0 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(gy, cd->oy, k0 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(gp, cd->op, k0 * 8, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(gs, cd->osig, k0 * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                pk_set_error("pk_comm_gather_scored: local copy failed");
+                rc = PK_E_HIP;
+                break;
+            }
+        }
+        ncclResult_t nr = ncclGroupStart();
+        size_t off = k0;
+        for (int r = 1; r < R && nr == ncclSuccess; r++) {
+            const size_t k = (size_t)h_counts[(size_t)r];
+            if (k == 0) continue;
+            nr = ncclRecv(gx + off, k, ncclInt32, r, c->comm, s);
+            if (nr == ncclSuccess) nr = ncclRecv(gy + off, k, ncclInt32, r, c->comm, s);
+            if (nr == ncclSuccess) nr = ncclRecv(gp + off, k, ncclFloat64, r, c->comm, s);
+            if (nr == ncclSuccess) nr = ncclRecv(gs + off, k, ncclFloat64, r, c->comm, s);
+            off += k;
+        }
+        ncclResult_t ne = ncclGroupEnd();
+        if (nr != ncclSuccess || ne != ncclSuccess) {
+            pk_set_error("pk_comm_gather_scored: RCCL recv failed: %s",
+                         ncclGetErrorString(nr != ncclSuccess ? nr : ne));
+            rc = PK_E_COMM;
+            break;
+        }
+        if (total > 0 && total <= cap && ox && oy && op && osignal) {
+            const size_t t = (size_t)total;
+            if (hipMemcpyAsync(ox, gx, t * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(oy, gy, t * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(op, gp, t * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(osignal, gs, t * 8, hipMemcpyDeviceToHost, s) != hipSuccess) {
+                pk_set_error("pk_comm_gather_scored: download failed");
+                rc = PK_E_HIP;
+                break;
+            }
+        } else if (total > cap) {
+            rc = PK_E_INVALID;
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) {
+            pk_set_error("pk_comm_gather_scored: stream sync failed");
+            rc = PK_E_HIP;
+        }
+    } while (0);
+    hipFree(gx);
+    hipFree(gy);
+    hipFree(gp);
+    hipFree(gs);
+    return rc;
+}

@@ -1,0 +1,144 @@
+// pk_common.h -- internal declarations shared by the HIP sources of
+// libpeakachu_hip.so (gfx950 only).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/peakachu_hip.h"
+
+// ------------------------------------------------------------------ errors
+void pk_set_error(const char *fmt, ...);
+
+#define PK_HIP(call)                                                          \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) {                                              \
+            pk_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                         __FILE__, __LINE__);                                 \
+            return PK_E_HIP;                                                  \
+        }                                                                     \
+    } while (0)
+
+#define PK_HIP_NULL(call)                                                     \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) {                                              \
+            pk_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                         __FILE__, __LINE__);                                 \
+            return nullptr;                                                   \
+        }                                                                     \
+    } while (0)
+
+// ----------------------------------------------------------- device context
+// One per device: the stream every kernel of the library is launched on and
+// the reusable scratch (feature tiles) sized by the "chunk" option.
+struct pk_device_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    float *fea_tiles = nullptr;   // [tile][F][BLK] float32 feature tiles
+    size_t fea_tiles_bytes = 0;
+    int64_t *scan_scratch = nullptr;  // block counts for the compaction scan
+    size_t scan_scratch_bytes = 0;
+    int cu_count = 0;
+};
+pk_device_ctx *pk_ctx(int device);  // lazily created; nullptr + error on failure
+int pk_ctx_reserve_tiles(pk_device_ctx *, size_t bytes);
+int pk_ctx_reserve_scan(pk_device_ctx *, size_t bytes);
+
+// ------------------------------------------------------------------ options
+struct pk_options {
+    int64_t chunk = 262144;     // candidates per extract/forest launch pair
+    int64_t forest_ilp = 4;     // trees walked concurrently per lane
+    int64_t forest_lds = 0;     // stage tree nodes through LDS (0 = read via L2)
+    int64_t extract_block = 64; // threads per extract block
+};
+extern pk_options g_opt;
+
+// ---------------------------------------------------------------- profiling
+// Brackets a kernel launch with HIP events on the library's stream when
+// profiling is enabled (pk_prof_enable); otherwise a no-op.
+enum pk_kclass { PK_K_EXTRACT = 0, PK_K_FOREST, PK_K_COMPACT, PK_K_BAND, PK_K_NCLASS };
+struct pk_prof_scope {
+    pk_prof_scope(pk_device_ctx *ctx, pk_kclass k);
+    ~pk_prof_scope();
+    pk_device_ctx *ctx;
+    pk_kclass k;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+// ------------------------------------------------------------------ handles
+// Forest node word (8 bytes).  Interior node: {thr32, packed}; leaf: the
+// float64 class-1 fraction.  Nodes of one tree are stored in preorder, so the
+// left child of node i is i+1 and only the right child's offset is stored.
+//   packed bits  0..9  feature index (F <= 1024)
+//               10     NaN goes left
+//               11     left child is a leaf
+//               12     right child is a leaf
+//               13..31 offset of the right child from this node (< 2^19)
+#define PK_NODE_FEAT_BITS 10
+#define PK_NODE_MISS_BIT 10
+#define PK_NODE_LLEAF_BIT 11
+#define PK_NODE_RLEAF_BIT 12
+#define PK_NODE_ROFF_SHIFT 13
+
+struct pk_forest {
+    int device;
+    int T, F;
+    int64_t n_nodes;       // slots in `nodes`
+    int max_depth;         // edges on the longest root->leaf path
+    int max_tree_nodes;
+    uint2 *nodes;          // device, n_nodes x 8 B
+    int32_t *root;         // device, T+1 offsets of each tree's root
+    std::vector<int32_t> h_root;
+};
+
+// Diagonal-major dense band: cell (r, r+k), dlo <= k <= dhi, lives at
+// band[(k - dlo) * ld + r]; everything else reads 0.
+struct pk_matrix {
+    int device;
+    int32_t n, dlo, dhi;
+    int64_t ld;            // row pitch in doubles (n rounded up to 64)
+    double *band;          // device
+    double *exp_arr;       // device
+    int32_t exp_len;
+};
+
+struct pk_cands {
+    int device;
+    int64_t N;
+    int32_t *x, *y;        // device, candidate coordinates
+    double *prob;          // device [N]
+    uint8_t *status;       // device [N] 1 = window survived the filters
+    // compacted outputs of the last run (device), capacity N
+    int32_t *ox, *oy;
+    double *op, *osig;
+    int64_t *n_out_dev;    // device scalar
+    int64_t n_out;         // host copy after the run
+    int32_t *batch_cnt;    // device [n_batches] survivors per reference batch
+    int64_t n_batches_cap;
+};
+
+// ------------------------------------------------------------ kernel entry
+// (implemented in the .hip files; all launch on ctx->stream)
+int pk_launch_band_build(pk_device_ctx *, pk_matrix *, const int32_t *d_indptr,
+                         const int32_t *d_indices, const double *d_data, int64_t nnz);
+
+// features of candidates [c0, c0+cn) -> tiles (tile width BLK) + status.
+// If fea64_rows != nullptr also writes row-major float64 features [cn][F].
+int pk_launch_extract(pk_device_ctx *, const pk_matrix *, int w, const int32_t *d_x,
+                      const int32_t *d_y, int64_t c0, int64_t cn, float *tiles, int blk,
+                      uint8_t *d_status, double *fea64_rows);
+
+// walk the forest over feature tiles of candidates [c0, c0+cn)
+int pk_launch_forest(pk_device_ctx *, const pk_forest *, const float *tiles, int blk,
+                     const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob);
+// row-major float32 features [N][F] -> tiles (for pk_predict)
+int pk_launch_tile_rows(pk_device_ctx *, const float *d_rows, int64_t N, int F, float *tiles,
+                        int blk);
+int pk_forest_tile_width(int F);  // candidates per feature tile for F features
+
+int pk_launch_compact(pk_device_ctx *, const pk_matrix *, pk_cands *, double thre,
+                      int64_t batch);

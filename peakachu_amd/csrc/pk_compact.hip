@@ -1,0 +1,194 @@
+// pk_compact.hip -- band construction and the tail of Chromosome.score for
+// gfx950: the reference's batch rule, the p > thre filter, deterministic
+// stream compaction in candidate order and the signal re-gather
+// (peakachu/scoreUtils.py:104-121).  Integer / byte work, HBM-bound, tiny
+// next to the extract and forest kernels.
+#include "pk_common.h"
+
+namespace {
+
+// ---- CSR -> diagonal-major band: one thread per stored entry ------------
+__global__ void band_build_kernel(const int32_t *__restrict__ indptr,
+                                  const int32_t *__restrict__ indices,
+                                  const double *__restrict__ data, int64_t nnz, int n, int dlo,
+                                  int dhi, int64_t ld, double *__restrict__ band)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    // row of entry e: largest r with indptr[r] <= e
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)indptr[mid] <= e) lo = mid;
+        else hi = mid;
+    }
+    const int r = lo;
+    const int col = indices[e];
+    const int k = col - r;
+    if (k < dlo || k > dhi || col < 0 || col >= n) return;
+    band[(int64_t)(k - dlo) * ld + r] = data[e];
+}
+
+// ---- survivors per reference batch (scoreUtils.py:104-108) --------------
+__global__ void batch_count_kernel(const uint8_t *__restrict__ status, int64_t N, int64_t batch,
+                                   int32_t *__restrict__ batch_cnt)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    if (status[c]) atomicAdd(&batch_cnt[c / batch], 1);
+}
+
+constexpr int CB = 256;          // threads per compaction block
+constexpr int CITEMS = 4;        // candidates per thread
+constexpr int CTILE = CB * CITEMS;
+
+__device__ __forceinline__ bool keep_flag(const uint8_t *status, const double *prob,
+                                          const int32_t *batch_cnt, int64_t batch, double thre,
+                                          int64_t c, int64_t N)
+{
+    // fea.shape[0] > 1 (scoreUtils.py:108) and p > thre (scoreUtils.py:110)
+    return c < N && status[c] && batch_cnt[c / batch] > 1 && prob[c] > thre;
+}
+
+__global__ void compact_count_kernel(const uint8_t *__restrict__ status,
+                                     const double *__restrict__ prob,
+                                     const int32_t *__restrict__ batch_cnt, int64_t batch,
+                                     double thre, int64_t N, int64_t *__restrict__ block_cnt)
+{
+    __shared__ int wsum[CB / 64];
+    const int64_t base = (int64_t)blockIdx.x * CTILE + (int64_t)threadIdx.x * CITEMS;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < CITEMS; i++) cnt += keep_flag(status, prob, batch_cnt, batch, thre, base + i, N);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int i = 0; i < CB / 64; i++) s += wsum[i];
+        block_cnt[blockIdx.x] = s;
+    }
+}
+
+// exclusive scan of block_cnt in place by one workgroup; total -> *n_out
+__global__ void compact_scan_kernel(int64_t *__restrict__ block_cnt, int64_t nblocks,
+                                    int64_t *__restrict__ n_out)
+{
+    __shared__ int64_t part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (nblocks + blockDim.x - 1) / blockDim.x;
+    const int64_t b0 = (int64_t)tid * per;
+    const int64_t b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    int64_t s = 0;
+    for (int64_t b = b0; b < b1; b++) s += block_cnt[b];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < (int)blockDim.x; i++) {
+            const int64_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        *n_out = run;
+    }
+    __syncthreads();
+    int64_t run = part[tid];
+    for (int64_t b = b0; b < b1; b++) {
+        const int64_t v = block_cnt[b];
+        block_cnt[b] = run;
+        run += v;
+    }
+}
+
+__global__ void compact_scatter_kernel(const uint8_t *__restrict__ status,
+                                       const double *__restrict__ prob,
+                                       const int32_t *__restrict__ batch_cnt, int64_t batch,
+                                       double thre, int64_t N, const int64_t *__restrict__ block_off,
+                                       const int32_t *__restrict__ xs, const int32_t *__restrict__ ys,
+                                       const double *__restrict__ band, int64_t ld, int dlo, int dhi,
+                                       int32_t *__restrict__ ox, int32_t *__restrict__ oy,
+                                       double *__restrict__ op, double *__restrict__ osig)
+{
+    __shared__ int wsum[CB / 64];
+    const int64_t base = (int64_t)blockIdx.x * CTILE + (int64_t)threadIdx.x * CITEMS;
+    bool k[CITEMS];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < CITEMS; i++) {
+        k[i] = keep_flag(status, prob, batch_cnt, batch, thre, base + i, N);
+        cnt += k[i];
+    }
+    // exclusive scan of cnt over the workgroup, thread order
+    int incl = cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < wave; i++) woff += wsum[i];
+    int64_t pos = block_off[blockIdx.x] + woff + incl - cnt;
+#pragma unroll
+    for (int i = 0; i < CITEMS; i++) {
+        if (!k[i]) continue;
+        const int64_t c = base + i;
+        const int x = xs[c], y = ys[c];
+        ox[pos] = x;
+        oy[pos] = y;
+        op[pos] = prob[c];
+        const int d = y - x;
+        // signal = M[row, col] (scoreUtils.py:120)
+        osig[pos] = (d >= dlo && d <= dhi) ? band[(int64_t)(d - dlo) * ld + x] : 0.0;
+        pos++;
+    }
+}
+
+}  // namespace
+
+int pk_launch_band_build(pk_device_ctx *ctx, pk_matrix *m, const int32_t *d_indptr,
+                         const int32_t *d_indices, const double *d_data, int64_t nnz)
+{
+    pk_prof_scope prof(ctx, PK_K_BAND);
+    const size_t bytes = (size_t)(m->dhi - m->dlo + 1) * m->ld * sizeof(double);
+    PK_HIP(hipMemsetAsync(m->band, 0, bytes, ctx->stream));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(band_build_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0,
+                           ctx->stream, d_indptr, d_indices, d_data, nnz, m->n, m->dlo, m->dhi,
+                           m->ld, m->band);
+        PK_HIP(hipGetLastError());
+    }
+    return PK_OK;
+}
+
+int pk_launch_compact(pk_device_ctx *ctx, const pk_matrix *m, pk_cands *cd, double thre,
+                      int64_t batch)
+{
+    const int64_t N = cd->N;
+    if (N == 0) {
+        PK_HIP(hipMemsetAsync(cd->n_out_dev, 0, sizeof(int64_t), ctx->stream));
+        return PK_OK;
+    }
+    pk_prof_scope prof(ctx, PK_K_COMPACT);
+    const int64_t nb = (N + batch - 1) / batch;
+    PK_HIP(hipMemsetAsync(cd->batch_cnt, 0, sizeof(int32_t) * (size_t)nb, ctx->stream));
+    hipLaunchKernelGGL(batch_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+                       ctx->stream, cd->status, N, batch, cd->batch_cnt);
+    const int64_t nblocks = (N + CTILE - 1) / CTILE;
+    int rc = pk_ctx_reserve_scan(ctx, sizeof(int64_t) * (size_t)nblocks);
+    if (rc) return rc;
+    hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nblocks), dim3(CB), 0, ctx->stream,
+                       cd->status, cd->prob, cd->batch_cnt, batch, thre, N, ctx->scan_scratch);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                       ctx->scan_scratch, nblocks, cd->n_out_dev);
+    hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)nblocks), dim3(CB), 0, ctx->stream,
+                       cd->status, cd->prob, cd->batch_cnt, batch, thre, N, ctx->scan_scratch,
+                       cd->x, cd->y, m->band, m->ld, m->dlo, m->dhi, cd->ox, cd->oy, cd->op,
+                       cd->osig);
+    PK_HIP(hipGetLastError());
+    return PK_OK;
+}

@@ -1,0 +1,347 @@
+// pk_extract.hip -- window gather + distance-normalise + Gaussian blur +
+// min-max scale for gfx950 (CDNA4), bit-exact float64.
+//
+// Replaces Chromosome.getwindow (peakachu/scoreUtils.py:70-93), which calls
+// utils.distance_normalize (peakachu/utils.py:211-237),
+// utils.distance_normaize_core (:180-202), scipy.ndimage.gaussian_filter
+// (sigma=1) and utils.image_normalize (:204-209) once per candidate.
+//
+// Design (MI355X-first):
+//  * the contact matrix lives in HBM as a diagonal-major dense band, so for a
+//    wave of 64 candidates that are consecutive along one diagonal -- the
+//    reference's candidate order -- every one of the (2w+1)^2 window-cell
+//    loads is a contiguous 512-byte read;
+//  * one candidate per lane, the whole window in VGPRs (242 for w=5, 338 for
+//    w=6; a wave owns its SIMD's 512-register file), fully unrolled so every
+//    register index is static; no LDS, no barriers;
+//  * the arithmetic order is scipy's / numba's exactly and the file is built
+//    with -ffp-contract=off: no FMA contraction, IEEE division;
+//  * float32 features leave in [tile][F][BLK] order so the store of feature
+//    f by a wave is one 256-byte line and the forest kernel can copy a tile
+//    into LDS with unit stride.
+//  * other window sizes (w=11 stress config) use a one-wave-per-candidate
+//    kernel that keeps the window in LDS.
+#include "pk_common.h"
+
+namespace {
+
+// scipy.ndimage._filters._gaussian_kernel1d(sigma=1, order=0, radius=4):
+// exp(-x^2/2)/sum, as hex literals (no device exp()).
+__device__ constexpr double GK0 = 0x1.9884a307594fbp-2;
+__device__ constexpr double GK1 = 0x1.ef8eb9ad499bap-3;
+__device__ constexpr double GK2 = 0x1.ba4b99d1799abp-5;
+__device__ constexpr double GK3 = 0x1.22724cb7eb269p-8;
+__device__ constexpr double GK4 = 0x1.18a9c4fd536c6p-13;
+
+// scipy 'reflect' line extension: (d c b a | a b c d | d c b a)
+__host__ __device__ constexpr int reflect_idx(int i, int n)
+{
+    while (i < 0 || i >= n) i = (i < 0) ? (-i - 1) : (2 * n - 1 - i);
+    return i;
+}
+
+// NI_Correlate1D, symmetric kernel: centre tap first, then outermost pair
+// inwards; one rounding per operation (no FMA).
+#define PK_BLUR9(c, m4, p4, m3, p3, m2, p2, m1, p1) \
+    ((((((c) * GK0 + ((m4) + (p4)) * GK4) + ((m3) + (p3)) * GK3) + ((m2) + (p2)) * GK2) + ((m1) + (p1)) * GK1))
+
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+// ------------------------------------------------------------------------
+// Register kernel: one candidate per lane.
+// ------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64) void extract_reg_kernel(
+    const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
+    const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
+    const int32_t *__restrict__ ys, int64_t c0, int64_t cn, float *__restrict__ tiles, int blk,
+    uint8_t *__restrict__ status, double *__restrict__ fea64_rows)
+{
+    constexpr int S = 2 * W + 1;
+    constexpr int F = S * S;
+    const int64_t local = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= cn) return;
+    const int64_t c = c0 + local;
+    const int xi = xs[c], yi = ys[c];
+
+    // scoreUtils.py:75: the window must lie inside the matrix
+    if (!(xi - W >= 0 && yi + W + 1 <= n)) {
+        status[c] = 0;
+        return;
+    }
+    const int d = yi - xi;
+    const int64_t r0 = (int64_t)(xi - W);
+
+    // ---- gather (scoreUtils.py:77-82): win[i][j] = M[x-w+i, y-w+j];
+    // cell (i,j) sits on diagonal k = d + j - i of the band.
+    double win[S][S];
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            const int k = d + j - i;
+            double v = 0.0;
+            if (k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + i];
+            win[i][j] = v;
+        }
+    }
+
+    // ---- utils.py:221-225: NaN -> 0, sparsity filter
+    int nnz = 0;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            double v = win[i][j];
+            v = (v != v) ? 0.0 : v;
+            win[i][j] = v;
+            nnz += (v != 0.0) ? 1 : 0;
+        }
+    }
+    bool ok = !((double)nnz < (double)F * 0.1);
+
+    // ---- utils.py:228-232: top-left w x w mean (numba: sequential C order)
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+#pragma unroll
+        for (int j = 0; j < W; j++) acc += win[i][j];
+    }
+    const double ll_mean = acc / (double)(W * W);
+    ok = ok && (ll_mean > 0.0);
+    const double p2ll = win[W][W] / ll_mean;
+    ok = ok && (p2ll > 0.1);
+    if (!ok) {
+        status[c] = 0;
+        return;
+    }
+
+    // ---- utils.py:180-202: divide by expected(|col-row|) unless the largest
+    // distance in the window falls outside exp_arr
+    const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
+    if (dmax < exp_len) {
+        double e[4 * W + 1];
+#pragma unroll
+        for (int q = 0; q <= 4 * W; q++) e[q] = exp_arr[iabs(d - 2 * W + q)];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int j = 0; j < S; j++) win[i][j] = win[i][j] / e[j - i + 2 * W];
+        }
+    }
+
+    // ---- scipy gaussian_filter(sigma=1): axis 0 (down each column) ...
+#pragma unroll
+    for (int j = 0; j < S; j++) {
+        double col[S];
+#pragma unroll
+        for (int i = 0; i < S; i++) col[i] = win[i][j];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            win[i][j] = PK_BLUR9(col[i], col[reflect_idx(i - 4, S)], col[reflect_idx(i + 4, S)],
+                                 col[reflect_idx(i - 3, S)], col[reflect_idx(i + 3, S)],
+                                 col[reflect_idx(i - 2, S)], col[reflect_idx(i + 2, S)],
+                                 col[reflect_idx(i - 1, S)], col[reflect_idx(i + 1, S)]);
+        }
+    }
+    // ... then axis 1 (along each row)
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+        double row[S];
+#pragma unroll
+        for (int j = 0; j < S; j++) row[j] = win[i][j];
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            win[i][j] = PK_BLUR9(row[j], row[reflect_idx(j - 4, S)], row[reflect_idx(j + 4, S)],
+                                 row[reflect_idx(j - 3, S)], row[reflect_idx(j + 3, S)],
+                                 row[reflect_idx(j - 2, S)], row[reflect_idx(j + 2, S)],
+                                 row[reflect_idx(j - 1, S)], row[reflect_idx(j + 1, S)]);
+        }
+    }
+
+    // ---- utils.py:204-209 image_normalize; numpy min/max propagate NaN
+    double mn = win[0][0], mx = win[0][0];
+    bool has_nan = false;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            const double v = win[i][j];
+            has_nan = has_nan || (v != v);
+            mn = (v < mn) ? v : mn;
+            mx = (v > mx) ? v : mx;
+        }
+    }
+    if (has_nan) {
+        mn = __builtin_nan("");
+        mx = mn;
+    }
+    const double den = mx - mn;
+
+    const int64_t tile = local / blk;
+    const int lane = (int)(local - tile * blk);
+    float *tp = tiles + (size_t)tile * F * blk + lane;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            const double v = (win[i][j] - mn) / den;
+            win[i][j] = v;
+            tp[(size_t)(i * S + j) * blk] = (float)v;  // sklearn's float32 cast (RNE)
+        }
+    }
+    if (fea64_rows) {
+        double *fp = fea64_rows + (size_t)local * F;
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int j = 0; j < S; j++) fp[i * S + j] = win[i][j];
+        }
+    }
+    status[c] = 1;
+}
+
+// ------------------------------------------------------------------------
+// Generic kernel (any w <= 15): one candidate per 64-lane wave, window in LDS.
+// Used for w = 11 (23x23, 529 features) where a window no longer fits one
+// lane's registers.  Same operation order as above.
+// ------------------------------------------------------------------------
+constexpr int GEN_WAVES = 4;
+
+__global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
+    int W, const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
+    const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
+    const int32_t *__restrict__ ys, int64_t c0, int64_t cn, float *__restrict__ tiles, int blk,
+    uint8_t *__restrict__ status, double *__restrict__ fea64_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int S = 2 * W + 1, F = S * S;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *A = smem + (size_t)wave * 2 * F;
+    double *B = A + F;
+    const int64_t local = (int64_t)blockIdx.x * GEN_WAVES + wave;
+    if (local >= cn) return;  // wave-uniform; no block barriers are used below
+    const int64_t c = c0 + local;
+    const int xi = xs[c], yi = ys[c];
+    if (!(xi - W >= 0 && yi + W + 1 <= n)) {
+        if (lane == 0) status[c] = 0;
+        return;
+    }
+    const int d = yi - xi;
+    const int64_t r0 = (int64_t)(xi - W);
+
+    int nnz = 0;
+    for (int f = lane; f < F; f += 64) {
+        const int i = f / S, j = f - i * S;
+        const int k = d + j - i;
+        double v = 0.0;
+        if (k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + i];
+        v = (v != v) ? 0.0 : v;
+        A[f] = v;
+        nnz += (v != 0.0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes of this wave landed
+    bool ok = !((double)nnz < (double)F * 0.1);
+    // sequential top-left sum, every lane computes the same value from LDS
+    double acc = 0.0;
+    for (int i = 0; i < W; i++)
+        for (int j = 0; j < W; j++) acc += A[i * S + j];
+    const double ll_mean = acc / (double)(W * W);
+    ok = ok && (ll_mean > 0.0);
+    const double p2ll = A[W * S + W] / ll_mean;
+    ok = ok && (p2ll > 0.1);
+    if (!ok) {
+        if (lane == 0) status[c] = 0;
+        return;
+    }
+    const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
+    if (dmax < exp_len) {
+        for (int f = lane; f < F; f += 64) {
+            const int i = f / S, j = f - i * S;
+            A[f] = A[f] / exp_arr[iabs(d + j - i)];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // axis 0: A -> B
+    for (int f = lane; f < F; f += 64) {
+        const int i = f / S, j = f - i * S;
+#define AT(q) A[reflect_idx((q), S) * S + j]
+        B[f] = PK_BLUR9(A[f], AT(i - 4), AT(i + 4), AT(i - 3), AT(i + 3), AT(i - 2), AT(i + 2),
+                        AT(i - 1), AT(i + 1));
+#undef AT
+    }
+    __builtin_amdgcn_wave_barrier();
+    // axis 1: B -> A
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    int has_nan = 0;
+    for (int f = lane; f < F; f += 64) {
+        const int i = f / S, j = f - i * S;
+#define BT(q) B[i * S + reflect_idx((q), S)]
+        const double v = PK_BLUR9(B[f], BT(j - 4), BT(j + 4), BT(j - 3), BT(j + 3), BT(j - 2),
+                                  BT(j + 2), BT(j - 1), BT(j + 1));
+#undef BT
+        A[f] = v;
+        has_nan |= (v != v) ? 1 : 0;
+        mn = (v < mn) ? v : mn;
+        mx = (v > mx) ? v : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double omn = __shfl_xor(mn, o), omx = __shfl_xor(mx, o);
+        mn = (omn < mn) ? omn : mn;
+        mx = (omx > mx) ? omx : mx;
+        has_nan |= __shfl_xor(has_nan, o);
+    }
+    if (has_nan) {
+        mn = __builtin_nan("");
+        mx = mn;
+    }
+    const double den = mx - mn;
+    const int64_t tile = local / blk;
+    const int tl = (int)(local - tile * blk);
+    float *tp = tiles + (size_t)tile * F * blk + tl;
+    for (int f = lane; f < F; f += 64) {
+        const double v = (A[f] - mn) / den;
+        tp[(size_t)f * blk] = (float)v;
+        if (fea64_rows) fea64_rows[(size_t)local * F + f] = v;
+    }
+    if (lane == 0) status[c] = 1;
+}
+
+}  // namespace
+
+int pk_launch_extract(pk_device_ctx *ctx, const pk_matrix *m, int w, const int32_t *d_x,
+                      const int32_t *d_y, int64_t c0, int64_t cn, float *tiles, int blk,
+                      uint8_t *d_status, double *fea64_rows)
+{
+    if (cn <= 0) return PK_OK;
+    pk_prof_scope prof(ctx, PK_K_EXTRACT);
+    if (w == 5 || w == 6) {
+        const int threads = 64;
+        const unsigned grid = (unsigned)((cn + threads - 1) / threads);
+        if (w == 5)
+            hipLaunchKernelGGL(extract_reg_kernel<5>, dim3(grid), dim3(threads), 0, ctx->stream,
+                               m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
+                               d_y, c0, cn, tiles, blk, d_status, fea64_rows);
+        else
+            hipLaunchKernelGGL(extract_reg_kernel<6>, dim3(grid), dim3(threads), 0, ctx->stream,
+                               m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
+                               d_y, c0, cn, tiles, blk, d_status, fea64_rows);
+    } else {
+        if (w < 1 || w > 15) {
+            pk_set_error("pk_extract: w=%d unsupported (1..15)", w);
+            return PK_E_UNSUPPORTED;
+        }
+        const int F = (2 * w + 1) * (2 * w + 1);
+        const size_t lds = (size_t)GEN_WAVES * 2 * F * sizeof(double);
+        const unsigned grid = (unsigned)((cn + GEN_WAVES - 1) / GEN_WAVES);
+        hipLaunchKernelGGL(extract_lds_kernel, dim3(grid), dim3(64 * GEN_WAVES), lds, ctx->stream,
+                           w, m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
+                           d_y, c0, cn, tiles, blk, d_status, fea64_rows);
+    }
+    PK_HIP(hipGetLastError());
+    return PK_OK;
+}

@@ -1,0 +1,197 @@
+"""Parity of the HIP path against the reference's golden vectors and the CPU
+oracle, through the C ABI.  Bit-exact: float64 features, pixel indices,
+probabilities, signal.  Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+import golden_io as gio
+from oracle import oracle_np as onp
+from peakachu_amd import _lib, synth, utils
+from peakachu_amd.forest import FlatForest
+
+pytestmark = pytest.mark.gpu
+
+
+def flat(fo):
+    return FlatForest(int(fo["F"]), fo["tree_off"], fo["left"], fo["right"], fo["feat"],
+                      fo["thr"], fo["miss_left"], fo["p1"])
+
+
+def hip_matrix(Mf, exp_arr, w, upper):
+    Mf = utils.canonical_csr(Mf)
+    return _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], exp_arr,
+                          -2 * w + 1, upper + 2 * w - 1)
+
+
+@pytest.mark.parametrize("name", ["g1_extract_w5.npz", "g1_extract_w6.npz", "g1_extract_w11.npz",
+                                  "g1_extract_w5_balanced.npz"])
+def test_extract_golden(hip_lib, name):
+    z = gio.load(name)
+    w, upper = int(z["w"]), int(z["upper"])
+    if "weights" in z.files:
+        M = gio.balance(gio.sym_matrix(z, "R"), z["weights"])
+    else:
+        M = gio.sym_matrix(z, "M")
+    Mf = utils.band_filter(M, w, upper)
+    assert gio.digest(Mf) == str(z["Mf_sha"])
+    ok = z["x"] <= z["y"]
+    x, y = z["x"][ok], z["y"][ok]
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper)
+    f64, f32, keep = hm.extract(w, x, y, want64=True, want32=True)
+    assert np.array_equal(np.stack([x[keep], y[keep]], 1), z["clist"])
+    assert np.array_equal(gio.bits(f64), gio.bits(z["fea"]))
+    assert np.array_equal(f32, z["fea"].astype(np.float32))
+
+
+@pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
+@pytest.mark.parametrize("ilp,lds", [(4, 0), (1, 0), (8, 0), (4, 24), (2, 8)])
+def test_forest_golden(hip_lib, tag, ilp, lds):
+    z = gio.load("g2_forest_%s.npz" % tag)
+    X = gio.load("g2_forest_plain.npz")["X"]
+    _lib.set_option("forest_ilp", ilp)
+    _lib.set_option("forest_lds", lds)
+    try:
+        hf = _lib.HipForest(flat(gio.forest(z)))
+        p = hf.predict(X)
+    finally:
+        _lib.set_option("forest_ilp", 4)
+        _lib.set_option("forest_lds", 0)
+    assert np.array_equal(gio.bits(p), gio.bits(z["p"]))
+
+
+def _g3_matrix(z):
+    raw = gio.sym_matrix(z, "R")
+    mode = str(z["mode"])
+    if mode == "raw":
+        return raw
+    if mode == "weights":
+        return gio.balance(raw, z["weights"])
+    return gio.hicstyle(raw, z["weights"])
+
+
+@pytest.mark.parametrize("name", ["g3_score_raw.npz", "g3_score_raw_minprob0.npz",
+                                  "g3_score_weights.npz", "g3_score_hicstyle.npz"])
+def test_score_golden(hip_lib, name):
+    z = gio.load(name)
+    w, upper = int(z["w"]), int(z["upper"])
+    Mf = utils.band_filter(_g3_matrix(z), w, upper)
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper)
+    hf = _lib.HipForest(flat(gio.forest(str(z["forest"]))))
+    ox, oy, op, osig = hm.score(hf, w, float(z["thre"]), z["ridx"], z["cidx"])
+    order = np.lexsort((oy, ox))
+    assert np.array_equal(ox[order], z["ri"]) and np.array_equal(oy[order], z["ci"])
+    assert np.array_equal(gio.bits(op[order]), gio.bits(z["prob"]))
+    assert np.array_equal(gio.bits(osig[order]), gio.bits(z["signal"]))
+
+
+def test_batch_quirk_golden(hip_lib):
+    z = gio.load("g4_batch_quirk.npz")
+    w, upper = int(z["w"]), int(z["upper"])
+    Mf = utils.band_filter(gio.sym_matrix(z, "R"), w, upper)
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper)
+    hf = _lib.HipForest(flat(gio.forest(str(z["forest"]))))
+    hot = z["hot"]
+    ox, oy, op, osig = hm.score(hf, w, 0.5, hot[:1], hot[1:])
+    assert ox.size == 0
+    ox, oy, op, osig = hm.score(hf, w, 0.5, z["bx"], z["by"])
+    order = np.lexsort((oy, ox))
+    assert np.array_equal(ox[order], z["b_ri"]) and np.array_equal(oy[order], z["b_ci"])
+    assert np.array_equal(gio.bits(op[order]), gio.bits(z["b_prob"]))
+    assert np.array_equal(gio.bits(osig[order]), gio.bits(z["b_signal"]))
+
+
+@pytest.mark.parametrize("w,seed,batch", [(5, 1, 100000), (5, 2, 777), (6, 3, 5000), (11, 4, 100000)])
+def test_score_vs_oracle_synthetic(hip_lib, w, seed, batch):
+    """Seeded synthetic band matrix, every non-zero band pixel a candidate,
+    a forest trained here on the fly is not needed: reuse the golden forest
+    for w=5 and a random forest of matching width otherwise."""
+    upper = 70
+    M, loops = synth.synth_band(900 if w < 11 else 400, 90, seed=seed)
+    exp_arr = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    if w == 11:
+        x, y = x[::7], y[::7]
+    F = (2 * w + 1) ** 2
+    fo = gio.forest("g2_forest_plain.npz") if w == 5 else random_forest_arrays(F, 40, seed)
+    hm = hip_matrix(Mf, exp_arr, w, upper)
+    hf = _lib.HipForest(flat(fo))
+    ox, oy, op, osig = hm.score(hf, w, 0.3, x, y, batch=batch)
+    rx, ry, rp, rs = onp.score(Mf, exp_arr, w, fo, 0.3, x, y, batch=batch, threads=8)
+    assert rx.size > 10
+    assert np.array_equal(ox, rx) and np.array_equal(oy, ry)
+    assert np.array_equal(gio.bits(op), gio.bits(rp))
+    assert np.array_equal(gio.bits(osig), gio.bits(rs))
+
+
+def random_forest_arrays(F, T, seed, depth=9):
+    """Random (untrained) trees in sklearn's array layout: enough to check
+    that walk + accumulation agree with the oracle on any forest."""
+    rng = np.random.default_rng(seed)
+    offs, left, right, feat, thr, miss, p1 = [0], [], [], [], [], [], []
+    for _ in range(T):
+        l, r, f, t, m, p = [], [], [], [], [], []
+
+        def grow(d):
+            i = len(l)
+            l.append(-1); r.append(-1); f.append(-2); t.append(-2.0); m.append(0)
+            p.append(float(rng.integers(0, 5)) / 4.0)
+            if d < depth and (d < 2 or rng.random() < 0.75):
+                f[i] = int(rng.integers(0, F)); t[i] = float(rng.random()); m[i] = int(rng.integers(0, 2))
+                l[i] = grow(d + 1)
+                r[i] = grow(d + 1)
+            return i
+        grow(0)
+        left += l; right += r; feat += f; thr += t; miss += m; p1 += p
+        offs.append(len(left))
+    return dict(tree_off=np.array(offs, np.int32), left=np.array(left, np.int32),
+                right=np.array(right, np.int32), feat=np.array(feat, np.int32),
+                thr=np.array(thr, np.float64), miss_left=np.array(miss, np.uint8),
+                p1=np.array(p1, np.float64), F=np.int32(F))
+
+
+def test_empty_and_edge_inputs(hip_lib):
+    z = gio.load("g3_score_raw.npz")
+    w, upper = int(z["w"]), int(z["upper"])
+    Mf = utils.band_filter(gio.sym_matrix(z, "R"), w, upper)
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper)
+    hf = _lib.HipForest(flat(gio.forest(str(z["forest"]))))
+    e = np.zeros(0, np.int32)
+    assert hm.score(hf, w, 0.5, e, e)[0].size == 0
+    n = Mf.shape[0]
+    # windows that leave the matrix are skipped, not errors (scoreUtils.py:75)
+    x = np.array([0, 2, n - 30, n - 3], np.int32)
+    y = np.array([10, 12, n - 2, n - 1], np.int32)
+    f64, _, keep = hm.extract(w, x, y)
+    assert keep.size == 0
+    with pytest.raises(_lib.PeakachuHipError):
+        hm.extract(w, np.array([50], np.int32), np.array([40], np.int32))  # x > y
+    with pytest.raises(_lib.PeakachuHipError):
+        hm.extract(w, np.array([50], np.int32), np.array([n], np.int32))   # outside
+
+
+def test_chromosome_drop_in(hip_lib, tmp_path):
+    """The mirror class reproduces the reference's bedpe text byte for byte."""
+    from peakachu_amd import scoreUtils
+    for name in ["g3_score_raw.npz", "g3_score_weights.npz", "g3_score_hicstyle.npz",
+                 "g3_score_raw_minprob0.npz"]:
+        z = gio.load(name)
+        raw = gio.sym_matrix(z, "R")
+        mode = str(z["mode"])
+        model = flat(gio.forest(str(z["forest"])))
+        kw = dict(lower=int(z["lower"]), upper=int(z["upper"]), cname=str(z["cname"]),
+                  res=int(z["res"]), width=int(z["w"]))
+        if mode == "raw":
+            ch = scoreUtils.Chromosome(raw, model, raw_M=raw, weights=None, **kw)
+        elif mode == "weights":
+            ch = scoreUtils.Chromosome(gio.balance(raw, z["weights"]), model, raw_M=raw,
+                                       weights=z["weights"], **kw)
+        else:
+            ch = scoreUtils.Chromosome(gio.hicstyle(raw, z["weights"]), model, raw_M=raw,
+                                       weights=None, **kw)
+        assert np.array_equal(ch.ridx, z["ridx"]) and np.array_equal(ch.cidx, z["cidx"])
+        result, R = ch.score(thre=float(z["thre"]))
+        out = tmp_path / (name + ".bedpe")
+        ch.writeBed(str(out), result, R)
+        text = out.read_text() if out.exists() else ""
+        assert text == str(z["bedpe"])
