@@ -1,0 +1,282 @@
+#!/usr/bin/env python
+"""Headline benchmark: candidate pixels scored per second on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic 30 000 x 30 000 band-diagonal
+contact matrix (200-bin = 2 Mb band at 10 kb), w = 5 (11x11 windows, 121
+features), 100-tree Random Forest, every non-zero band pixel with
+6 <= col-row <= 200 a candidate (about 5.6 M), threshold 0.5, reference batch
+size 100 000.  One step = one pass of the hot path (extract -> forest ->
+threshold/compact [-> RCCL gather of the scored pixels when N > 1]) over the
+candidate list, with matrix, forest and candidates already resident in HBM.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scores
+its own synthetic chromosome (weak scaling; chromosomes shard embarrassingly,
+peakachu/score_genome.py:46-84) and rank 0 collects the scored pixels with
+one RCCL gather.  torch.distributed (gloo) is used only for the rendezvous,
+the barriers and the max-over-ranks of the timings.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def b_alg(F):
+    """Algorithmic bytes per candidate: 8F window cells +
+    4F feature write + 4F feature read + 8 coords + 8 prob."""
+    return 16 * F + 16
+
+
+def build_workload(seed, n, band, w, lower, upper):
+    from peakachu_amd import synth, utils
+    M, _ = synth.synth_band(n, band, seed=seed)
+    upper = min(upper, n - 2 * w)
+    exp_arr = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, max(lower, w + 1), upper)
+    return Mf, exp_arr, x, y, upper
+
+
+def host_cores():
+    """CPU threads this process may really use: the affinity mask capped by
+    the cgroup CPU quota (the GPU box gives one GPU's job a share of the host)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    cores = min(cores, max(1, q // per))
+            break
+        except Exception:
+            continue
+    env = os.environ.get("PK_BENCH_CPU_THREADS")
+    if env:
+        cores = int(env)
+    return cores
+
+
+def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, target_s=15.0):
+    """The CPU oracle (a port of the reference's algorithm, bit-exact against
+    its golden vectors) timed on this box's host cores on a strided sample of
+    the same candidate list."""
+    from oracle import oracle_np as onp
+    from peakachu_amd.forest import FlatForest
+    fod = {k: getattr(fo, k) for k in FlatForest.FIELDS}
+    cores = host_cores()
+    N = x.size
+    m, dt, xs = 50000, 0.0, x
+    for _ in range(4):  # grow the sample until it costs about target_s of wall time
+        stride = max(1, N // max(1, m))
+        xs, ys = x[::stride], y[::stride]
+        t0 = time.perf_counter()
+        onp.score(Mf, exp_arr, w, fod, thre, xs, ys, batch=batch, threads=cores)
+        dt = time.perf_counter() - t0
+        if dt >= 0.6 * target_s or xs.size >= N:
+            break
+        m = int(min(N, xs.size * min(10.0, 1.1 * target_s / max(dt, 1e-3))))
+    return dict(value=xs.size / dt, unit="candidates/s", cores=cores, kind="port",
+                sample="every %d-th candidate of the workload (%d of %d), %.1f s wall, "
+                       "oracle/pk_oracle.c pko_score_mt with OpenMP over candidates"
+                       % (stride, xs.size, N, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=30000)
+    ap.add_argument("--band", type=int, default=200)
+    ap.add_argument("-w", type=int, default=5)
+    ap.add_argument("--thre", type=float, default=0.5)
+    ap.add_argument("--batch", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "(--nproc-per-node %d)" % (a.gpus, a.gpus))
+        a.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+
+    from peakachu_amd import _lib
+    from peakachu_amd.forest import FlatForest
+    L = _lib.require_device()
+    dev = local_rank
+    for kv in a.opt:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
+
+    w = a.w
+    F = (2 * w + 1) ** 2
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w%d_t100.npz" % w))
+    # weak scaling: rank r scores its own synthetic chromosome (seed r)
+    Mf, exp_arr, x, y, upper = build_workload(rank, a.n, a.band, w, 6, a.band)
+    t0 = time.perf_counter()
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], exp_arr,
+                        -2 * w + 1, upper + 2 * w - 1, device=dev)
+    hf = _lib.HipForest(fo, device=dev)
+    cd = _lib.HipCands(x, y, device=dev)
+    _lib.check(L.pk_device_synchronize(dev), "sync")
+    upload_s = time.perf_counter() - t0
+
+    comm = None
+    if world > 1:
+        ids = [None]
+        if rank == 0:
+            buf = np.zeros(128, np.uint8)
+            _lib.check(L.pk_comm_unique_id(buf), "pk_comm_unique_id")
+            ids = [buf.tobytes()]
+        dist.broadcast_object_list(ids, src=0)
+        comm = L.pk_comm_create(dev, world, rank, np.frombuffer(ids[0], np.uint8).copy())
+        if not comm:
+            raise RuntimeError("pk_comm_create: " + _lib.last_error())
+    cap = int(x.size) * world
+    counts = np.zeros(world, np.int64)
+    if rank == 0 and world > 1:
+        gx = np.empty(cap, np.int32); gy = np.empty(cap, np.int32)
+        gp = np.empty(cap, np.float64); gs = np.empty(cap, np.float64)
+
+    def step():
+        n_out = cd.run(hm, hf, w, a.thre, a.batch)
+        if comm:
+            if rank == 0:
+                _lib.check(L.pk_comm_gather_scored(comm, cd.h, counts, cap, gx.ctypes.data,
+                                                   gy.ctypes.data, gp.ctypes.data,
+                                                   gs.ctypes.data), "gather")
+            else:
+                _lib.check(L.pk_comm_gather_scored(comm, cd.h, counts, 0, None, None, None,
+                                                   None), "gather")
+        return n_out
+
+    def sync():
+        _lib.check(L.pk_device_synchronize(dev), "sync")
+        if dist:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step()
+    L.pk_prof_enable(1)
+    L.pk_prof_reset()
+    sync()
+    t0 = time.perf_counter()
+    n_out = 0
+    for _ in range(a.steps):
+        n_out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    L.pk_prof_enable(0)
+    kern = {k: _lib.prof_get(k) for k in ("extract", "forest", "compact")}
+
+    n_local = int(x.size)
+    if dist:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        c = torch.tensor([n_local], dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n_total = int(c[0])
+    else:
+        n_total = n_local
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        value = n_total * a.steps / elapsed
+        # dominant kernel = the class with the most device time on rank 0
+        dom = max(("extract", "forest"), key=lambda k: kern[k][0])
+        dom_ms, dom_n = kern[dom]
+        alg_bytes_total = float(n_local) * a.steps * b_alg(F)
+        achieved = alg_bytes_total / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        fst = fo.stats()
+        out = {
+            "metric": "candidate pixels scored/sec",
+            "value": value,
+            "unit": "candidates/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "synthetic %dx%d band-diagonal (%d-bin band) CSR, w=%d, %d-tree RF, "
+                            "all non-zero band pixels 6<=d<=%d" % (a.n, a.n, a.band, w, fo.T, upper),
+                "candidates_per_gpu": n_local,
+                "features": F,
+                "trees": fo.T,
+                "nodes_per_tree_mean": round(fst["nodes_per_tree_mean"], 1),
+                "threshold": a.thre,
+                "reference_batch": a.batch,
+                "scored_pixels_rank0": int(n_out),
+                "parallelism": "chromosome-sharded x%d, one RCCL gather" % world,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "alg_bytes_per_candidate": b_alg(F),
+                "avg_launch_ms": dom_ms / dom_n if dom_n else None,
+                "launches": dom_n,
+                "candidates_per_launch": n_local * a.steps / dom_n if dom_n else None,
+            },
+            "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kern.items()},
+            "whole_path_alg_GBs": value * b_alg(F) / 1e9,
+            "upload_s": upload_s,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(Mf, exp_arr, w, fo, a.thre, x, y, a.batch)
+        print(json.dumps(out))
+        sys.stdout.flush()
+
+    if comm:
+        L.pk_comm_destroy(comm)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

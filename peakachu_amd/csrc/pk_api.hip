@@ -182,6 +182,11 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_lds = value;
     } else if (!strcmp(name, "extract_block")) {
         g_opt.extract_block = value;
+    } else if (!strcmp(name, "forest_slots")) {
+        if (value != 2 && value != 4 && value != 6 && value != 8) return PK_E_INVALID;
+        g_opt.forest_slots = value;
+    } else if (!strcmp(name, "forest_dbg")) {
+        g_opt.forest_dbg = value;
     } else {
         pk_set_error("unknown option '%s'", name);
         return PK_E_INVALID;
@@ -195,6 +200,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "chunk")) return g_opt.chunk;
     if (!strcmp(name, "forest_ilp")) return g_opt.forest_ilp;
     if (!strcmp(name, "forest_lds")) return g_opt.forest_lds;
+    if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
     if (!strcmp(name, "extract_block")) return g_opt.extract_block;
     return -1;
 }
@@ -256,10 +262,17 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
     std::vector<int32_t> root(T + 1);
     std::vector<int32_t> pos, stack, depth;
     int max_depth = 0, max_tree = 0;
-    auto put_leaf = [&](double v) {
+    auto leaf_word = [](double v) {
         uint64_t b;
         memcpy(&b, &v, 8);
-        nodes.push_back(make_uint2((unsigned)(b & 0xffffffffu), (unsigned)(b >> 32)));
+        return make_uint2((unsigned)(b & 0xffffffffu), (unsigned)(b >> 32));
+    };
+    auto leaf_kind = [](double v) -> unsigned {
+        uint64_t b;
+        memcpy(&b, &v, 8);
+        if (b == 0) return PK_KIND_ZERO;                     // +0.0
+        if (v == 1.0) return PK_KIND_ONE;
+        return PK_KIND_LEAF;
     };
     for (int t = 0; t < T; t++) {
         const int32_t base = tree_off[t], nn = tree_off[t + 1] - base;
@@ -267,56 +280,56 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
             pk_set_error("pk_forest_create: tree %d is empty", t);
             return nullptr;
         }
+        if (nodes.size() & 1) nodes.push_back(make_uint2(0, 0));  // even start
         root[t] = (int32_t)nodes.size();
         if (left[base] == -1) {
-            // a one-leaf tree: give it a root whose two children are that leaf
-            const unsigned pk = (1u << PK_NODE_MISS_BIT) | (1u << PK_NODE_LLEAF_BIT) |
-                                (1u << PK_NODE_RLEAF_BIT) | (2u << PK_NODE_ROFF_SHIFT);
+            // a one-leaf tree: a root that sends everything to that leaf
+            const unsigned kind = leaf_kind(p1[base]);
+            unsigned pk = (1u << PK_NODE_MISS_BIT) | (kind << PK_NODE_LKIND_SHIFT) |
+                          (kind << PK_NODE_RKIND_SHIFT) | (1u << PK_NODE_ROFF_SHIFT);
             float inf = INFINITY;
             unsigned tb;
             memcpy(&tb, &inf, 4);
             nodes.push_back(make_uint2(tb, pk));
-            put_leaf(p1[base]);
-            put_leaf(p1[base]);
-            if (max_tree < 3) max_tree = 3;
+            if (kind == PK_KIND_LEAF) nodes.push_back(leaf_word(p1[base]));
+            if (max_tree < 2) max_tree = 2;
             continue;
         }
-        // preorder positions (left child first)
+        // preorder word positions (left subtree first); pure leaves get none
         pos.assign(nn, -1);
         depth.assign(nn, 0);
         stack.clear();
         stack.push_back(0);
-        int32_t next = 0;
+        int32_t next = 0, visited = 0;
         while (!stack.empty()) {
             const int32_t v = stack.back();
             stack.pop_back();
-            if (v < 0 || v >= nn || pos[v] != -1 || next >= nn) {
+            if (v < 0 || v >= nn || pos[v] != -1 || ++visited > nn) {
                 pk_set_error("pk_forest_create: tree %d is malformed at node %d", t, v);
                 return nullptr;
             }
-            pos[v] = next++;
             if (depth[v] > max_depth) max_depth = depth[v];
             const int32_t l = left[base + v], r = right[base + v];
-            if (l != -1) {
-                if (l < 0 || l >= nn || r < 0 || r >= nn) {
-                    pk_set_error("pk_forest_create: tree %d node %d has bad children", t, v);
-                    return nullptr;
-                }
-                depth[l] = depth[r] = depth[v] + 1;
-                stack.push_back(r);
-                stack.push_back(l);
+            if (l == -1) {
+                pos[v] = (leaf_kind(p1[base + v]) == PK_KIND_LEAF) ? next++ : -2;
+                continue;
             }
+            pos[v] = next++;
+            if (l < 0 || l >= nn || r < 0 || r >= nn) {
+                pk_set_error("pk_forest_create: tree %d node %d has bad children", t, v);
+                return nullptr;
+            }
+            depth[l] = depth[r] = depth[v] + 1;
+            stack.push_back(r);
+            stack.push_back(l);
         }
         const size_t tree_base = nodes.size();
         nodes.resize(tree_base + (size_t)next);
         for (int32_t v = 0; v < nn; v++) {
-            if (pos[v] < 0) continue;  // unreachable node
+            if (pos[v] < 0) continue;  // unreachable node or pure leaf
             const int32_t l = left[base + v], r = right[base + v];
             if (l == -1) {
-                uint64_t b;
-                memcpy(&b, &p1[base + v], 8);
-                nodes[tree_base + pos[v]] =
-                    make_uint2((unsigned)(b & 0xffffffffu), (unsigned)(b >> 32));
+                nodes[tree_base + pos[v]] = leaf_word(p1[base + v]);
                 continue;
             }
             const int32_t f = feat[base + v];
@@ -324,16 +337,22 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
                 pk_set_error("pk_forest_create: tree %d node %d feature %d out of range", t, v, f);
                 return nullptr;
             }
-            const int64_t roff = (int64_t)pos[r] - pos[v];
-            if (pos[l] != pos[v] + 1 || roff <= 0 || roff >= (1 << (32 - PK_NODE_ROFF_SHIFT))) {
-                pk_set_error("pk_forest_create: tree %d too large (right offset %lld)", t,
-                             (long long)roff);
+            const unsigned lk = left[base + l] == -1 ? leaf_kind(p1[base + l]) : PK_KIND_NODE;
+            const unsigned rk = left[base + r] == -1 ? leaf_kind(p1[base + r]) : PK_KIND_NODE;
+            int64_t roff = 0;
+            if (lk <= PK_KIND_LEAF && pos[l] != pos[v] + 1) roff = -1;
+            if (rk <= PK_KIND_LEAF) {
+                if (roff == 0) roff = (int64_t)pos[r] - pos[v];
+                if (roff <= 0 || roff >= (1 << (32 - PK_NODE_ROFF_SHIFT))) roff = -1;
+            }
+            if (roff < 0) {
+                pk_set_error("pk_forest_create: tree %d too large or inconsistent at node %d", t, v);
                 return nullptr;
             }
             unsigned pk = (unsigned)f;
             if (miss_left && miss_left[base + v]) pk |= 1u << PK_NODE_MISS_BIT;
-            if (left[base + l] == -1) pk |= 1u << PK_NODE_LLEAF_BIT;
-            if (left[base + r] == -1) pk |= 1u << PK_NODE_RLEAF_BIT;
+            pk |= lk << PK_NODE_LKIND_SHIFT;
+            pk |= rk << PK_NODE_RKIND_SHIFT;
             pk |= (unsigned)roff << PK_NODE_ROFF_SHIFT;
             const float t32 = floor_to_f32(thr[base + v]);
             unsigned tb;
@@ -342,6 +361,7 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
         }
         if (next > max_tree) max_tree = next;
     }
+    if (nodes.size() & 1) nodes.push_back(make_uint2(0, 0));
     root[T] = (int32_t)nodes.size();
 
     pk_forest *fo = new pk_forest();
@@ -354,7 +374,7 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
     fo->nodes = nullptr;
     fo->root = nullptr;
     fo->h_root = root;
-    if (hipMalloc((void **)&fo->nodes, nodes.size() * sizeof(uint2)) != hipSuccess ||
+    if (hipMalloc((void **)&fo->nodes, (nodes.size() + 2) * sizeof(uint2)) != hipSuccess ||
         hipMalloc((void **)&fo->root, root.size() * sizeof(int32_t)) != hipSuccess) {
         pk_set_error("pk_forest_create: device allocation failed");
         pk_forest_destroy(fo);

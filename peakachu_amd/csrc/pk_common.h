@@ -51,9 +51,11 @@ int pk_ctx_reserve_scan(pk_device_ctx *, size_t bytes);
 // ------------------------------------------------------------------ options
 struct pk_options {
     int64_t chunk = 262144;     // candidates per extract/forest launch pair
-    int64_t forest_ilp = 4;     // trees walked concurrently per lane
-    int64_t forest_lds = 0;     // stage tree nodes through LDS (0 = read via L2)
+    int64_t forest_ilp = 4;     // L2 kernel: trees walked concurrently per lane
+    int64_t forest_slots = 8;   // LDS kernel: tree slots (wave pairs) per workgroup
+    int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
     int64_t extract_block = 64; // threads per extract block
+    int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
 };
 extern pk_options g_opt;
 
@@ -70,19 +72,29 @@ struct pk_prof_scope {
 };
 
 // ------------------------------------------------------------------ handles
-// Forest node word (8 bytes).  Interior node: {thr32, packed}; leaf: the
-// float64 class-1 fraction.  Nodes of one tree are stored in preorder, so the
-// left child of node i is i+1 and only the right child's offset is stored.
-//   packed bits  0..9  feature index (F <= 1024)
-//               10     NaN goes left
-//               11     left child is a leaf
-//               12     right child is a leaf
-//               13..31 offset of the right child from this node (< 2^19)
+// Forest node word (8 bytes).  Interior node: {thr32, packed}; stored leaf:
+// the float64 class-1 fraction.  A tree's words are in preorder; leaves whose
+// value is exactly 0.0 or 1.0 ("pure", >90 % of the leaves of a grown forest)
+// get no word at all -- the parent's kind field says which.  So the left
+// child, if it has a word, is the next word, and the right child's word is
+// `roff` words further (roff = 1 + words of the left subtree).
+//   packed bits  0..9   feature index (F <= 1024)
+//               10      NaN goes left
+//               11..12  kind of the left child
+//               13..14  kind of the right child
+//               15..31  roff (< 2^17)
+//   kind: 0 interior word, 1 stored leaf word, 2 pure leaf 0.0, 3 pure leaf 1.0
+// Every tree starts on an even word (16-byte aligned) so groups of trees can
+// be copied into LDS with 16-byte accesses.
 #define PK_NODE_FEAT_BITS 10
 #define PK_NODE_MISS_BIT 10
-#define PK_NODE_LLEAF_BIT 11
-#define PK_NODE_RLEAF_BIT 12
-#define PK_NODE_ROFF_SHIFT 13
+#define PK_NODE_LKIND_SHIFT 11
+#define PK_NODE_RKIND_SHIFT 13
+#define PK_NODE_ROFF_SHIFT 15
+#define PK_KIND_NODE 0u
+#define PK_KIND_LEAF 1u
+#define PK_KIND_ZERO 2u
+#define PK_KIND_ONE 3u
 
 struct pk_forest {
     int device;

@@ -30,12 +30,48 @@ __global__ void band_build_kernel(const int32_t *__restrict__ indptr,
 }
 
 // ---- survivors per reference batch (scoreUtils.py:104-108) --------------
+// One workgroup counts 4096 consecutive candidates: wave ballots, one LDS
+// add per wave, one global atomic per workgroup and batch it touches (a
+// workgroup straddles at most two batches when batch >= 4096; smaller
+// batches fall back to per-candidate atomics).
+constexpr int BC_ITEMS = 16;
 __global__ void batch_count_kernel(const uint8_t *__restrict__ status, int64_t N, int64_t batch,
                                    int32_t *__restrict__ batch_cnt)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= N) return;
-    if (status[c]) atomicAdd(&batch_cnt[c / batch], 1);
+    __shared__ int cnt[2];
+    const int64_t base = (int64_t)blockIdx.x * (256 * BC_ITEMS);
+    const int64_t b0 = base / batch;
+    if (batch < 256 * BC_ITEMS) {
+        for (int i = 0; i < BC_ITEMS; i++) {
+            const int64_t c = base + (int64_t)i * 256 + threadIdx.x;
+            if (c < N && status[c]) atomicAdd(&batch_cnt[c / batch], 1);
+        }
+        return;
+    }
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int mine0 = 0, mine1 = 0;
+    for (int i = 0; i < BC_ITEMS; i++) {
+        const int64_t c = base + (int64_t)i * 256 + threadIdx.x;
+        if (c < N && status[c]) {
+            if (c / batch == b0) mine0++;
+            else mine1++;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mine0 += __shfl_xor(mine0, o);
+        mine1 += __shfl_xor(mine1, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mine0) atomicAdd(&cnt[0], mine0);
+        if (mine1) atomicAdd(&cnt[1], mine1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (cnt[0]) atomicAdd(&batch_cnt[b0], cnt[0]);
+        if (cnt[1]) atomicAdd(&batch_cnt[b0 + 1], cnt[1]);
+    }
 }
 
 constexpr int CB = 256;          // threads per compaction block
@@ -176,7 +212,8 @@ int pk_launch_compact(pk_device_ctx *ctx, const pk_matrix *m, pk_cands *cd, doub
     pk_prof_scope prof(ctx, PK_K_COMPACT);
     const int64_t nb = (N + batch - 1) / batch;
     PK_HIP(hipMemsetAsync(cd->batch_cnt, 0, sizeof(int32_t) * (size_t)nb, ctx->stream));
-    hipLaunchKernelGGL(batch_count_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(batch_count_kernel,
+                       dim3((unsigned)((N + 256 * BC_ITEMS - 1) / (256 * BC_ITEMS))), dim3(256), 0,
                        ctx->stream, cd->status, N, batch, cd->batch_cnt);
     const int64_t nblocks = (N + CTILE - 1) / CTILE;
     int rc = pk_ctx_reserve_scan(ctx, sizeof(int64_t) * (size_t)nblocks);

@@ -24,26 +24,38 @@
 
 namespace {
 
-__device__ __forceinline__ double node_as_double(uint2 n)
+__device__ __forceinline__ double word_as_double(uint2 n)
 {
     return __longlong_as_double(((long long)n.y << 32) | (long long)n.x);
 }
 
-// one step of one chain: `n` is the interior node at `idx`
-__device__ __forceinline__ void step(uint2 n, const float *fea, int blk, int lane, int &idx,
-                                     bool &at_leaf)
+// value of a finished chain: `kind` of the child it stepped to, `w` that
+// child's word (only meaningful for a stored leaf)
+__device__ __forceinline__ double leaf_value(unsigned kind, uint2 w)
 {
-    const unsigned pk = n.y;
-    const float x = fea[(pk & ((1u << PK_NODE_FEAT_BITS) - 1)) * blk + lane];
-    const float thr = __uint_as_float(n.x);
-    const bool miss = (pk >> PK_NODE_MISS_BIT) & 1u;
-    const bool go_left = (x <= thr) || ((x != x) && miss);
-    at_leaf = go_left ? ((pk >> PK_NODE_LLEAF_BIT) & 1u) : ((pk >> PK_NODE_RLEAF_BIT) & 1u);
-    idx += go_left ? 1 : (int)(pk >> PK_NODE_ROFF_SHIFT);
+    return kind == PK_KIND_LEAF ? word_as_double(w) : (kind == PK_KIND_ONE ? 1.0 : 0.0);
+}
+
+// sklearn's split: x <= thr goes left; NaN goes where missing_go_to_left says.
+// Bitwise, so no branch is generated for the (rare) NaN case.
+__device__ __forceinline__ bool goes_left(float x, uint2 n)
+{
+    const bool le = x <= __uint_as_float(n.x);
+    const bool nan_left = (x != x) & (((n.y >> PK_NODE_MISS_BIT) & 1u) != 0);
+    return le | nan_left;
+}
+
+__device__ __forceinline__ unsigned node_feat(uint2 n) { return n.y & ((1u << PK_NODE_FEAT_BITS) - 1); }
+__device__ __forceinline__ int node_roff(uint2 n) { return (int)(n.y >> PK_NODE_ROFF_SHIFT); }
+__device__ __forceinline__ unsigned node_kind(uint2 n, bool left)
+{
+    return (n.y >> (left ? PK_NODE_LKIND_SHIFT : PK_NODE_RKIND_SHIFT)) & 3u;
 }
 
 // ------------------------------------------------------------------------
 // v1: nodes read through the cache hierarchy, ILP trees in flight per lane.
+// Kept for feature counts whose tile leaves no room for an LDS tree buffer
+// (w = 11) and as an independent second implementation for the tests.
 // ------------------------------------------------------------------------
 template <int ILP>
 __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
@@ -72,11 +84,11 @@ __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t 
     double acc = 0.0;
     for (int t = 0; t < T; t += ILP) {
         int idx[ILP];
-        bool leaf[ILP];
+        unsigned kind[ILP];
 #pragma unroll
         for (int k = 0; k < ILP; k++) {
             idx[k] = root[min(t + k, T - 1)];
-            leaf[k] = false;
+            kind[k] = PK_KIND_NODE;
         }
         bool all_done = false;
         while (!all_done) {
@@ -86,13 +98,18 @@ __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t 
             all_done = true;
 #pragma unroll
             for (int k = 0; k < ILP; k++) {
-                if (!leaf[k]) step(nd[k], fea, blk, lane, idx[k], leaf[k]);
-                all_done = all_done && leaf[k];
+                if (kind[k] == PK_KIND_NODE) {
+                    const float x = fea[node_feat(nd[k]) * blk + lane];
+                    const bool gl = goes_left(x, nd[k]);
+                    kind[k] = node_kind(nd[k], gl);
+                    idx[k] += gl ? 1 : node_roff(nd[k]);
+                }
+                all_done = all_done && (kind[k] != PK_KIND_NODE);
             }
         }
         double v[ILP];
 #pragma unroll
-        for (int k = 0; k < ILP; k++) v[k] = node_as_double(nodes[idx[k]]);
+        for (int k = 0; k < ILP; k++) v[k] = leaf_value(kind[k], nodes[idx[k]]);
 #pragma unroll
         for (int k = 0; k < ILP; k++)
             if (t + k < T) acc += v[k];  // tree order: sklearn's sequential sum
@@ -101,78 +118,188 @@ __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t 
 }
 
 // ------------------------------------------------------------------------
-// v2: trees staged through LDS.  The workgroup copies a group of whole trees
-// (as many as fit `tree_lds_words`) into LDS, every lane walks them, repeat.
-// Trees larger than the staging buffer are walked from global memory.
+// v2: trees streamed through LDS.
+//
+// A workgroup owns LDS_C = 128 candidates (feature tile [F][128], 62 KB at
+// F = 121) and 2*SLOTS waves.  Wave pair s (= wave >> 1) is "tree slot" s: its
+// two waves cover the 128 candidates and walk the same tree, so node reads
+// near the root are LDS broadcasts.  Trees are copied into LDS in groups of up
+// to SLOTS whole trees; slot s walks tree s of the group, leaf values are
+// parked in LDS and the slot-0 lanes add them in tree order -- the same
+// sequential float64 sum sklearn computes.
+//
+// One LDS round trip per tree level: as soon as a node word is known, the
+// lane issues the feature read AND the reads of both child words (left =
+// next word, right = roff words on); when they return it picks the child, so
+// the next level's node never costs a second dependent LDS access.
+//
+// The walk is instruction-issue bound (about 16 VALU per level), so
+// parallelism comes from waves (SLOTS up to 8 = 16 waves per CU), not from
+// several chains per lane, and the NaN routing (missing_go_to_left) is only
+// compiled into a slow path taken by waves that actually hold a NaN feature.
+//
+// Staging overlaps the walk: each thread loads its share of the NEXT group
+// into registers before walking the current one and writes it to LDS after
+// the barrier that ends the walk.
 // ------------------------------------------------------------------------
-template <int ILP>
-__global__ void forest_lds_kernel(const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
-                                  int T, int F, const float *__restrict__ tiles,
-                                  const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
-                                  double *__restrict__ prob, int tree_lds_words)
+constexpr int LDS_C = 128;
+
+template <bool WITH_NAN>
+__device__ __forceinline__ double walk_tree_lds(const char *fea_b, int cl4, const char *a)
 {
-    extern __shared__ __attribute__((aligned(16))) float fea[];  // [F][blk] then tree buffer
-    const int blk = blockDim.x;
-    const int lane = threadIdx.x;
-    const int64_t tile = blockIdx.x;
-    uint2 *tbuf = reinterpret_cast<uint2 *>(fea + (size_t)F * blk);
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(tiles + (size_t)tile * F * blk);
-        float4 *dst = reinterpret_cast<float4 *>(fea);
-        const int nvec = F * blk / 4;
-        for (int i = lane; i < nvec; i += blk) dst[i] = src[i];
+    // a: LDS byte address of the current node word
+    uint2 cur = *reinterpret_cast<const uint2 *>(a);
+    uint2 nxt;
+    unsigned kind;
+    do {
+        const unsigned pk = cur.y;
+        const float x = *reinterpret_cast<const float *>(fea_b + (((pk & 1023u) << 9) | cl4));
+        const char *ra = a + ((pk >> PK_NODE_ROFF_SHIFT) << 3);
+        const uint2 lw = *reinterpret_cast<const uint2 *>(a + 8);
+        const uint2 rw = *reinterpret_cast<const uint2 *>(ra);
+        bool gl = x <= __uint_as_float(cur.x);
+        if (WITH_NAN) gl = gl | ((x != x) & (((pk >> PK_NODE_MISS_BIT) & 1u) != 0));
+        kind = (pk >> (gl ? PK_NODE_LKIND_SHIFT : PK_NODE_RKIND_SHIFT)) & 3u;
+        nxt.x = gl ? lw.x : rw.x;
+        nxt.y = gl ? lw.y : rw.y;
+        a = gl ? a + 8 : ra;
+        cur = nxt;
+    } while (kind == PK_KIND_NODE);
+    return leaf_value(kind, nxt);
+}
+
+// generic (global-memory) walk of one tree, for trees too large to stage
+__device__ __forceinline__ double walk_tree_global(const uint2 *__restrict__ base, int idx,
+                                                   const float *fea, int cl)
+{
+    unsigned kind;
+    uint2 nd;
+    do {
+        nd = base[idx];
+        const float x = fea[node_feat(nd) * LDS_C + cl];
+        const bool gl = goes_left(x, nd);
+        kind = node_kind(nd, gl);
+        idx += gl ? 1 : node_roff(nd);
+    } while (kind == PK_KIND_NODE);
+    return leaf_value(kind, base[idx]);
+}
+
+// The next tree group travels global -> registers (prefetch, issued before the
+// current group is walked) -> LDS (commit, after the barrier ending the walk).
+template <int PF, int THREADS>
+__device__ __forceinline__ void group_prefetch(uint4 (&pf)[PF], const uint2 *__restrict__ nodes,
+                                               const int32_t *__restrict__ root, int t, int t1,
+                                               int tree_words, int tid)
+{
+    const int g0 = root[t];
+    const int nv = (root[t1] - g0) >> 1;
+    if (nv * 2 > tree_words) return;  // a giant tree is walked from global memory
+    const uint4 *src = reinterpret_cast<const uint4 *>(nodes + g0);
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+        const int i = tid + q * THREADS;
+        pf[q] = i < nv ? src[i] : make_uint4(0, 0, 0, 0);
     }
-    const int64_t local = tile * blk + lane;
+}
+
+template <int PF, int THREADS>
+__device__ __forceinline__ void group_commit(const uint4 (&pf)[PF], uint2 *tbuf,
+                                             const int32_t *__restrict__ root, int t, int t1,
+                                             int tree_words, int tid)
+{
+    const int nv = (root[t1] - root[t]) >> 1;
+    if (nv * 2 > tree_words) return;
+    uint4 *dst = reinterpret_cast<uint4 *>(tbuf);
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+        const int i = tid + q * THREADS;
+        if (i < nv) dst[i] = pf[q];
+    }
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
+    const uint2 *__restrict__ nodes, const int32_t *__restrict__ root, int T, int F,
+    const float *__restrict__ tiles, const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
+    double *__restrict__ prob, int tree_words, int dbg)
+{
+    constexpr int THREADS = LDS_C * SLOTS;
+    // registers per thread for the prefetched group: the launcher keeps
+    // tree_words <= THREADS * PF * 2
+    constexpr int PF = 8;
+    extern __shared__ __attribute__((aligned(16))) float fea[];  // [F][128] | val | trees
+    double *val = reinterpret_cast<double *>(fea + (size_t)F * LDS_C);  // [SLOTS][128]
+    uint2 *tbuf = reinterpret_cast<uint2 *>(val + SLOTS * LDS_C);       // tree_words + 2 pad
+    const int tid = threadIdx.x;
+    const int cl = tid & (LDS_C - 1);
+    const int slot = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform -> SGPR
+    const int64_t tile = blockIdx.x;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(tiles + (size_t)tile * F * LDS_C);
+        float4 *dst = reinterpret_cast<float4 *>(fea);
+        const int nvec = F * LDS_C / 4;
+        for (int i = tid; i < nvec; i += THREADS) dst[i] = src[i];
+    }
+    const int64_t local = tile * LDS_C + cl;
     const bool valid = local < cn;
     const int64_t c = c0 + (valid ? local : 0);
     const bool active = valid && status[c];
-    double acc = 0.0;
-    int t = 0;
-    while (t < T) {  // T, root[] are uniform: every thread takes the same trips
-        // group = trees t..t1-1 whose nodes [root[t], root[t1]) fit the buffer
+
+    // group g = trees [t, t1): as many whole trees as fit, at most SLOTS
+    auto group_end = [&](int t) {
         const int g0 = root[t];
         int t1 = t + 1;
-        while (t1 < T && root[t1 + 1] - g0 <= tree_lds_words) t1++;
-        const int gwords = root[t1] - g0;
-        const bool staged = gwords <= tree_lds_words;
-        __syncthreads();  // previous group fully walked (and feature tile landed)
-        if (staged) {
-            for (int i = lane; i < gwords; i += blk) tbuf[i] = nodes[g0 + i];
-        }
-        __syncthreads();
-        if (active) {
-            const uint2 *base = staged ? (const uint2 *)tbuf : nodes + g0;
-            for (int tt = t; tt < t1; tt += ILP) {
-                int idx[ILP];
-                bool leaf[ILP];
-#pragma unroll
-                for (int k = 0; k < ILP; k++) {
-                    idx[k] = root[min(tt + k, t1 - 1)] - g0;
-                    leaf[k] = false;
-                }
-                bool all_done = false;
-                while (!all_done) {
-                    uint2 nd[ILP];
-#pragma unroll
-                    for (int k = 0; k < ILP; k++) nd[k] = base[idx[k]];
-                    all_done = true;
-#pragma unroll
-                    for (int k = 0; k < ILP; k++) {
-                        if (!leaf[k]) step(nd[k], fea, blk, lane, idx[k], leaf[k]);
-                        all_done = all_done && leaf[k];
-                    }
-                }
-                double v[ILP];
-#pragma unroll
-                for (int k = 0; k < ILP; k++) v[k] = node_as_double(base[idx[k]]);
-#pragma unroll
-                for (int k = 0; k < ILP; k++)
-                    if (tt + k < t1) acc += v[k];
+        while (t1 < T && t1 - t < SLOTS && root[t1 + 1] - g0 <= tree_words) t1++;
+        return t1;
+    };
+    uint4 pf[PF];  // the next group, in flight / parked in VGPRs
+    int t = 0, t1 = group_end(0);
+    group_prefetch<PF, THREADS>(pf, nodes, root, t, t1, tree_words, tid);
+    group_commit<PF, THREADS>(pf, tbuf, root, t, t1, tree_words, tid);
+    __syncthreads();  // feature tile and first group are in LDS
+
+    // does this wave hold a NaN feature?  (decides the walk variant below)
+    bool wave_nan = false;
+    if (!(dbg & 4)) {
+        bool my_nan = false;
+        if (active)
+            for (int f = 0; f < F; f++) {
+                const float x = fea[f * LDS_C + cl];
+                my_nan = my_nan | (x != x);
             }
-        }
-        t = t1;
+        wave_nan = __any(my_nan);
     }
-    if (valid) prob[c] = active ? acc / (double)T : 0.0;
+
+    double acc = 0.0;
+    const char *fea_b = reinterpret_cast<const char *>(fea);
+    const int cl4 = cl << 2;
+    while (t < T) {  // uniform trip count: T and root[] are the same for every thread
+        const int g0 = root[t];
+        const int gt = t1 - t;
+        const bool staged = root[t1] - g0 <= tree_words;
+        const int tn = t1, tn1 = t1 < T ? group_end(t1) : t1;
+        if (tn < T)  // loads fly while this group is walked
+            group_prefetch<PF, THREADS>(pf, nodes, root, tn, tn1, tree_words, tid);
+        if (active && slot < gt && !(dbg & 2)) {
+            double v;
+            if (staged) {
+                const char *a = reinterpret_cast<const char *>(tbuf + (root[t + slot] - g0));
+                v = wave_nan ? walk_tree_lds<true>(fea_b, cl4, a) : walk_tree_lds<false>(fea_b, cl4, a);
+            } else {
+                v = walk_tree_global(nodes, root[t + slot], fea, cl);
+            }
+            val[slot * LDS_C + cl] = v;
+        }
+        __syncthreads();  // every walk of the group is done: tbuf may be overwritten
+        if (tn < T) group_commit<PF, THREADS>(pf, tbuf, root, tn, tn1, tree_words, tid);
+        if (slot == 0 && active) {
+            for (int j = 0; j < gt; j++) acc += val[j * LDS_C + cl];  // tree order
+        }
+        __syncthreads();  // next group staged; val consumed
+        t = tn;
+        t1 = tn1;
+    }
+    if (slot == 0 && valid) prob[c] = active ? acc / (double)T : 0.0;
 }
 
 // row-major [N][F] float32 -> [tile][F][blk] tiles (pk_predict's input path)
@@ -202,6 +329,10 @@ int set_max_lds(KernelT k, size_t bytes)
 // the 160 KiB LDS of a CU (keeping 4 KiB spare), at most 256.
 int pk_forest_tile_width(int F)
 {
+    // LDS-streamed trees: 128-candidate tiles, provided a useful tree buffer
+    // (>= 32 KiB) is left beside the tile
+    if (g_opt.forest_lds > 0 && (size_t)F * 4 * LDS_C + 8192 + 32768 <= (size_t)160 * 1024)
+        return LDS_C;
     int blk = (int)((156 * 1024) / ((size_t)F * 4)) / 64 * 64;
     if (blk > 256) blk = 256;
     if (blk < 64) blk = 0;  // F too large for an LDS-resident tile
@@ -227,13 +358,20 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
                            f->nodes, f->root, f->T, f->F, tiles, d_status, c0, cn, d_prob);   \
     } while (0)
 
-#define PK_LAUNCH_LDS(ILP)                                                                    \
+#define PK_LAUNCH_LDS(SLOTS)                                                                  \
     do {                                                                                      \
-        int rc__ = set_max_lds(forest_lds_kernel<ILP>, lds);                                  \
+        const size_t val_bytes = (size_t)(SLOTS) * LDS_C * sizeof(double);                    \
+        size_t room = (size_t)160 * 1024 - fea_bytes - val_bytes - 2 * sizeof(uint2);        \
+        if ((size_t)g_opt.forest_lds * 1024 < room) room = (size_t)g_opt.forest_lds * 1024;   \
+        const size_t pf_cap = (size_t)LDS_C * (SLOTS) * 8 * 16; /* THREADS * PF * 16 B */      \
+        if (room > pf_cap) room = pf_cap;                                                     \
+        const int tree_words = (int)(room / sizeof(uint2)) & ~1;                              \
+        const size_t lds = fea_bytes + val_bytes + (size_t)(tree_words + 2) * sizeof(uint2);  \
+        int rc__ = set_max_lds(forest_lds_kernel<SLOTS>, lds);                                \
         if (rc__) return rc__;                                                                \
-        hipLaunchKernelGGL(forest_lds_kernel<ILP>, dim3(grid), dim3(blk), lds, ctx->stream,   \
-                           f->nodes, f->root, f->T, f->F, tiles, d_status, c0, cn, d_prob,    \
-                           tree_words);                                                       \
+        hipLaunchKernelGGL(forest_lds_kernel<SLOTS>, dim3(grid), dim3(LDS_C *(SLOTS)), lds,   \
+                           ctx->stream, f->nodes, f->root, f->T, f->F, tiles, d_status, c0,   \
+                           cn, d_prob, tree_words, (int)g_opt.forest_dbg);                    \
     } while (0)
 
 int pk_launch_forest(pk_device_ctx *ctx, const pk_forest *f, const float *tiles, int blk,
@@ -244,17 +382,12 @@ int pk_launch_forest(pk_device_ctx *ctx, const pk_forest *f, const float *tiles,
     const unsigned grid = (unsigned)((cn + blk - 1) / blk);
     const size_t fea_bytes = (size_t)f->F * blk * sizeof(float);
     const int ilp = (int)g_opt.forest_ilp;
-    if (g_opt.forest_lds > 0) {
-        // whatever LDS the feature tile leaves (one workgroup per CU)
-        size_t room = (size_t)160 * 1024 - fea_bytes;
-        if ((size_t)g_opt.forest_lds * 1024 < room) room = (size_t)g_opt.forest_lds * 1024;
-        const int tree_words = (int)(room / sizeof(uint2));
-        const size_t lds = fea_bytes + (size_t)tree_words * sizeof(uint2);
-        switch (ilp) {
-        case 1: PK_LAUNCH_LDS(1); break;
+    if (blk == LDS_C && g_opt.forest_lds > 0) {
+        switch ((int)g_opt.forest_slots) {
         case 2: PK_LAUNCH_LDS(2); break;
-        case 8: PK_LAUNCH_LDS(8); break;
-        default: PK_LAUNCH_LDS(4); break;
+        case 4: PK_LAUNCH_LDS(4); break;
+        case 6: PK_LAUNCH_LDS(6); break;
+        default: PK_LAUNCH_LDS(8); break;
         }
     } else {
         const size_t lds = fea_bytes;
