@@ -251,14 +251,17 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
         pk_set_error("pk_forest_create: bad arguments");
         return nullptr;
     }
-    if (F > (1 << PK_NODE_FEAT_BITS)) {
-        pk_set_error("pk_forest_create: F=%d exceeds %d features", F, 1 << PK_NODE_FEAT_BITS);
+    if (F > PK_NODE_FEAT_MAX) {
+        pk_set_error("pk_forest_create: F=%d exceeds %d features", F, PK_NODE_FEAT_MAX);
         return nullptr;
     }
     pk_device_ctx *ctx = pk_ctx(device);
     if (!ctx) return nullptr;
 
     std::vector<uint2> nodes;
+    std::vector<int32_t> big;  // side table of right offsets >= PK_NODE_ROFF_BIG
+    std::vector<uint8_t> tree_big(T, 0);
+    bool any_big = false;
     std::vector<int32_t> root(T + 1);
     std::vector<int32_t> pos, stack, depth;
     int max_depth = 0, max_tree = 0;
@@ -286,7 +289,7 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
             // a one-leaf tree: a root that sends everything to that leaf
             const unsigned kind = leaf_kind(p1[base]);
             unsigned pk = (1u << PK_NODE_MISS_BIT) | (kind << PK_NODE_LKIND_SHIFT) |
-                          (kind << PK_NODE_RKIND_SHIFT) | (1u << PK_NODE_ROFF_SHIFT);
+                          (kind << PK_NODE_RKIND_SHIFT) | (1u << PK_NODE_ROFF_SHIFT);  // feature 0
             float inf = INFINITY;
             unsigned tb;
             memcpy(&tb, &inf, 4);
@@ -343,17 +346,26 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
             if (lk <= PK_KIND_LEAF && pos[l] != pos[v] + 1) roff = -1;
             if (rk <= PK_KIND_LEAF) {
                 if (roff == 0) roff = (int64_t)pos[r] - pos[v];
-                if (roff <= 0 || roff >= (1 << (32 - PK_NODE_ROFF_SHIFT))) roff = -1;
+                if (roff <= 0) roff = -1;
             }
             if (roff < 0) {
                 pk_set_error("pk_forest_create: tree %d too large or inconsistent at node %d", t, v);
                 return nullptr;
             }
-            unsigned pk = (unsigned)f;
+            unsigned pk = (unsigned)f << PK_NODE_FEAT_SHIFT;
             if (miss_left && miss_left[base + v]) pk |= 1u << PK_NODE_MISS_BIT;
             pk |= lk << PK_NODE_LKIND_SHIFT;
             pk |= rk << PK_NODE_RKIND_SHIFT;
-            pk |= (unsigned)roff << PK_NODE_ROFF_SHIFT;
+            if (roff >= PK_NODE_ROFF_BIG) {
+                // rare: a tree of more than 8190 words keeps this offset in the side table
+                if (big.size() < nodes.size()) big.resize(nodes.size(), 0);
+                big[tree_base + pos[v]] = (int32_t)roff;
+                tree_big[t] = 1;
+                any_big = true;
+                pk |= (unsigned)PK_NODE_ROFF_BIG << PK_NODE_ROFF_SHIFT;
+            } else {
+                pk |= (unsigned)roff << PK_NODE_ROFF_SHIFT;
+            }
             const float t32 = floor_to_f32(thr[base + v]);
             unsigned tb;
             memcpy(&tb, &t32, 4);
@@ -373,7 +385,12 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
     fo->max_tree_nodes = max_tree;
     fo->nodes = nullptr;
     fo->root = nullptr;
+    fo->big_roff = nullptr;
+    fo->grp = nullptr;
+    fo->n_grp = 0;
+    fo->grp_words = fo->grp_slots = -1;
     fo->h_root = root;
+    fo->h_big = tree_big;
     if (hipMalloc((void **)&fo->nodes, (nodes.size() + 2) * sizeof(uint2)) != hipSuccess ||
         hipMalloc((void **)&fo->root, root.size() * sizeof(int32_t)) != hipSuccess) {
         pk_set_error("pk_forest_create: device allocation failed");
@@ -388,7 +405,53 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
         pk_forest_destroy(fo);
         return nullptr;
     }
+    if (any_big) {
+        big.resize(nodes.size() + 2, 0);
+        if (hipMalloc((void **)&fo->big_roff, big.size() * sizeof(int32_t)) != hipSuccess ||
+            hipMemcpy(fo->big_roff, big.data(), big.size() * sizeof(int32_t),
+                      hipMemcpyHostToDevice) != hipSuccess) {
+            pk_set_error("pk_forest_create: side-table upload failed");
+            pk_forest_destroy(fo);
+            return nullptr;
+        }
+    }
     return fo;
+}
+
+// Tree groups of the LDS forest kernel: consecutive whole trees, at most
+// `slots` of them and at most `tree_words` words; a tree that is too large
+// (or uses the side table) forms a group of its own that is not staged.
+int pk_forest_groups(pk_forest *f, int tree_words, int slots)
+{
+    if (f->grp && f->grp_words == tree_words && f->grp_slots == slots) return PK_OK;
+    std::vector<int32_t> first, staged;
+    int t = 0;
+    while (t < f->T) {
+        first.push_back(t);
+        const int g0 = f->h_root[t];
+        const bool big = f->h_big[t] || f->h_root[t + 1] - g0 > tree_words;
+        int t1 = t + 1;
+        if (!big)
+            while (t1 < f->T && t1 - t < slots && !f->h_big[t1] &&
+                   f->h_root[t1 + 1] - g0 <= tree_words)
+                t1++;
+        staged.push_back(big ? 0 : 1);
+        t = t1;
+    }
+    const int G = (int)first.size();
+    first.push_back(f->T);
+    first.push_back(f->T);  // one spare entry: the kernel reads grp[g + 2]
+    std::vector<int32_t> tab(first);
+    tab.insert(tab.end(), staged.begin(), staged.end());
+    tab.push_back(0);
+    if (f->grp) PK_HIP(hipFree(f->grp));
+    f->grp = nullptr;
+    PK_HIP(hipMalloc((void **)&f->grp, tab.size() * sizeof(int32_t)));
+    PK_HIP(hipMemcpy(f->grp, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    f->n_grp = G;
+    f->grp_words = tree_words;
+    f->grp_slots = slots;
+    return PK_OK;
 }
 
 extern "C" void pk_forest_destroy(pk_forest *f)
@@ -397,6 +460,8 @@ extern "C" void pk_forest_destroy(pk_forest *f)
     hipSetDevice(f->device);
     if (f->nodes) hipFree(f->nodes);
     if (f->root) hipFree(f->root);
+    if (f->big_roff) hipFree(f->big_roff);
+    if (f->grp) hipFree(f->grp);
     delete f;
 }
 
@@ -735,7 +800,6 @@ extern "C" int pk_predict(pk_forest *f, int64_t N, const float *fea32, double *p
         pk_set_error("pk_predict: device allocation failed");
         rc = PK_E_NOMEM;
     }
-    if (!rc && hipMemsetAsync(d_status, 1, (size_t)chunk, ctx->stream) != hipSuccess) rc = PK_E_HIP;
     for (int64_t c0 = 0; !rc && c0 < N; c0 += chunk) {
         const int64_t cn = N - c0 < chunk ? N - c0 : chunk;
         if (hipMemcpyAsync(d_rows, fea32 + (size_t)c0 * F, (size_t)cn * F * 4,
@@ -744,7 +808,7 @@ extern "C" int pk_predict(pk_forest *f, int64_t N, const float *fea32, double *p
             rc = PK_E_HIP;
             break;
         }
-        rc = pk_launch_tile_rows(ctx, d_rows, cn, F, ctx->fea_tiles, blk);
+        rc = pk_launch_tile_rows(ctx, d_rows, cn, F, ctx->fea_tiles, blk, d_status);
         if (rc) break;
         rc = pk_launch_forest(ctx, f, ctx->fea_tiles, blk, d_status, 0, cn, d_prob);
         if (rc) break;

@@ -78,19 +78,25 @@ struct pk_prof_scope {
 // get no word at all -- the parent's kind field says which.  So the left
 // child, if it has a word, is the next word, and the right child's word is
 // `roff` words further (roff = 1 + words of the left subtree).
-//   packed bits  0..9   feature index (F <= 1024)
-//               10      NaN goes left
-//               11..12  kind of the left child
-//               13..14  kind of the right child
-//               15..31  roff (< 2^17)
+//   packed bit   0      NaN goes left
+//               1..2    kind of the left child
+//               3..4    kind of the right child
+//               9..18   feature index, i.e. the field read in place is
+//                       feature*512 = the byte offset of that feature's row
+//                       in a [F][128] float tile
+//               19..31  roff (0..8190); 8191 = look roff up in the side
+//                       table big_roff[] (trees of more than 8190 words)
 //   kind: 0 interior word, 1 stored leaf word, 2 pure leaf 0.0, 3 pure leaf 1.0
 // Every tree starts on an even word (16-byte aligned) so groups of trees can
 // be copied into LDS with 16-byte accesses.
-#define PK_NODE_FEAT_BITS 10
-#define PK_NODE_MISS_BIT 10
-#define PK_NODE_LKIND_SHIFT 11
-#define PK_NODE_RKIND_SHIFT 13
-#define PK_NODE_ROFF_SHIFT 15
+#define PK_NODE_FEAT_MAX 1024
+#define PK_NODE_MISS_BIT 0
+#define PK_NODE_LKIND_SHIFT 1
+#define PK_NODE_RKIND_SHIFT 3
+#define PK_NODE_FEAT_SHIFT 9
+#define PK_NODE_FEAT_MASK 0x7fe00u
+#define PK_NODE_ROFF_SHIFT 19
+#define PK_NODE_ROFF_BIG 8191
 #define PK_KIND_NODE 0u
 #define PK_KIND_LEAF 1u
 #define PK_KIND_ZERO 2u
@@ -104,8 +110,16 @@ struct pk_forest {
     int max_tree_nodes;
     uint2 *nodes;          // device, n_nodes x 8 B
     int32_t *root;         // device, T+1 offsets of each tree's root
+    int32_t *big_roff;     // device side table [n_nodes] or nullptr
     std::vector<int32_t> h_root;
+    std::vector<uint8_t> h_big;   // per tree: uses the side table (never staged in LDS)
+    // LDS-kernel tree groups for one (tree_words, slots) launch shape, cached
+    int32_t *grp;          // device, n_grp+1 first-tree indices, then n_grp staged flags
+    int n_grp;
+    int grp_words, grp_slots;
 };
+// (re)build f->grp for this launch shape; returns PK_OK or an error code
+int pk_forest_groups(pk_forest *f, int tree_words, int slots);
 
 // Diagonal-major dense band: cell (r, r+k), dlo <= k <= dhi, lives at
 // band[(k - dlo) * ld + r]; everything else reads 0.
@@ -123,7 +137,8 @@ struct pk_cands {
     int64_t N;
     int32_t *x, *y;        // device, candidate coordinates
     double *prob;          // device [N]
-    uint8_t *status;       // device [N] 1 = window survived the filters
+    uint8_t *status;       // device [N] 0 = filtered out, 1 = window survived, 2 = survived
+                           // and its features are NaN (constant window)
     // compacted outputs of the last run (device), capacity N
     int32_t *ox, *oy;
     double *op, *osig;
@@ -145,11 +160,12 @@ int pk_launch_extract(pk_device_ctx *, const pk_matrix *, int w, const int32_t *
                       uint8_t *d_status, double *fea64_rows);
 
 // walk the forest over feature tiles of candidates [c0, c0+cn)
-int pk_launch_forest(pk_device_ctx *, const pk_forest *, const float *tiles, int blk,
+int pk_launch_forest(pk_device_ctx *, pk_forest *, const float *tiles, int blk,
                      const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob);
-// row-major float32 features [N][F] -> tiles (for pk_predict)
+// row-major float32 features [N][F] -> tiles (for pk_predict); status[i] = 1,
+// or 2 if row i holds a NaN
 int pk_launch_tile_rows(pk_device_ctx *, const float *d_rows, int64_t N, int F, float *tiles,
-                        int blk);
+                        int blk, uint8_t *d_status);
 int pk_forest_tile_width(int F);  // candidates per feature tile for F features
 
 int pk_launch_compact(pk_device_ctx *, const pk_matrix *, pk_cands *, double thre,

@@ -181,12 +181,14 @@ __global__ __launch_bounds__(64) void extract_reg_kernel(
     const int64_t tile = local / blk;
     const int lane = (int)(local - tile * blk);
     float *tp = tiles + (size_t)tile * F * blk + lane;
+    bool fea_nan = false;  // e.g. a constant window: 0/0
 #pragma unroll
     for (int i = 0; i < S; i++) {
 #pragma unroll
         for (int j = 0; j < S; j++) {
             const double v = (win[i][j] - mn) / den;
             win[i][j] = v;
+            fea_nan = fea_nan || (v != v);
             tp[(size_t)(i * S + j) * blk] = (float)v;  // sklearn's float32 cast (RNE)
         }
     }
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(64) void extract_reg_kernel(
             for (int j = 0; j < S; j++) fp[i * S + j] = win[i][j];
         }
     }
-    status[c] = 1;
+    status[c] = fea_nan ? 2 : 1;  // 2: NaN features (the forest kernel then honours missing_go_to_left)
 }
 
 // ------------------------------------------------------------------------
@@ -303,12 +305,15 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     const int64_t tile = local / blk;
     const int tl = (int)(local - tile * blk);
     float *tp = tiles + (size_t)tile * F * blk + tl;
+    bool fea_nan = false;
     for (int f = lane; f < F; f += 64) {
         const double v = (A[f] - mn) / den;
+        fea_nan = fea_nan || (v != v);
         tp[(size_t)f * blk] = (float)v;
         if (fea64_rows) fea64_rows[(size_t)local * F + f] = v;
     }
-    if (lane == 0) status[c] = 1;
+    fea_nan = __any(fea_nan);
+    if (lane == 0) status[c] = fea_nan ? 2 : 1;
 }
 
 }  // namespace

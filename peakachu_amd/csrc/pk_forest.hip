@@ -45,8 +45,16 @@ __device__ __forceinline__ bool goes_left(float x, uint2 n)
     return le | nan_left;
 }
 
-__device__ __forceinline__ unsigned node_feat(uint2 n) { return n.y & ((1u << PK_NODE_FEAT_BITS) - 1); }
-__device__ __forceinline__ int node_roff(uint2 n) { return (int)(n.y >> PK_NODE_ROFF_SHIFT); }
+__device__ __forceinline__ unsigned node_feat(uint2 n)
+{
+    return (n.y & PK_NODE_FEAT_MASK) >> PK_NODE_FEAT_SHIFT;
+}
+// right-child offset of the word at absolute index `idx`
+__device__ __forceinline__ int node_roff(uint2 n, const int32_t *__restrict__ big_roff, int idx)
+{
+    const int r = (int)(n.y >> PK_NODE_ROFF_SHIFT);
+    return (r == PK_NODE_ROFF_BIG && big_roff) ? big_roff[idx] : r;
+}
 __device__ __forceinline__ unsigned node_kind(uint2 n, bool left)
 {
     return (n.y >> (left ? PK_NODE_LKIND_SHIFT : PK_NODE_RKIND_SHIFT)) & 3u;
@@ -59,7 +67,8 @@ __device__ __forceinline__ unsigned node_kind(uint2 n, bool left)
 // ------------------------------------------------------------------------
 template <int ILP>
 __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
-                                 int T, int F, const float *__restrict__ tiles,
+                                 const int32_t *__restrict__ big_roff, int T, int F,
+                                 const float *__restrict__ tiles,
                                  const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
                                  double *__restrict__ prob)
 {
@@ -102,7 +111,7 @@ __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t 
                     const float x = fea[node_feat(nd[k]) * blk + lane];
                     const bool gl = goes_left(x, nd[k]);
                     kind[k] = node_kind(nd[k], gl);
-                    idx[k] += gl ? 1 : node_roff(nd[k]);
+                    idx[k] += gl ? 1 : node_roff(nd[k], big_roff, idx[k]);
                 }
                 all_done = all_done && (kind[k] != PK_KIND_NODE);
             }
@@ -144,16 +153,34 @@ __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t 
 // ------------------------------------------------------------------------
 constexpr int LDS_C = 128;
 
-template <bool WITH_NAN>
+// SPEC = fetch both child words together with the feature (one LDS round trip
+// per level, 20 bytes read); !SPEC = fetch only the chosen child afterwards
+// (two dependent round trips, 12 bytes read).
+template <bool WITH_NAN, bool SPEC>
 __device__ __forceinline__ double walk_tree_lds(const char *fea_b, int cl4, const char *a)
 {
+    if (!SPEC) {
+        uint2 cur = *reinterpret_cast<const uint2 *>(a);
+        unsigned kind;
+        do {
+            const unsigned pk = cur.y;
+            const float x = *reinterpret_cast<const float *>(fea_b + ((pk & PK_NODE_FEAT_MASK) | cl4));
+            bool gl = x <= __uint_as_float(cur.x);
+            if (WITH_NAN) gl = gl | ((x != x) & (((pk >> PK_NODE_MISS_BIT) & 1u) != 0));
+            kind = (pk >> (gl ? PK_NODE_LKIND_SHIFT : PK_NODE_RKIND_SHIFT)) & 3u;
+            a = gl ? a + 8 : a + ((pk >> PK_NODE_ROFF_SHIFT) << 3);
+            cur = *reinterpret_cast<const uint2 *>(a);
+        } while (kind == PK_KIND_NODE);
+        return leaf_value(kind, cur);
+    }
     // a: LDS byte address of the current node word
     uint2 cur = *reinterpret_cast<const uint2 *>(a);
     uint2 nxt;
     unsigned kind;
     do {
         const unsigned pk = cur.y;
-        const float x = *reinterpret_cast<const float *>(fea_b + (((pk & 1023u) << 9) | cl4));
+        // feature row offset is stored in place: one v_and_or_b32
+        const float x = *reinterpret_cast<const float *>(fea_b + ((pk & PK_NODE_FEAT_MASK) | cl4));
         const char *ra = a + ((pk >> PK_NODE_ROFF_SHIFT) << 3);
         const uint2 lw = *reinterpret_cast<const uint2 *>(a + 8);
         const uint2 rw = *reinterpret_cast<const uint2 *>(ra);
@@ -169,7 +196,8 @@ __device__ __forceinline__ double walk_tree_lds(const char *fea_b, int cl4, cons
 }
 
 // generic (global-memory) walk of one tree, for trees too large to stage
-__device__ __forceinline__ double walk_tree_global(const uint2 *__restrict__ base, int idx,
+__device__ __forceinline__ double walk_tree_global(const uint2 *__restrict__ base,
+                                                   const int32_t *__restrict__ big_roff, int idx,
                                                    const float *fea, int cl)
 {
     unsigned kind;
@@ -179,7 +207,7 @@ __device__ __forceinline__ double walk_tree_global(const uint2 *__restrict__ bas
         const float x = fea[node_feat(nd) * LDS_C + cl];
         const bool gl = goes_left(x, nd);
         kind = node_kind(nd, gl);
-        idx += gl ? 1 : node_roff(nd);
+        idx += gl ? 1 : node_roff(nd, big_roff, idx);
     } while (kind == PK_KIND_NODE);
     return leaf_value(kind, base[idx]);
 }
@@ -219,7 +247,8 @@ __device__ __forceinline__ void group_commit(const uint4 (&pf)[PF], uint2 *tbuf,
 
 template <int SLOTS>
 __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
-    const uint2 *__restrict__ nodes, const int32_t *__restrict__ root, int T, int F,
+    const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
+    const int32_t *__restrict__ big_roff, const int32_t *__restrict__ grp, int n_grp, int T, int F,
     const float *__restrict__ tiles, const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
     double *__restrict__ prob, int tree_words, int dbg)
 {
@@ -243,55 +272,49 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     const int64_t local = tile * LDS_C + cl;
     const bool valid = local < cn;
     const int64_t c = c0 + (valid ? local : 0);
-    const bool active = valid && status[c];
+    const unsigned st = valid ? status[c] : 0;
+    const bool active = st != 0;
+    // a wave holding a candidate with NaN features takes the slow walk
+    const bool wave_nan = __any(st == 2);
 
-    // group g = trees [t, t1): as many whole trees as fit, at most SLOTS
-    auto group_end = [&](int t) {
-        const int g0 = root[t];
-        int t1 = t + 1;
-        while (t1 < T && t1 - t < SLOTS && root[t1 + 1] - g0 <= tree_words) t1++;
-        return t1;
-    };
+    // group g = trees [grp[g], grp[g+1]); grp[n_grp+2+g] = staged in LDS or not
+    const int32_t *gstaged = grp + n_grp + 2;
     uint4 pf[PF];  // the next group, in flight / parked in VGPRs
-    int t = 0, t1 = group_end(0);
-    group_prefetch<PF, THREADS>(pf, nodes, root, t, t1, tree_words, tid);
-    group_commit<PF, THREADS>(pf, tbuf, root, t, t1, tree_words, tid);
-    __syncthreads();  // feature tile and first group are in LDS
-
-    // does this wave hold a NaN feature?  (decides the walk variant below)
-    bool wave_nan = false;
-    if (!(dbg & 4)) {
-        bool my_nan = false;
-        if (active)
-            for (int f = 0; f < F; f++) {
-                const float x = fea[f * LDS_C + cl];
-                my_nan = my_nan | (x != x);
-            }
-        wave_nan = __any(my_nan);
+    int t = grp[0], t1 = grp[1];
+    if (gstaged[0]) {
+        group_prefetch<PF, THREADS>(pf, nodes, root, t, t1, tree_words, tid);
+        group_commit<PF, THREADS>(pf, tbuf, root, t, t1, tree_words, tid);
     }
+    __syncthreads();  // feature tile and first group are in LDS
 
     double acc = 0.0;
     const char *fea_b = reinterpret_cast<const char *>(fea);
     const int cl4 = cl << 2;
-    while (t < T) {  // uniform trip count: T and root[] are the same for every thread
+    for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
         const int g0 = root[t];
         const int gt = t1 - t;
-        const bool staged = root[t1] - g0 <= tree_words;
-        const int tn = t1, tn1 = t1 < T ? group_end(t1) : t1;
-        if (tn < T)  // loads fly while this group is walked
+        const bool staged = gstaged[g] != 0;
+        const int tn = t1, tn1 = grp[g + 2];
+        const bool next_staged = (g + 1 < n_grp) && gstaged[g + 1] != 0;
+        if (next_staged)  // loads fly while this group is walked
             group_prefetch<PF, THREADS>(pf, nodes, root, tn, tn1, tree_words, tid);
         if (active && slot < gt && !(dbg & 2)) {
             double v;
             if (staged) {
                 const char *a = reinterpret_cast<const char *>(tbuf + (root[t + slot] - g0));
-                v = wave_nan ? walk_tree_lds<true>(fea_b, cl4, a) : walk_tree_lds<false>(fea_b, cl4, a);
+                if (dbg & 8)
+                    v = wave_nan ? walk_tree_lds<true, false>(fea_b, cl4, a)
+                                 : walk_tree_lds<false, false>(fea_b, cl4, a);
+                else
+                    v = wave_nan ? walk_tree_lds<true, true>(fea_b, cl4, a)
+                                 : walk_tree_lds<false, true>(fea_b, cl4, a);
             } else {
-                v = walk_tree_global(nodes, root[t + slot], fea, cl);
+                v = walk_tree_global(nodes, big_roff, root[t + slot], fea, cl);
             }
             val[slot * LDS_C + cl] = v;
         }
         __syncthreads();  // every walk of the group is done: tbuf may be overwritten
-        if (tn < T) group_commit<PF, THREADS>(pf, tbuf, root, tn, tn1, tree_words, tid);
+        if (next_staged) group_commit<PF, THREADS>(pf, tbuf, root, tn, tn1, tree_words, tid);
         if (slot == 0 && active) {
             for (int j = 0; j < gt; j++) acc += val[j * LDS_C + cl];  // tree order
         }
@@ -302,17 +325,24 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     if (slot == 0 && valid) prob[c] = active ? acc / (double)T : 0.0;
 }
 
-// row-major [N][F] float32 -> [tile][F][blk] tiles (pk_predict's input path)
+// row-major [N][F] float32 -> [tile][F][blk] tiles (pk_predict's input path):
+// one wave per row, which also notes whether the row holds a NaN.
 __global__ void tile_rows_kernel(const float *__restrict__ rows, int64_t N, int F,
-                                 float *__restrict__ tiles, int blk)
+                                 float *__restrict__ tiles, int blk, uint8_t *__restrict__ status)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * F) return;
-    const int64_t c = i / F;
-    const int f = (int)(i - c * F);
+    const int64_t c = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= N) return;
     const int64_t tile = c / blk;
-    const int lane = (int)(c - tile * blk);
-    tiles[((size_t)tile * F + f) * blk + lane] = rows[i];
+    const int col = (int)(c - tile * blk);
+    bool nan = false;
+    for (int f = lane; f < F; f += 64) {
+        const float v = rows[c * F + f];
+        nan = nan || (v != v);
+        tiles[((size_t)tile * F + f) * blk + col] = v;
+    }
+    nan = __any(nan);
+    if (lane == 0) status[c] = nan ? 2 : 1;
 }
 
 template <typename KernelT>
@@ -340,12 +370,11 @@ int pk_forest_tile_width(int F)
 }
 
 int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int F, float *tiles,
-                        int blk)
+                        int blk, uint8_t *d_status)
 {
     if (N <= 0) return PK_OK;
-    const int64_t total = N * F;
-    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       ctx->stream, d_rows, N, F, tiles, blk);
+    hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, ctx->stream,
+                       d_rows, N, F, tiles, blk, d_status);
     PK_HIP(hipGetLastError());
     return PK_OK;
 }
@@ -355,7 +384,8 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
         int rc__ = set_max_lds(forest_l2_kernel<ILP>, lds);                                   \
         if (rc__) return rc__;                                                                \
         hipLaunchKernelGGL(forest_l2_kernel<ILP>, dim3(grid), dim3(blk), lds, ctx->stream,    \
-                           f->nodes, f->root, f->T, f->F, tiles, d_status, c0, cn, d_prob);   \
+                           f->nodes, f->root, f->big_roff, f->T, f->F, tiles, d_status, c0,   \
+                           cn, d_prob);                                                       \
     } while (0)
 
 #define PK_LAUNCH_LDS(SLOTS)                                                                  \
@@ -369,12 +399,15 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
         const size_t lds = fea_bytes + val_bytes + (size_t)(tree_words + 2) * sizeof(uint2);  \
         int rc__ = set_max_lds(forest_lds_kernel<SLOTS>, lds);                                \
         if (rc__) return rc__;                                                                \
+        rc__ = pk_forest_groups(f, tree_words, SLOTS);                                        \
+        if (rc__) return rc__;                                                                \
         hipLaunchKernelGGL(forest_lds_kernel<SLOTS>, dim3(grid), dim3(LDS_C *(SLOTS)), lds,   \
-                           ctx->stream, f->nodes, f->root, f->T, f->F, tiles, d_status, c0,   \
-                           cn, d_prob, tree_words, (int)g_opt.forest_dbg);                    \
+                           ctx->stream, f->nodes, f->root, f->big_roff, f->grp, f->n_grp,     \
+                           f->T, f->F, tiles, d_status, c0, cn, d_prob, tree_words,           \
+                           (int)g_opt.forest_dbg);                                            \
     } while (0)
 
-int pk_launch_forest(pk_device_ctx *ctx, const pk_forest *f, const float *tiles, int blk,
+int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int blk,
                      const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob)
 {
     if (cn <= 0) return PK_OK;
