@@ -216,11 +216,15 @@ def main():
         dom_ms, dom_n = kern[dom]
         alg_bytes_total = float(n_local) * a.steps * b_alg(F)
         achieved = alg_bytes_total / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel, from the committed PMC
+        # passes (profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # gfx950 correction applied); only valid for the default w=5 workload
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and w == 5 and dom_n:
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                per_cand = json.load(open(tpath))[dom]["bytes_per_candidate"]
+                traffic = per_cand * n_local * a.steps / dom_n
             except Exception:
                 traffic = None
         fst = fo.stats()

@@ -137,6 +137,13 @@ void pk_comm_destroy(pk_comm *);
 int pk_comm_gather_scored(pk_comm *, pk_cands *, int64_t *counts, int64_t cap,
                           int32_t *ox, int32_t *oy, double *op, double *osignal);
 
+/* generic gather-v of host bytes to rank 0 (score_genome: every rank sends the
+ * packed records of the chromosomes it scored; peakachu/score_genome.py:83-84
+ * appends them to one file).  counts (nranks entries, bytes) is filled on
+ * every rank; recv (capacity cap bytes) only on rank 0, in rank order. */
+int pk_comm_gatherv_bytes(pk_comm *, const void *send, int64_t nbytes, int64_t *counts,
+                          void *recv, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,3 +190,96 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
     hipFree(gs);
     return rc;
 }
+
+extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbytes, int64_t *counts,
+                                     void *recv, int64_t cap)
+{
+    if (!c || nbytes < 0 || (nbytes > 0 && !send)) {
+        pk_set_error("pk_comm_gatherv_bytes: bad arguments");
+        return PK_E_INVALID;
+    }
+    pk_device_ctx *ctx = pk_ctx(c->device);
+    if (!ctx) return PK_E_NODEVICE;
+    hipStream_t s = ctx->stream;
+    const int R = c->nranks;
+    int64_t *d_mine = nullptr;
+    uint8_t *d_send = nullptr, *d_recv = nullptr;
+    int rc = PK_OK;
+    std::vector<int64_t> h_counts((size_t)R);
+    do {
+        if (hipMalloc((void **)&d_mine, 8) != hipSuccess ||
+            hipMalloc((void **)&d_send, (size_t)(nbytes > 0 ? nbytes : 1)) != hipSuccess) {
+            pk_set_error("pk_comm_gatherv_bytes: device allocation failed");
+            rc = PK_E_NOMEM;
+            break;
+        }
+        if (hipMemcpyAsync(d_mine, &nbytes, 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+            (nbytes > 0 &&
+             hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, s) != hipSuccess)) {
+            pk_set_error("pk_comm_gatherv_bytes: upload failed");
+            rc = PK_E_HIP;
+            break;
+        }
+        ncclResult_t nr = ncclAllGather(d_mine, c->d_counts, 1, ncclInt64, c->comm, s);
+        if (nr != ncclSuccess ||
+            hipMemcpyAsync(h_counts.data(), c->d_counts, 8 * (size_t)R, hipMemcpyDeviceToHost, s) !=
+                hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            pk_set_error("pk_comm_gatherv_bytes: count exchange failed");
+            rc = PK_E_COMM;
+            break;
+        }
+        int64_t total = 0;
+        for (int r = 0; r < R; r++) total += h_counts[(size_t)r];
+        if (counts)
+            for (int r = 0; r < R; r++) counts[r] = h_counts[(size_t)r];
+        if (c->rank != 0) {
+            if (nbytes > 0) {
+                nr = ncclSend(d_send, (size_t)nbytes, ncclUint8, 0, c->comm, s);
+                if (nr != ncclSuccess) {
+                    pk_set_error("ncclSend failed: %s", ncclGetErrorString(nr));
+                    rc = PK_E_COMM;
+                    break;
+                }
+            }
+            if (hipStreamSynchronize(s) != hipSuccess) rc = PK_E_HIP;
+            break;
+        }
+        if (hipMalloc((void **)&d_recv, (size_t)(total > 0 ? total : 1)) != hipSuccess) {
+            pk_set_error("pk_comm_gatherv_bytes: staging allocation failed");
+            rc = PK_E_NOMEM;
+            break;
+        }
+        if (nbytes > 0 &&
+            hipMemcpyAsync(d_recv, d_send, (size_t)nbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            rc = PK_E_HIP;
+            break;
+        }
+        nr = ncclGroupStart();
+        size_t off = (size_t)h_counts[0];
+        for (int r = 1; r < R && nr == ncclSuccess; r++) {
+            const size_t k = (size_t)h_counts[(size_t)r];
+            if (k) nr = ncclRecv(d_recv + off, k, ncclUint8, r, c->comm, s);
+            off += k;
+        }
+        ncclResult_t ne = ncclGroupEnd();
+        if (nr != ncclSuccess || ne != ncclSuccess) {
+            pk_set_error("pk_comm_gatherv_bytes: RCCL recv failed");
+            rc = PK_E_COMM;
+            break;
+        }
+        if (total > cap || (total > 0 && !recv)) {
+            pk_set_error("pk_comm_gatherv_bytes: %lld bytes exceed the root capacity %lld",
+                         (long long)total, (long long)cap);
+            rc = PK_E_INVALID;
+        } else if (total > 0 &&
+                   hipMemcpyAsync(recv, d_recv, (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
+            rc = PK_E_HIP;
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) rc = PK_E_HIP;
+    } while (0);
+    if (d_mine) hipFree(d_mine);
+    if (d_send) hipFree(d_send);
+    if (d_recv) hipFree(d_recv);
+    return rc;
+}

@@ -1,0 +1,98 @@
+"""Contact-map access for the scoring drivers.
+
+The reference reads `.cool` through `cooler` and `.hic` through `straw`
+(peakachu/score_genome.py:26-35,55-57; peakachu/utils.py:17-58).  Neither
+package (nor a contact map) is available in the build environment, so the
+drivers accept
+  * a `.cool` URI when `cooler` is importable (same calls as the reference),
+  * a `.pkmap.npz` container written by `write_pkmap` -- per chromosome the
+    symmetric raw-count CSR and, optionally, balancing weights -- which is
+    what the synthetic configurations use.
+Both are served through the three calls the reference makes on a Cooler:
+`chromnames`, `matrix(balance=..., sparse=True).fetch(chrom)` (a symmetric
+COO, NaN where a weight is NaN) and `bins().fetch(chrom)[name].values`.
+"""
+import numpy as np
+from scipy import sparse
+
+
+def write_pkmap(path, chroms, resolution=10000, weight_name="weight"):
+    """chroms: ordered dict name -> (raw symmetric CSR, weights or None)."""
+    out = {"chromnames": np.array(list(chroms.keys())), "resolution": np.int64(resolution),
+           "weight_name": np.array(weight_name)}
+    for name, (M, w) in chroms.items():
+        M = sparse.csr_matrix(M, dtype=np.float64)
+        M.sum_duplicates()
+        M.sort_indices()
+        out[name + "/indptr"] = M.indptr.astype(np.int64)
+        out[name + "/indices"] = M.indices.astype(np.int32)
+        out[name + "/data"] = M.data
+        out[name + "/n"] = np.int64(M.shape[0])
+        if w is not None:
+            out[name + "/weights"] = np.asarray(w, np.float64)
+    np.savez_compressed(path, **out)
+
+
+class _Selector:
+    def __init__(self, fn):
+        self._fn = fn
+
+    def fetch(self, chrom):
+        return self._fn(chrom)
+
+
+class _Bins(dict):
+    pass
+
+
+class PkMap:
+    """Cooler-like view of a .pkmap.npz container."""
+
+    def __init__(self, path):
+        self._z = np.load(path, allow_pickle=False)
+        self.chromnames = [str(c) for c in self._z["chromnames"]]
+        self.binsize = int(self._z["resolution"])
+        self.weight_name = str(self._z["weight_name"])
+
+    def _raw(self, chrom):
+        z = self._z
+        n = int(z[chrom + "/n"])
+        return sparse.csr_matrix((z[chrom + "/data"], z[chrom + "/indices"],
+                                  z[chrom + "/indptr"]), shape=(n, n))
+
+    def _weights(self, chrom):
+        key = chrom + "/weights"
+        if key not in self._z.files:
+            raise KeyError("no balancing weights stored for %s" % chrom)
+        return self._z[key]
+
+    def matrix(self, balance=False, sparse=True):
+        def fetch(chrom):
+            M = self._raw(chrom).tocoo()
+            if balance:
+                w = self._weights(chrom)
+                M.data = M.data * w[M.row] * w[M.col]
+            return M
+        return _Selector(fetch)
+
+    def bins(self):
+        def fetch(chrom):
+            class _Col:
+                def __init__(self, v):
+                    self.values = v
+            b = _Bins()
+            b[self.weight_name] = _Col(self._weights(chrom))
+            return b
+        return _Selector(fetch)
+
+
+def open_map(path):
+    """`-p/--path`: .pkmap.npz, or anything cooler.Cooler accepts."""
+    if str(path).endswith(".npz"):
+        return PkMap(path)
+    try:
+        import cooler
+    except ImportError as e:
+        raise ImportError("reading %s needs the `cooler` package (not installed); "
+                          "use a .pkmap.npz container instead" % path) from e
+    return cooler.Cooler(path)

@@ -1,0 +1,24 @@
+"""`peakachu score_chromosome` for the MI355X path
+(peakachu/score_chromosome.py:3-71): same flags, same output."""
+import os
+
+import numpy as np
+
+from . import io
+from .forest import load_model
+from .score_genome import build_chromosome
+
+
+def main(args):
+    np.seterr(divide='ignore', invalid='ignore')
+    if os.path.exists(args.output):
+        os.remove(args.output)
+    model = load_model(args.model)
+    correct = False if args.clr_weight_name.lower() == 'raw' else args.clr_weight_name
+    width = int((np.sqrt(model.feature_importances_.size) - 1) / 2)
+    Lib = io.open_map(args.path)
+    ccname = args.chrom
+    cikada = 'chr' + ccname.lstrip('chr')  # always "chr"-prefixed (score_chromosome.py:37)
+    X = build_chromosome(Lib, ccname, cikada, model, correct, args, width, getattr(args, "device", 0))
+    result, R = X.score(thre=args.minimum_prob)
+    X.writeBed(args.output, result, R)

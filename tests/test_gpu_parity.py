@@ -202,3 +202,78 @@ def test_chromosome_drop_in(hip_lib, tmp_path):
         ch.writeBed(str(out), result, R)
         text = out.read_text() if out.exists() else ""
         assert text == str(z["bedpe"])
+
+
+@pytest.mark.parametrize("tag,wname,chroms", [("weight", "weight", ["#", "X"]),
+                                              ("raw", "raw", ["#", "X"]), ("all", "raw", [])])
+def test_score_genome_cli_matches_reference(hip_lib, tmp_path, tag, wname, chroms):
+    """`peakachu score_genome` drop-in: byte-identical bedpe to the reference's
+    own score_genome.main on the same container (golden G6)."""
+    import os
+    from peakachu_amd import cli
+    z = gio.load("g6_driver.npz")
+    model = tmp_path / "forest.npz"
+    flat(gio.forest(str(z["forest"]))).save(str(model))
+    out = tmp_path / (tag + ".bedpe")
+    out.write_text("stale\n")  # must be removed first (score_genome.py:11-12)
+    argv = ["score_genome", "-p", os.path.join(gio.GOLD, str(z["container"])), "-m", str(model),
+            "-O", str(out), "--clr-weight-name", wname, "-u", str(int(z["upper"])), "-C"] + chroms
+    cli.run(argv)
+    assert out.read_text() == str(z["genome_" + tag])
+
+
+def test_score_chromosome_cli_matches_reference(hip_lib, tmp_path):
+    import os
+    from peakachu_amd import cli
+    z = gio.load("g6_driver.npz")
+    model = tmp_path / "forest.npz"
+    flat(gio.forest(str(z["forest"]))).save(str(model))
+    out = tmp_path / "c.bedpe"
+    cli.run(["score_chromosome", "-p", os.path.join(gio.GOLD, str(z["container"])), "-m",
+             str(model), "-O", str(out), "-C", "3", "-u", str(int(z["upper"]))])
+    assert out.read_text() == str(z["chrom_3_weight"])
+
+
+def test_buildmatrix_drop_in(hip_lib):
+    from peakachu_amd import trainUtils
+    z = gio.load("g5_buildmatrix.npz")
+    M = gio.sym_matrix(z, "M")
+    coords = list(zip(z["x"].tolist(), z["y"].tolist()))
+    fea = trainUtils.buildmatrix(M, coords, w=int(z["w"]))
+    assert np.array_equal(gio.bits(np.asarray(fea)), gio.bits(z["fea"]))
+    assert trainUtils.buildmatrix(M, coords[:5], w=int(z["w"])) is None
+
+
+def test_rccl_gather_single_rank(hip_lib):
+    """The RCCL gather code path with a 1-rank communicator (the only shape a
+    one-GPU box can run): results come back unchanged and in order."""
+    import ctypes as C
+    L = hip_lib
+    z = gio.load("g3_score_raw_minprob0.npz")
+    w, upper = int(z["w"]), int(z["upper"])
+    Mf = utils.band_filter(gio.sym_matrix(z, "R"), w, upper)
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper)
+    hf = _lib.HipForest(flat(gio.forest(str(z["forest"]))))
+    cd = _lib.HipCands(z["ridx"], z["cidx"])
+    n = cd.run(hm, hf, w, 0.0)
+    ox, oy, op, osig = cd.fetch()
+    uid = np.zeros(128, np.uint8)
+    _lib.check(L.pk_comm_unique_id(uid), "uid")
+    comm = L.pk_comm_create(0, 1, 0, uid)
+    assert comm, _lib.last_error()
+    try:
+        counts = np.zeros(1, np.int64)
+        gx = np.empty(n, np.int32); gy = np.empty(n, np.int32)
+        gp = np.empty(n, np.float64); gs = np.empty(n, np.float64)
+        _lib.check(L.pk_comm_gather_scored(comm, cd.h, counts, n, gx.ctypes.data, gy.ctypes.data,
+                                           gp.ctypes.data, gs.ctypes.data), "gather")
+        assert counts[0] == n and n > 100
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy)
+        assert np.array_equal(gio.bits(gp), gio.bits(op)) and np.array_equal(gio.bits(gs), gio.bits(osig))
+        payload = np.arange(1000, dtype=np.uint8)
+        recv = np.zeros(1000, np.uint8)
+        _lib.check(L.pk_comm_gatherv_bytes(comm, payload.ctypes.data, 1000, counts,
+                                           recv.ctypes.data, 1000), "gatherv")
+        assert counts[0] == 1000 and np.array_equal(recv, payload)
+    finally:
+        L.pk_comm_destroy(comm)

@@ -1,0 +1,115 @@
+"""Host-side logic against the reference's golden outputs (CPU only):
+expected-by-distance, band filter, candidate selection, chromosome queue,
+sharding helpers, the map container and bedpe formatting."""
+import numpy as np
+import pytest
+
+import golden_io as gio
+from peakachu_amd import cli, dist, io, score_genome, scoreUtils, utils
+
+
+def _mode_inputs(z):
+    raw = gio.sym_matrix(z, "R")
+    mode = str(z["mode"])
+    if mode == "raw":
+        return raw, raw, None, True
+    if mode == "weights":
+        return gio.balance(raw, z["weights"]), raw, z["weights"], False
+    return gio.hicstyle(raw, z["weights"]), raw, None, True
+
+
+@pytest.mark.parametrize("name", ["g3_score_raw.npz", "g3_score_weights.npz",
+                                  "g3_score_hicstyle.npz"])
+def test_expected_bandfilter_candidates(name):
+    z = gio.load(name)
+    w = int(z["w"])
+    M, raw, wts, rawmode = _mode_inputs(z)
+    lower = max(int(z["lower"]), w + 1)
+    upper = min(int(z["upper"]), M.shape[0] - 2 * w)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=rawmode)
+    assert np.array_equal(gio.bits(e), gio.bits(z["exp_arr"]))
+    if str(z["mode"]) == "hicstyle":
+        bg = utils.calculate_expected(raw, upper + 2 * w, raw=True)
+    else:
+        bg = e
+    assert np.array_equal(gio.bits(bg), gio.bits(z["background"]))
+    Mf = utils.band_filter(M, w, upper)
+    assert gio.digest(Mf) == str(z["Mf_sha"])
+    x, y = utils.candidates(raw, bg, wts, lower, upper)
+    assert np.array_equal(x, z["ridx"]) and np.array_equal(y, z["cidx"])
+
+
+def test_buildmatrix_expected():
+    z = gio.load("g5_buildmatrix.npz")
+    M = gio.sym_matrix(z, "M")
+    e = utils.calculate_expected(M, int(z["maxdis"]))
+    assert np.array_equal(gio.bits(e), gio.bits(z["exp_arr"]))
+
+
+def test_select_chromosomes():
+    names = ["chr1", "chr2", "3", "chrX", "chrM", "chrY", "chr10_random"]
+    assert score_genome.select_chromosomes(names, ["#", "X"]) == ["chr1", "chr2", "3", "chrX"]
+    assert score_genome.select_chromosomes(names, []) == names
+    assert score_genome.select_chromosomes(names, ["M", "Y"]) == ["chrM", "chrY"]
+
+
+def test_lpt_and_blocks():
+    w = [50, 10, 40, 30, 20, 60, 5]
+    own = dist.lpt_assign(w, 3)
+    assert sorted(sum(own, [])) == list(range(len(w)))
+    loads = [sum(w[i] for i in o) for o in own]
+    assert max(loads) - min(loads) <= max(w)
+    assert dist.lpt_assign(w, 3) == own  # deterministic
+    assert dist.lpt_assign(w, 1) == [list(range(len(w)))]
+    for N, R, B in ((100001, 2, 100000), (5557769, 8, 100000), (10, 4, 100000), (0, 3, 7)):
+        rr = dist.block_ranges(N, R, B)
+        assert rr[0][0] == 0 and rr[-1][1] == N
+        for (a, b), (c, d) in zip(rr, rr[1:]):
+            assert b == c and a <= b
+        assert all(a % B == 0 for a, _ in rr)
+
+
+def test_pkmap_roundtrip(tmp_path):
+    from peakachu_amd import synth
+    M, _ = synth.synth_band(200, 40, seed=5)
+    wts = synth.synth_weights(200, 5, n_nan=2)
+    path = str(tmp_path / "m.pkmap.npz")
+    io.write_pkmap(path, {"chr1": (M, wts), "chr2": (M, None)}, resolution=5000)
+    lib = io.open_map(path)
+    assert lib.chromnames == ["chr1", "chr2"] and lib.binsize == 5000
+    raw = utils.tocsr(lib.matrix(balance=False, sparse=True).fetch("chr1"))
+    assert (raw != M).nnz == 0
+    bal = utils.tocsr(lib.matrix(balance="weight", sparse=True).fetch("chr1"))
+    ref = gio.balance(M, wts)
+    assert np.array_equal(gio.bits(bal.data), gio.bits(ref.data))
+    assert np.array_equal(gio.bits(lib.bins().fetch("chr1")["weight"].values), gio.bits(wts))
+    with pytest.raises(KeyError):
+        lib.bins().fetch("chr2")
+
+
+def test_write_bedpe_format(tmp_path):
+    from scipy import sparse
+    r = np.array([3, 3, 1]); c = np.array([9, 4, 7])
+    p = np.array([0.5781894544004801, 1.0, 1e-05]); s = np.array([6.0, 0.25, 3.0])
+    P = sparse.csr_matrix((p, (r, c)), shape=(12, 12))
+    S = sparse.csr_matrix((s, (r, c)), shape=(12, 12))
+    out = tmp_path / "o.bedpe"
+    scoreUtils.write_bedpe(str(out), "chr9", 10000, P, S)
+    scoreUtils.write_bedpe(str(out), "chr9", 10000, P, S)  # append mode
+    lines = out.read_text().splitlines()
+    assert lines[0] == "chr9\t10000\t20000\tchr9\t70000\t80000\t1e-05\t3.0"
+    assert lines[1] == "chr9\t30000\t40000\tchr9\t40000\t50000\t1.0\t0.25"
+    assert lines[2] == "chr9\t30000\t40000\tchr9\t90000\t100000\t0.5781894544004801\t6.0"
+    assert len(lines) == 6
+
+
+def test_cli_defaults_match_reference():
+    args, _ = cli.getargs(["score_genome", "-p", "x.npz", "-m", "m.npz", "-O", "o"])
+    assert (args.resolution, args.clr_weight_name, args.chroms, args.lower, args.upper,
+            args.minimum_prob) == (10000, "weight", ["#", "X"], 6, 300, 0.5)
+    args, _ = cli.getargs(["score_chromosome", "-C", "chr21", "--clr-weight-name", "raw",
+                           "-u", "400", "--minimum-prob", "0.1"])
+    assert (args.chrom, args.clr_weight_name, args.upper, args.minimum_prob) == \
+        ("chr21", "raw", 400, 0.1)
+    args, _ = cli.getargs(["score_genome", "-C"])
+    assert args.chroms == []

@@ -421,16 +421,86 @@ def g4_batch_quirk(raw, rf):
     print("G4 (a) kept %d, (b) kept %d of 100001" % (res_a["ri"].size, res_b["ri"].size))
 
 
+def g6_driver(forests):
+    """The reference's own score_genome.main / score_chromosome.main
+    (peakachu/score_genome.py:3-84, score_chromosome.py:3-71) run against a
+    multi-chromosome container through a file-backed stand-in for `cooler`
+    (the package is not installed): chromosome filter "# X", chrM excluded,
+    an un-prefixed label, chromosome order, balanced and raw modes."""
+    import joblib
+    from peakachu import score_genome, score_chromosome
+    from peakachu_amd import io as pkio
+    rf = forests["plain"]
+    chroms = {}
+    for i, (name, n) in enumerate((("chr1", 420), ("chr2", 380), ("3", 300), ("chrX", 340),
+                                   ("chrM", 150))):
+        raw, loops, dead = holey_band(n, 90, 61 + i, decay=1.0, lam0=150.0, floor=0.3)
+        chroms[name] = (raw, synth.synth_weights(n, 61 + i, n_nan=3))
+    cont = os.path.join(OUT, "g6_genome.pkmap.npz")
+    pkio.write_pkmap(cont, chroms, resolution=10000)
+    fake = types.ModuleType("cooler")
+    fake.Cooler = pkio.PkMap
+    sys.modules["cooler"] = fake
+    tmpd = tempfile.mkdtemp()
+    mpath = os.path.join(tmpd, "model.pkl")
+    joblib.dump(rf, mpath)
+    out = {}
+
+    class A:
+        pass
+    for tag, wname, chrsel in (("weight", "weight", ["#", "X"]), ("raw", "raw", ["#", "X"]),
+                               ("all", "raw", [])):
+        a = A()
+        a.output = os.path.join(tmpd, tag + ".bedpe")
+        a.model, a.path, a.clr_weight_name = mpath, cont, wname
+        a.chroms, a.lower, a.upper, a.resolution, a.minimum_prob = chrsel, 6, 80, 10000, 0.5
+        buf = io.StringIO(); old = sys.stdout; sys.stdout = buf
+        try:
+            score_genome.main(a)
+        finally:
+            sys.stdout = old
+        out["genome_" + tag] = np.array(open(a.output).read() if os.path.exists(a.output) else "")
+        print("G6 score_genome %-6s %d lines" % (tag, str(out["genome_" + tag]).count("\n")))
+    a = A()
+    a.output = os.path.join(tmpd, "c.bedpe")
+    a.model, a.path, a.clr_weight_name, a.chrom = mpath, cont, "weight", "3"
+    a.lower, a.upper, a.resolution, a.minimum_prob = 6, 80, 10000, 0.5
+    buf = io.StringIO(); old = sys.stdout; sys.stdout = buf
+    try:
+        score_chromosome.main(a)
+    finally:
+        sys.stdout = old
+    out["chrom_3_weight"] = np.array(open(a.output).read() if os.path.exists(a.output) else "")
+    save("g6_driver.npz", forest=np.array("g2_forest_plain.npz"),
+         container=np.array("g6_genome.pkmap.npz"), lower=np.int32(6), upper=np.int32(80),
+         **out)
+    del sys.modules["cooler"]
+
+
 def main():
+    """`make_golden.py` regenerates everything; `make_golden.py g6` only the
+    named groups (g2 is always run: the later groups need its forest)."""
     os.makedirs(OUT, exist_ok=True)
-    for f in os.listdir(OUT):
-        if f.endswith(".npz"):
-            os.remove(os.path.join(OUT, f))
-    g1_extract()
+    want = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6"}
+    if "g1" in want:
+        g1_extract()
+    global save
+    real_save = save
+    if "g2" not in want:
+        save = lambda *a, **k: None  # train the forest without rewriting its fixture
     forests = g2_forest()
-    g5_buildmatrix()
-    raw, rf = g3_end_to_end(forests)
-    g4_batch_quirk(raw, rf)
+    save = real_save
+    if "g5" in want:
+        g5_buildmatrix()
+    if "g3" in want or "g4" in want:
+        if "g3" not in want:
+            save = lambda *a, **k: None
+        raw, rf = g3_end_to_end(forests)
+        save = real_save
+        if "g4" in want:
+            g4_batch_quirk(raw, rf)
+    if "g6" in want:
+        g6_driver(forests)
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("total %.1f KB" % (tot / 1024))
 
