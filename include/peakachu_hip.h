@@ -121,6 +121,9 @@ int pk_prof_reset(void);
 /* accumulated device time (ms) and launch count of kernel class `name`
  * ("extract", "forest", "compact", "band") since the last reset */
 int pk_prof_get(const char *name, double *ms_total, int64_t *launches);
+/* diagnostic builds only (option "forest_dbg" bit 4): in-kernel cycle stamps of
+ * one workgroup, written to a buffer no kernel reads; n <= 65536 entries */
+int pk_debug_read(int device, int64_t *out, int64_t n);
 
 /* ---- multi-GPU: one process per GPU, one gather of the scored pixels -----
  * Chromosomes / candidate blocks are scored independently per rank

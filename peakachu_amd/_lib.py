@@ -52,6 +52,7 @@ SIGNATURES = {
     "pk_prof_enable": (C.c_int, [C.c_int]),
     "pk_prof_reset": (C.c_int, []),
     "pk_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pk_debug_read": (C.c_int, [C.c_int, _i64p, C.c_int64]),
     "pk_comm_unique_id": (C.c_int, [_u8p]),
     "pk_comm_create": (_vp, [C.c_int, C.c_int, C.c_int, _u8p]),
     "pk_comm_destroy": (None, [_vp]),

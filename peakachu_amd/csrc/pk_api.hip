@@ -102,6 +102,8 @@ pk_device_ctx *pk_ctx(int device)
     c->device = device;
     c->cu_count = prop.multiProcessorCount;
     PK_HIP_NULL(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    PK_HIP_NULL(hipMalloc((void **)&c->dbg_buf, 65536 * sizeof(long long)));
+    PK_HIP_NULL(hipMemset(c->dbg_buf, 0, 65536 * sizeof(long long)));
     g_ctx[device] = c;
     return c;
 }
@@ -203,6 +205,16 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
     if (!strcmp(name, "extract_block")) return g_opt.extract_block;
     return -1;
+}
+
+extern "C" int pk_debug_read(int device, int64_t *out, int64_t n)
+{
+    pk_device_ctx *c = pk_ctx(device);
+    if (!c) return PK_E_NODEVICE;
+    if (!out || n < 0 || n > 65536) return PK_E_INVALID;
+    PK_HIP(hipStreamSynchronize(c->stream));
+    PK_HIP(hipMemcpy(out, c->dbg_buf, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return PK_OK;
 }
 
 extern "C" int pk_prof_enable(int on)

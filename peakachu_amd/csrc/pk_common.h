@@ -43,6 +43,7 @@ struct pk_device_ctx {
     int64_t *scan_scratch = nullptr;  // block counts for the compaction scan
     size_t scan_scratch_bytes = 0;
     int cu_count = 0;
+    long long *dbg_buf = nullptr;  // diagnostic cycle stamps (pk_debug_read), 64 Ki entries
 };
 pk_device_ctx *pk_ctx(int device);  // lazily created; nullptr + error on failure
 int pk_ctx_reserve_tiles(pk_device_ctx *, size_t bytes);
@@ -50,7 +51,7 @@ int pk_ctx_reserve_scan(pk_device_ctx *, size_t bytes);
 
 // ------------------------------------------------------------------ options
 struct pk_options {
-    int64_t chunk = 262144;     // candidates per extract/forest launch pair
+    int64_t chunk = 524288;     // candidates per extract/forest launch pair (254 MB of tiles at w=5)
     int64_t forest_ilp = 4;     // L2 kernel: trees walked concurrently per lane
     int64_t forest_slots = 8;   // LDS kernel: tree slots (wave pairs) per workgroup
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)

@@ -153,26 +153,12 @@ __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t 
 // ------------------------------------------------------------------------
 constexpr int LDS_C = 128;
 
-// SPEC = fetch both child words together with the feature (one LDS round trip
-// per level, 20 bytes read); !SPEC = fetch only the chosen child afterwards
-// (two dependent round trips, 12 bytes read).
-template <bool WITH_NAN, bool SPEC>
+// Both child words are fetched together with the feature: one LDS round trip
+// per level (20 bytes read).  Fetching only the chosen child afterwards (two
+// dependent round trips, 12 bytes) was measured 8-10 % slower at 16 waves/CU.
+template <bool WITH_NAN>
 __device__ __forceinline__ double walk_tree_lds(const char *fea_b, int cl4, const char *a)
 {
-    if (!SPEC) {
-        uint2 cur = *reinterpret_cast<const uint2 *>(a);
-        unsigned kind;
-        do {
-            const unsigned pk = cur.y;
-            const float x = *reinterpret_cast<const float *>(fea_b + ((pk & PK_NODE_FEAT_MASK) | cl4));
-            bool gl = x <= __uint_as_float(cur.x);
-            if (WITH_NAN) gl = gl | ((x != x) & (((pk >> PK_NODE_MISS_BIT) & 1u) != 0));
-            kind = (pk >> (gl ? PK_NODE_LKIND_SHIFT : PK_NODE_RKIND_SHIFT)) & 3u;
-            a = gl ? a + 8 : a + ((pk >> PK_NODE_ROFF_SHIFT) << 3);
-            cur = *reinterpret_cast<const uint2 *>(a);
-        } while (kind == PK_KIND_NODE);
-        return leaf_value(kind, cur);
-    }
     // a: LDS byte address of the current node word
     uint2 cur = *reinterpret_cast<const uint2 *>(a);
     uint2 nxt;
@@ -182,6 +168,9 @@ __device__ __forceinline__ double walk_tree_lds(const char *fea_b, int cl4, cons
         // feature row offset is stored in place: one v_and_or_b32
         const float x = *reinterpret_cast<const float *>(fea_b + ((pk & PK_NODE_FEAT_MASK) | cl4));
         const char *ra = a + ((pk >> PK_NODE_ROFF_SHIFT) << 3);
+        // (predicating these reads on the child having a word -- 46 % are pure
+        // leaves -- was measured slower: the exec-mask code costs more than the
+        // LDS cycles it saves)
         const uint2 lw = *reinterpret_cast<const uint2 *>(a + 8);
         const uint2 rw = *reinterpret_cast<const uint2 *>(ra);
         bool gl = x <= __uint_as_float(cur.x);
@@ -250,7 +239,7 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
     const int32_t *__restrict__ big_roff, const int32_t *__restrict__ grp, int n_grp, int T, int F,
     const float *__restrict__ tiles, const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
-    double *__restrict__ prob, int tree_words, int dbg)
+    double *__restrict__ prob, int tree_words, int dbg, long long *__restrict__ stamps)
 {
     constexpr int THREADS = LDS_C * SLOTS;
     // registers per thread for the prefetched group: the launcher keeps
@@ -287,6 +276,13 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     }
     __syncthreads();  // feature tile and first group are in LDS
 
+    // diagnostic build only (dbg bit 4): cycle stamps of workgroup 0 go to a
+    // buffer nothing else reads; [wave][group][5]
+#define PK_STAMP(slot_)                                                                  \
+    do {                                                                                 \
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && (tid & 63) == 0 && g < 32)        \
+            stamps[((tid >> 6) * 32 + g) * 5 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
     double acc = 0.0;
     const char *fea_b = reinterpret_cast<const char *>(fea);
     const int cl4 = cl << 2;
@@ -296,33 +292,34 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
         const bool staged = gstaged[g] != 0;
         const int tn = t1, tn1 = grp[g + 2];
         const bool next_staged = (g + 1 < n_grp) && gstaged[g + 1] != 0;
+        PK_STAMP(0);
         if (next_staged)  // loads fly while this group is walked
             group_prefetch<PF, THREADS>(pf, nodes, root, tn, tn1, tree_words, tid);
         if (active && slot < gt && !(dbg & 2)) {
             double v;
             if (staged) {
                 const char *a = reinterpret_cast<const char *>(tbuf + (root[t + slot] - g0));
-                if (dbg & 8)
-                    v = wave_nan ? walk_tree_lds<true, false>(fea_b, cl4, a)
-                                 : walk_tree_lds<false, false>(fea_b, cl4, a);
-                else
-                    v = wave_nan ? walk_tree_lds<true, true>(fea_b, cl4, a)
-                                 : walk_tree_lds<false, true>(fea_b, cl4, a);
+                v = wave_nan ? walk_tree_lds<true>(fea_b, cl4, a) : walk_tree_lds<false>(fea_b, cl4, a);
             } else {
                 v = walk_tree_global(nodes, big_roff, root[t + slot], fea, cl);
             }
             val[slot * LDS_C + cl] = v;
         }
+        PK_STAMP(1);
         __syncthreads();  // every walk of the group is done: tbuf may be overwritten
+        PK_STAMP(2);
         if (next_staged) group_commit<PF, THREADS>(pf, tbuf, root, tn, tn1, tree_words, tid);
         if (slot == 0 && active) {
             for (int j = 0; j < gt; j++) acc += val[j * LDS_C + cl];  // tree order
         }
+        PK_STAMP(3);
         __syncthreads();  // next group staged; val consumed
+        PK_STAMP(4);
         t = tn;
         t1 = tn1;
     }
     if (slot == 0 && valid) prob[c] = active ? acc / (double)T : 0.0;
+#undef PK_STAMP
 }
 
 // row-major [N][F] float32 -> [tile][F][blk] tiles (pk_predict's input path):
@@ -404,7 +401,7 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
         hipLaunchKernelGGL(forest_lds_kernel<SLOTS>, dim3(grid), dim3(LDS_C *(SLOTS)), lds,   \
                            ctx->stream, f->nodes, f->root, f->big_roff, f->grp, f->n_grp,     \
                            f->T, f->F, tiles, d_status, c0, cn, d_prob, tree_words,           \
-                           (int)g_opt.forest_dbg);                                            \
+                           (int)g_opt.forest_dbg, ctx->dbg_buf);                              \
     } while (0)
 
 int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int blk,

@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""GPU-box diagnostic: where does a tree group's time go inside the LDS forest
+kernel?  Runs config 2 with in-kernel s_memtime stamps (workgroup 0 of the last
+launch) and prints per-phase cycle shares.  Shares, not absolute times."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from peakachu_amd import _lib
+from peakachu_amd.forest import FlatForest
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+Mf, e, x, y, upper = bench.build_workload(0, n, 200, 5, 6, 200)
+fo = FlatForest.load("peakachu_amd/data/forest_w5_t100.npz")
+L = _lib.require_device()
+hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -9, upper + 9)
+hf = _lib.HipForest(fo)
+cd = _lib.HipCands(x, y)
+cd.run(hm, hf, 5, 0.5)
+_lib.set_option("forest_dbg", 16)
+cd.run(hm, hf, 5, 0.5)
+_lib.set_option("forest_dbg", 0)
+buf = np.zeros(16 * 32 * 5, np.int64)
+_lib.check(L.pk_debug_read(0, buf, buf.size), "dbg")
+st = buf.reshape(16, 32, 5)
+ng = int((st[0, :, 0] != 0).sum())
+st = st[:, :ng, :].astype(np.float64)
+walk = st[:, :, 1] - st[:, :, 0]
+bar1 = st[:, :, 2] - st[:, :, 1]
+commit = st[:, :, 3] - st[:, :, 2]
+bar2 = st[:, :, 4] - st[:, :, 3]
+tot = st[:, -1, 4] - st[:, 0, 0]
+print("groups", ng, "cycles per group (mean over 16 waves):")
+print("  prefetch-issue+walk %8.0f  (min wave %.0f max wave %.0f)" % (walk.mean(), walk.mean(1).min(), walk.mean(1).max()))
+print("  wait at barrier 1   %8.0f" % bar1.mean())
+print("  commit+accumulate   %8.0f" % commit.mean())
+print("  wait at barrier 2   %8.0f" % bar2.mean())
+print("  total per group     %8.0f ; whole workgroup %.0f cycles" % ((st[:, :, 4] - st[:, :, 0]).mean(), tot.mean()))
+print("per-wave walk means:", np.round(walk.mean(1)).astype(int).tolist())
