@@ -47,6 +47,46 @@ def build_workload(seed, n, band, w, lower, upper):
     return Mf, exp_arr, x, y, upper
 
 
+def load_forest(spec, w, F):
+    """The committed trained forest for this window size, a flat-forest file,
+    or `random:T[:depth]`: seeded untrained random trees (stress configs for
+    which no trained model is shipped; same node format and walk cost profile,
+    but NOT a trained model -- named as such in the output)."""
+    from peakachu_amd.forest import FlatForest
+    if spec is None:
+        return FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w%d_t100.npz" % w))
+    if not spec.startswith("random:"):
+        return FlatForest.load(spec)
+    parts = spec.split(":")
+    T = int(parts[1])
+    depth = int(parts[2]) if len(parts) > 2 else 16
+    rng = np.random.default_rng(12345)
+    offs, cols = [0], {k: [] for k in ("left", "right", "feat", "thr", "miss_left", "p1")}
+    for _ in range(T):
+        # random binary tree grown from a random frontier to about 2 500 nodes
+        left, right, feat, thr, p1, dep = [-1], [-1], [-2], [-2.0], [0.0], [0]
+        frontier = [0]
+        while frontier and len(left) < 2500:
+            i = frontier.pop(int(rng.integers(0, len(frontier))))
+            if dep[i] >= depth:
+                continue
+            feat[i] = int(rng.integers(0, F))
+            thr[i] = float(rng.random())
+            for side in (left, right):
+                side[i] = len(left)
+                left.append(-1); right.append(-1); feat.append(-2); thr.append(-2.0)
+                p1.append(float(rng.integers(0, 2)) if rng.random() < 0.9 else float(rng.random()))
+                dep.append(dep[i] + 1)
+                frontier.append(len(left) - 1)
+        k = len(left)
+        cols["left"].append(np.array(left, np.int32)); cols["right"].append(np.array(right, np.int32))
+        cols["feat"].append(np.array(feat, np.int32)); cols["thr"].append(np.array(thr, np.float64))
+        cols["miss_left"].append(np.zeros(k, np.uint8)); cols["p1"].append(np.array(p1, np.float64))
+        offs.append(offs[-1] + k)
+    return FlatForest(F, np.array(offs, np.int32), *[np.concatenate(cols[k]) for k in
+                                                     ("left", "right", "feat", "thr", "miss_left", "p1")])
+
+
 def host_cores():
     """CPU threads this process may really use: the affinity mask capped by
     the cgroup CPU quota (the GPU box gives one GPU's job a share of the host)."""
@@ -104,12 +144,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=30000)
+    ap.add_argument("--bins", dest="n", type=int, default=30000, help="matrix side in bins")
     ap.add_argument("--band", type=int, default=200)
-    ap.add_argument("-w", type=int, default=5)
+    ap.add_argument("-w", "--width", dest="w", type=int, default=5)
     ap.add_argument("--thre", type=float, default=0.5)
     ap.add_argument("--batch", type=int, default=100000)
+    ap.add_argument("--upper", type=int, default=None, help="largest candidate distance in bins (default: band)")
+    ap.add_argument("--stride", type=int, default=1, help="score every stride-th band pixel")
+    ap.add_argument("--forest", default=None,
+                    help="flat-forest .npz, or random:T[:depth] for untrained random trees "
+                         "(default: the committed forest for -w)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="rehearsal only: all ranks use device 0 and the RCCL gather is skipped "
+                         "(RCCL refuses two ranks on one GPU); the result is not a valid measurement")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
     a = ap.parse_args()
 
@@ -130,16 +178,18 @@ def main():
     from peakachu_amd import _lib
     from peakachu_amd.forest import FlatForest
     L = _lib.require_device()
-    dev = local_rank
+    dev = 0 if a.rehearse_shared_gpu else local_rank
     for kv in a.opt:
         k, v = kv.split("=")
         _lib.set_option(k, int(v))
 
     w = a.w
     F = (2 * w + 1) ** 2
-    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w%d_t100.npz" % w))
+    fo = load_forest(a.forest, w, F)
     # weak scaling: rank r scores its own synthetic chromosome (seed r)
-    Mf, exp_arr, x, y, upper = build_workload(rank, a.n, a.band, w, 6, a.band)
+    Mf, exp_arr, x, y, upper = build_workload(rank, a.n, a.band, w, 6, a.upper or a.band)
+    if a.stride > 1:
+        x, y = x[::a.stride].copy(), y[::a.stride].copy()
     t0 = time.perf_counter()
     hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], exp_arr,
                         -2 * w + 1, upper + 2 * w - 1, device=dev)
@@ -149,7 +199,7 @@ def main():
     upload_s = time.perf_counter() - t0
 
     comm = None
-    if world > 1:
+    if world > 1 and not a.rehearse_shared_gpu:
         ids = [None]
         if rank == 0:
             buf = np.zeros(128, np.uint8)
@@ -242,8 +292,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic %dx%d band-diagonal (%d-bin band) CSR, w=%d, %d-tree RF, "
-                            "all non-zero band pixels 6<=d<=%d" % (a.n, a.n, a.band, w, fo.T, upper),
+                "workload": "synthetic %dx%d band-diagonal (%d-bin band) CSR, w=%d, %d-tree RF%s, "
+                            "%s non-zero band pixels %d<=d<=%d"
+                            % (a.n, a.n, a.band, w, fo.T,
+                               " (untrained random trees)" if (a.forest or "").startswith("random:") else "",
+                               "all" if a.stride == 1 else "every %d-th of the" % a.stride,
+                               max(6, w + 1), upper),
                 "candidates_per_gpu": n_local,
                 "features": F,
                 "trees": fo.T,
@@ -251,7 +305,8 @@ def main():
                 "threshold": a.thre,
                 "reference_batch": a.batch,
                 "scored_pixels_rank0": int(n_out),
-                "parallelism": "chromosome-sharded x%d, one RCCL gather" % world,
+                "parallelism": "chromosome-sharded x%d, one RCCL gather%s"
+                               % (world, " (REHEARSAL: shared GPU, no gather)" if a.rehearse_shared_gpu else ""),
             },
             "roofline": {
                 "bound": "hbm",

@@ -1,0 +1,150 @@
+"""BASELINE.json-size runs on the GPU, checked through size-independent
+properties (the oracle cannot score millions of candidates in a test):
+  * invariance: the result does not depend on chunking, the forest kernel
+    variant or how candidates are sharded into blocks (cut at batch multiples);
+  * sampled parity: a random 1/400 of the candidates against the CPU oracle,
+    bit-exact (per-candidate status and probability via pk_score_fetch_all);
+  * order: outputs are in candidate order; signal equals M[row, col];
+  * idempotence: a second run of the same handles gives the same bytes.
+Needs an MI355X: -m gpu."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import golden_io as gio
+from oracle import oracle_np as onp
+from peakachu_amd import _lib, dist, synth, utils
+from peakachu_amd.forest import FlatForest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def digest(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def random_forest(F, T, seed, depth=14, p_split=0.8):
+    from test_gpu_parity import random_forest_arrays
+    return random_forest_arrays(F, T, seed, depth=depth)
+
+
+@pytest.fixture(scope="module")
+def config2(hip_lib):
+    """configs[1]: 30k x 30k, 200-bin band, w=5, the committed 100-tree forest."""
+    w, n, band = 5, 30000, 200
+    M, _ = synth.synth_band(n, band, seed=0)
+    upper = band
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w5_t100.npz"))
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, n, e, -2 * w + 1, upper + 2 * w - 1)
+    hf = _lib.HipForest(fo)
+    return dict(w=w, Mf=Mf, e=e, x=x, y=y, fo=fo, hm=hm, hf=hf)
+
+
+def test_config2_properties(config2):
+    c = config2
+    w, x, y = c["w"], c["x"], c["y"]
+    assert x.size > 5_000_000
+    cd = _lib.HipCands(x, y)
+    n1 = cd.run(c["hm"], c["hf"], w, 0.5)
+    ox, oy, op, osig = cd.fetch()
+    st, pr = cd.fetch_all()
+    base = digest(ox, oy, op, osig)
+    # idempotence
+    assert cd.run(c["hm"], c["hf"], w, 0.5) == n1
+    assert digest(*cd.fetch()) == base
+    # candidate order + signal
+    pos = {}
+    key = x.astype(np.int64) * 30000 + y
+    idx = np.searchsorted(np.sort(key), ox.astype(np.int64) * 30000 + oy)
+    order_in_input = np.argsort(key, kind="stable")[idx]
+    assert np.all(np.diff(order_in_input) > 0)
+    assert np.array_equal(osig, np.asarray(c["Mf"][ox, oy]).ravel())
+    assert np.all(op > 0.5) and np.all(st[order_in_input] == 1)
+    assert np.array_equal(gio.bits(pr[order_in_input]), gio.bits(op))
+    # invariance to chunking and kernel variant
+    old = {k: _lib.load().pk_get_option(k.encode()) for k in ("chunk", "forest_slots", "forest_lds")}
+    try:
+        for opts in (dict(chunk=65536), dict(chunk=1000003), dict(forest_slots=4),
+                     dict(forest_lds=0)):
+            for k, v in opts.items():
+                _lib.set_option(k, v)
+            cd2 = _lib.HipCands(x, y)
+            assert cd2.run(c["hm"], c["hf"], w, 0.5) == n1
+            assert digest(*cd2.fetch()) == base, opts
+            st2, pr2 = cd2.fetch_all()
+            assert np.array_equal(st2, st) and np.array_equal(gio.bits(pr2), gio.bits(pr))
+            cd2.close()
+            for k, v in old.items():
+                _lib.set_option(k, v)
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+    # invariance to sharding into batch-aligned blocks (the 8-GPU split)
+    parts = []
+    for lo, hi in dist.block_ranges(x.size, 8, 100000):
+        cdr = _lib.HipCands(x[lo:hi], y[lo:hi])
+        cdr.run(c["hm"], c["hf"], w, 0.5)
+        parts.append(cdr.fetch())
+        cdr.close()
+    cat = [np.concatenate([p[i] for p in parts]) for i in range(4)]
+    assert digest(*cat) == base
+    # sampled parity with the oracle (status + probability of every sampled candidate)
+    rng = np.random.default_rng(1)
+    sel = np.sort(rng.choice(x.size, x.size // 400, replace=False))
+    fod = {k: getattr(c["fo"], k) for k in FlatForest.FIELDS}
+    fea, keep = onp.extract(c["Mf"], c["e"], w, x[sel], y[sel])
+    p_ref = onp.predict(fod, fea.astype(np.float32))
+    st_ref = np.zeros(sel.size, np.uint8)
+    st_ref[keep] = 1
+    assert np.array_equal(st[sel] != 0, st_ref != 0)
+    assert np.array_equal(gio.bits(pr[sel][keep]), gio.bits(p_ref))
+
+
+@pytest.mark.parametrize("w,T,n,band,upper,stride", [(6, 100, 20000, 300, 300, 7),
+                                                     (11, 500, 4000, 120, 100, 3),
+                                                     (5, 100, 60000, 800, 800, 40)])
+def test_other_configs_sampled_parity(hip_lib, w, T, n, band, upper, stride):
+    """w=6 (the released models' window), w=11 x 500 trees (configs[4]) and the
+    5 kb band (configs[3]: 2x bins, upper = 800) on random forests of matching
+    width: every `stride`-th band pixel is scored; a sample is checked
+    bit-exactly against the oracle, the rest through kernel-variant invariance."""
+    M, _ = synth.synth_band(n, band, seed=w)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    x, y = x[::stride], y[::stride]
+    F = (2 * w + 1) ** 2
+    fo = random_forest(F, T, seed=w)
+    ff = FlatForest(F, fo["tree_off"], fo["left"], fo["right"], fo["feat"], fo["thr"],
+                    fo["miss_left"], fo["p1"])
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, n, e, -2 * w + 1, upper + 2 * w - 1)
+    hf = _lib.HipForest(ff)
+    cd = _lib.HipCands(x, y)
+    thre = 0.45
+    n1 = cd.run(hm, hf, w, thre)
+    out = cd.fetch()
+    st, pr = cd.fetch_all()
+    assert n1 > 0 and st.sum() > x.size // 2
+    old = _lib.load().pk_get_option(b"forest_lds")
+    try:
+        _lib.set_option("forest_lds", 0)
+        cd2 = _lib.HipCands(x, y)
+        assert cd2.run(hm, hf, w, thre) == n1
+        assert digest(*cd2.fetch()) == digest(*out)
+    finally:
+        _lib.set_option("forest_lds", old)
+    rng = np.random.default_rng(w)
+    sel = np.sort(rng.choice(x.size, min(x.size, 3000), replace=False))
+    fea, keep = onp.extract(Mf, e, w, x[sel], y[sel])
+    p_ref = onp.predict(fo, fea.astype(np.float32))
+    assert np.array_equal(np.flatnonzero(st[sel]), keep)
+    assert np.array_equal(gio.bits(pr[sel][keep]), gio.bits(p_ref))
