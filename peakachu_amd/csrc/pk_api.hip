@@ -187,6 +187,12 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_slots")) {
         if (value != 2 && value != 4 && value != 6 && value != 8) return PK_E_INVALID;
         g_opt.forest_slots = value;
+    } else if (!strcmp(name, "forest_pipe")) {
+        if (value < 0 || value > 2) return PK_E_INVALID;
+        g_opt.forest_pipe = value;
+    } else if (!strcmp(name, "forest_pipe_slots")) {
+        if (value != 0 && (value < 4 || value > 8)) return PK_E_INVALID;
+        g_opt.forest_pipe_slots = value;
     } else if (!strcmp(name, "forest_dbg")) {
         g_opt.forest_dbg = value;
     } else {
@@ -203,6 +209,8 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_ilp")) return g_opt.forest_ilp;
     if (!strcmp(name, "forest_lds")) return g_opt.forest_lds;
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
+    if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
+    if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
     if (!strcmp(name, "extract_block")) return g_opt.extract_block;
     return -1;
 }
@@ -394,10 +402,12 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
     fo->F = F;
     fo->n_nodes = (int64_t)nodes.size();
     fo->max_depth = max_depth;
-    fo->max_tree_nodes = max_tree;
+    fo->max_tree_words = max_tree;
     fo->nodes = nullptr;
     fo->root = nullptr;
     fo->big_roff = nullptr;
+    fo->tree_staged = nullptr;
+    fo->staged_words = -1;
     fo->grp = nullptr;
     fo->n_grp = 0;
     fo->grp_words = fo->grp_slots = -1;
@@ -466,6 +476,18 @@ int pk_forest_groups(pk_forest *f, int tree_words, int slots)
     return PK_OK;
 }
 
+int pk_forest_stage_flags(pk_forest *f, int region_words)
+{
+    if (f->tree_staged && f->staged_words == region_words) return PK_OK;
+    std::vector<int32_t> fl((size_t)f->T);
+    for (int t = 0; t < f->T; t++)
+        fl[(size_t)t] = (!f->h_big[(size_t)t] && f->h_root[t + 1] - f->h_root[t] <= region_words) ? 1 : 0;
+    if (!f->tree_staged) PK_HIP(hipMalloc((void **)&f->tree_staged, sizeof(int32_t) * (size_t)f->T));
+    PK_HIP(hipMemcpy(f->tree_staged, fl.data(), sizeof(int32_t) * (size_t)f->T, hipMemcpyHostToDevice));
+    f->staged_words = region_words;
+    return PK_OK;
+}
+
 extern "C" void pk_forest_destroy(pk_forest *f)
 {
     if (!f) return;
@@ -473,6 +495,7 @@ extern "C" void pk_forest_destroy(pk_forest *f)
     if (f->nodes) hipFree(f->nodes);
     if (f->root) hipFree(f->root);
     if (f->big_roff) hipFree(f->big_roff);
+    if (f->tree_staged) hipFree(f->tree_staged);
     if (f->grp) hipFree(f->grp);
     delete f;
 }
@@ -671,7 +694,15 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
     if (rc) return rc;
     PK_HIP(hipMemcpyAsync(&cd->n_out, cd->n_out_dev, sizeof(int64_t), hipMemcpyDeviceToHost,
                           ctx->stream));
+    long long err = 0;
+    PK_HIP(hipMemcpyAsync(&err, ctx->dbg_buf + 65535, sizeof(long long), hipMemcpyDeviceToHost,
+                          ctx->stream));
     PK_HIP(hipStreamSynchronize(ctx->stream));
+    if (err) {
+        PK_HIP(hipMemset(ctx->dbg_buf + 65535, 0, sizeof(long long)));
+        pk_set_error("forest pipeline timed out waiting on its LDS ring (internal error)");
+        return PK_E_HIP;
+    }
     if (n_out) *n_out = cd->n_out;
     return PK_OK;
 }

@@ -56,6 +56,8 @@ struct pk_options {
     int64_t forest_slots = 8;   // LDS kernel: tree slots (wave pairs) per workgroup
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
     int64_t extract_block = 64; // threads per extract block
+    int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
+    int64_t forest_pipe_slots = 0;  // 0 = as many as fit (max 8)
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
 };
 extern pk_options g_opt;
@@ -108,10 +110,12 @@ struct pk_forest {
     int T, F;
     int64_t n_nodes;       // slots in `nodes`
     int max_depth;         // edges on the longest root->leaf path
-    int max_tree_nodes;
+    int max_tree_words;
     uint2 *nodes;          // device, n_nodes x 8 B
     int32_t *root;         // device, T+1 offsets of each tree's root
     int32_t *big_roff;     // device side table [n_nodes] or nullptr
+    int32_t *tree_staged;  // device [T]: tree fits a pipeline region (see pk_forest_stage_flags)
+    int staged_words;      // region size tree_staged was computed for (-1 = none)
     std::vector<int32_t> h_root;
     std::vector<uint8_t> h_big;   // per tree: uses the side table (never staged in LDS)
     // LDS-kernel tree groups for one (tree_words, slots) launch shape, cached
@@ -121,6 +125,8 @@ struct pk_forest {
 };
 // (re)build f->grp for this launch shape; returns PK_OK or an error code
 int pk_forest_groups(pk_forest *f, int tree_words, int slots);
+// per-tree flag: words <= region_words and no side-table offsets
+int pk_forest_stage_flags(pk_forest *f, int region_words);
 
 // Diagonal-major dense band: cell (r, r+k), dlo <= k <= dhi, lives at
 // band[(k - dlo) * ld + r]; everything else reads 0.

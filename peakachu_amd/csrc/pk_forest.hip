@@ -201,38 +201,18 @@ __device__ __forceinline__ double walk_tree_global(const uint2 *__restrict__ bas
     return leaf_value(kind, base[idx]);
 }
 
-// The next tree group travels global -> registers (prefetch, issued before the
-// current group is walked) -> LDS (commit, after the barrier ending the walk).
-template <int PF, int THREADS>
-__device__ __forceinline__ void group_prefetch(uint4 (&pf)[PF], const uint2 *__restrict__ nodes,
-                                               const int32_t *__restrict__ root, int t, int t1,
-                                               int tree_words, int tid)
-{
-    const int g0 = root[t];
-    const int nv = (root[t1] - g0) >> 1;
-    if (nv * 2 > tree_words) return;  // a giant tree is walked from global memory
-    const uint4 *src = reinterpret_cast<const uint4 *>(nodes + g0);
-#pragma unroll
-    for (int q = 0; q < PF; q++) {
-        const int i = tid + q * THREADS;
-        pf[q] = i < nv ? src[i] : make_uint4(0, 0, 0, 0);
-    }
-}
-
-template <int PF, int THREADS>
-__device__ __forceinline__ void group_commit(const uint4 (&pf)[PF], uint2 *tbuf,
-                                             const int32_t *__restrict__ root, int t, int t1,
-                                             int tree_words, int tid)
-{
-    const int nv = (root[t1] - root[t]) >> 1;
-    if (nv * 2 > tree_words) return;
-    uint4 *dst = reinterpret_cast<uint4 *>(tbuf);
-#pragma unroll
-    for (int q = 0; q < PF; q++) {
-        const int i = tid + q * THREADS;
-        if (i < nv) dst[i] = pf[q];
-    }
-}
+// The next tree (group) travels global -> registers (prefetch, issued before
+// the current one is walked) -> LDS (commit, afterwards).  The registers are
+// individually named (X-macros), not an array: the compiler demoted arrays to
+// scratch memory here.  The loads are unconditional with a clamped index:
+// nothing may consume a loaded value before the walk, or the compiler waits
+// for the load on the spot.
+#define PK_PF8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define PK_PF16(X) PK_PF8(X) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define PK_PF_DECL(q) uint4 pf##q;
+#define PK_PF_LOAD(q) pf##q = pf_src[min(pf_tid + (q) * pf_stride, pf_nv - 1)];
+#define PK_PF_STORE(q) \
+    if (pf_tid + (q) * pf_stride < pf_nv) pf_dst[pf_tid + (q) * pf_stride] = pf##q;
 
 template <int SLOTS>
 __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
@@ -242,9 +222,8 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     double *__restrict__ prob, int tree_words, int dbg, long long *__restrict__ stamps)
 {
     constexpr int THREADS = LDS_C * SLOTS;
-    // registers per thread for the prefetched group: the launcher keeps
-    // tree_words <= THREADS * PF * 2
-    constexpr int PF = 8;
+    // 8 x uint4 registers per thread hold the prefetched group: the launcher
+    // keeps tree_words <= THREADS * 8 * 2
     extern __shared__ __attribute__((aligned(16))) float fea[];  // [F][128] | val | trees
     double *val = reinterpret_cast<double *>(fea + (size_t)F * LDS_C);  // [SLOTS][128]
     uint2 *tbuf = reinterpret_cast<uint2 *>(val + SLOTS * LDS_C);       // tree_words + 2 pad
@@ -268,11 +247,17 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
 
     // group g = trees [grp[g], grp[g+1]); grp[n_grp+2+g] = staged in LDS or not
     const int32_t *gstaged = grp + n_grp + 2;
-    uint4 pf[PF];  // the next group, in flight / parked in VGPRs
+    PK_PF8(PK_PF_DECL)  // the next group, in flight / parked in VGPRs
+    const int pf_tid = tid, pf_stride = THREADS;
+    const uint4 *pf_src;
+    uint4 *const pf_dst = reinterpret_cast<uint4 *>(tbuf);
+    int pf_nv;
     int t = grp[0], t1 = grp[1];
     if (gstaged[0]) {
-        group_prefetch<PF, THREADS>(pf, nodes, root, t, t1, tree_words, tid);
-        group_commit<PF, THREADS>(pf, tbuf, root, t, t1, tree_words, tid);
+        pf_src = reinterpret_cast<const uint4 *>(nodes + root[t]);
+        pf_nv = (root[t1] - root[t]) >> 1;
+        PK_PF8(PK_PF_LOAD)
+        PK_PF8(PK_PF_STORE)
     }
     __syncthreads();  // feature tile and first group are in LDS
 
@@ -293,8 +278,11 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
         const int tn = t1, tn1 = grp[g + 2];
         const bool next_staged = (g + 1 < n_grp) && gstaged[g + 1] != 0;
         PK_STAMP(0);
-        if (next_staged)  // loads fly while this group is walked
-            group_prefetch<PF, THREADS>(pf, nodes, root, tn, tn1, tree_words, tid);
+        if (next_staged) {  // loads fly while this group is walked
+            pf_src = reinterpret_cast<const uint4 *>(nodes + root[tn]);
+            pf_nv = (root[tn1] - root[tn]) >> 1;
+            PK_PF8(PK_PF_LOAD)
+        }
         if (active && slot < gt && !(dbg & 2)) {
             double v;
             if (staged) {
@@ -308,7 +296,7 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
         PK_STAMP(1);
         __syncthreads();  // every walk of the group is done: tbuf may be overwritten
         PK_STAMP(2);
-        if (next_staged) group_commit<PF, THREADS>(pf, tbuf, root, tn, tn1, tree_words, tid);
+        if (next_staged) { PK_PF8(PK_PF_STORE) }
         if (slot == 0 && active) {
             for (int j = 0; j < gt; j++) acc += val[j * LDS_C + cl];  // tree order
         }
@@ -320,6 +308,169 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     }
     if (slot == 0 && valid) prob[c] = active ? acc / (double)T : 0.0;
 #undef PK_STAMP
+}
+
+// ------------------------------------------------------------------------
+// v3: barrier-free tree pipeline.
+//
+// In v2 about 40 % of a tree group's time is lost to the two workgroup
+// barriers and the exposed LDS commit between them (in-kernel stamps,
+// DESIGN.md).  Here every tree SLOT (a pair of waves covering the workgroup's
+// 128 candidates, one candidate per lane) runs on its own: slot s walks trees
+// s, s+S, s+2S, ... from a private LDS region sized for the largest tree.
+// While a wave walks tree t it holds its half of tree t+S in registers
+// (global loads issued before the walk); when BOTH waves of the slot have
+// finished walking (an LDS counter, not a workgroup barrier) each writes its
+// half into the region, and when both halves have landed they walk on.  Slots
+// never wait for each other, so one slot's commit overlaps the other slots'
+// walks.  Leaf values go through an LDS ring of R trees with generation
+// flags; the two waves of slot 0 consume the ring in tree order (each its own
+// 64 candidates), which keeps the float64 sum sequential as in sklearn.
+// Producers wait only when they are R trees ahead of the consumer.  Every
+// spin is bounded; on a timeout the kernel raises an error word instead of
+// hanging.  (A first version with one wave per slot and two candidates per
+// lane ran 2.3x slower than v2: 6 waves per CU issue too slowly.)
+// ------------------------------------------------------------------------
+constexpr int PIPE_R = 16;                        // ring entries (trees)
+constexpr int PIPE_REGION_MAX = 2 * 64 * 8 * 2;   // words a region can hold (2 waves x 8 uint4/lane)
+constexpr int PIPE_SPIN_LIMIT = 1 << 22;
+
+__device__ __forceinline__ bool spin_until_ge(const int *ctr, int target)
+{
+    for (int spin = 0; spin <= PIPE_SPIN_LIMIT; spin++) {
+        if (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target)
+            return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+template <int S>
+__global__ __launch_bounds__(LDS_C *S) void forest_pipe_kernel(
+    const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
+    const int32_t *__restrict__ big_roff, const int32_t *__restrict__ tree_staged, int T, int F,
+    const float *__restrict__ tiles, const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
+    double *__restrict__ prob, int region_words, int dbg, long long *__restrict__ errword)
+{
+    constexpr int THREADS = LDS_C * S;
+    extern __shared__ __attribute__((aligned(16))) float fea[];     // [F][128]
+    double *val = reinterpret_cast<double *>(fea + (size_t)F * LDS_C);  // [R][128]
+    int *ready = reinterpret_cast<int *>(val + PIPE_R * LDS_C);     // [R][2] tree published, per half
+    int *cons = ready + 2 * PIPE_R;                                 // [2] trees consumed, per half
+    int *walked = cons + 2;                                         // [S] waves done walking (counts up)
+    int *landed = walked + 8;                                       // [S] waves done committing
+    uint2 *regions = reinterpret_cast<uint2 *>(ready + 64);         // S regions (256 B of flags)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave >> 1, half = wave & 1;
+    const int cl = half * 64 + lane;
+    const int64_t tile = blockIdx.x;
+    uint2 *reg = regions + (size_t)slot * region_words;
+    if (tid < 64) ready[tid] = tid < 2 * PIPE_R ? -1 : 0;  // ready = -1, cons/walked/landed = 0
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(tiles + (size_t)tile * F * LDS_C);
+        float4 *dst = reinterpret_cast<float4 *>(fea);
+        const int nvec = F * LDS_C / 4;
+        for (int i = tid; i < nvec; i += THREADS) dst[i] = src[i];
+    }
+    // this slot's first tree: each wave moves its half (uint4 index = half*64 + lane + 128 q)
+    PK_PF8(PK_PF_DECL)
+    const int pf_tid = cl, pf_stride = LDS_C;
+    const uint4 *pf_src;
+    uint4 *const pf_dst = reinterpret_cast<uint4 *>(reg);
+    int pf_nv = 1;
+    int t = slot;
+    if (t < T && tree_staged[t]) {
+        pf_src = reinterpret_cast<const uint4 *>(nodes + root[t]);
+        pf_nv = (root[t + 1] - root[t]) >> 1;
+        PK_PF8(PK_PF_LOAD)
+        PK_PF8(PK_PF_STORE)
+    }
+    __syncthreads();  // the only workgroup barrier: tile + flags + first trees are in LDS
+
+    const int64_t local = tile * LDS_C + cl;
+    const bool valid = local < cn;
+    const unsigned st = valid ? status[c0 + local] : 0;
+    const bool active = st != 0;
+    const bool wave_nan = __any(st == 2);
+    const char *fea_b = reinterpret_cast<const char *>(fea);
+    const int cl4 = cl << 2;
+
+    double acc = 0.0;  // slot 0 only
+    int next = 0;      // slot 0 only: next tree to add
+    bool ok = true;
+    // slot 0: add every published tree of this half, in tree order
+    auto consume = [&]() {
+        while (next < T &&
+               __hip_atomic_load(&ready[2 * (next & (PIPE_R - 1)) + half], __ATOMIC_ACQUIRE,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP) == next) {
+            acc += val[(next & (PIPE_R - 1)) * LDS_C + cl];
+            next++;
+        }
+        __hip_atomic_store(&cons[half], next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+
+    int round = 0;
+    for (; t < T; t += S, round++) {  // wave-uniform
+        // scalar (SGPR) tree index: the root / flag lookups become s_loads and do
+        // not share the vector-memory counter with the prefetch below
+        t = __builtin_amdgcn_readfirstlane(t);
+        const int tn = t + S;
+        const bool cur_staged = tree_staged[t] != 0;
+        const bool nxt_staged = tn < T && tree_staged[tn] != 0;
+        if (nxt_staged) {  // loads fly while this tree is walked
+            pf_src = reinterpret_cast<const uint4 *>(nodes + root[tn]);
+            pf_nv = (root[tn + 1] - root[tn]) >> 1;
+            PK_PF8(PK_PF_LOAD)
+        }
+        double v = 0.0;
+        if (active && !(dbg & 2)) {
+            if (cur_staged) {
+                const char *ra = reinterpret_cast<const char *>(reg);
+                v = wave_nan ? walk_tree_lds<true>(fea_b, cl4, ra) : walk_tree_lds<false>(fea_b, cl4, ra);
+            } else {
+                v = walk_tree_global(nodes, big_roff, root[t], fea, cl);
+            }
+        }
+        // this wave no longer reads the region
+        if (lane == 0)
+            __hip_atomic_fetch_add(&walked[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // ring space: tree t may be published once tree t-R has been consumed (this half)
+        if (slot == 0) {
+            consume();
+            for (int spin = 0; t >= next + PIPE_R && ok; spin++) {
+                __builtin_amdgcn_s_sleep(1);
+                consume();
+                ok = spin <= PIPE_SPIN_LIMIT;
+            }
+        } else {
+            ok = ok && spin_until_ge(&cons[half], t - PIPE_R + 1);
+        }
+        val[(t & (PIPE_R - 1)) * LDS_C + cl] = v;
+        __hip_atomic_store(&ready[2 * (t & (PIPE_R - 1)) + half], t, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tn < T) {
+            // both waves of the slot are done with tree t -> the next tree may move in
+            ok = ok && spin_until_ge(&walked[slot], 2 * (round + 1));
+            if (nxt_staged) { PK_PF8(PK_PF_STORE) }
+            if (lane == 0)
+                __hip_atomic_fetch_add(&landed[slot], 1, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot == 0) consume();
+            // both halves of tree t+S are in the region
+            ok = ok && spin_until_ge(&landed[slot], 2 * (round + 1));
+        }
+    }
+    if (slot == 0) {
+        for (int spin = 0; next < T && ok; spin++) {
+            consume();
+            if (next < T) __builtin_amdgcn_s_sleep(2);
+            ok = spin <= PIPE_SPIN_LIMIT;
+        }
+        if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
+    }
+    if (!ok && lane == 0) errword[0] = 1;  // host turns this into PK_E_HIP
 }
 
 // row-major [N][F] float32 -> [tile][F][blk] tiles (pk_predict's input path):
@@ -404,6 +555,34 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
                            (int)g_opt.forest_dbg, ctx->dbg_buf);                              \
     } while (0)
 
+#define PK_LAUNCH_PIPE(SS)                                                                    \
+    do {                                                                                      \
+        int rc__ = set_max_lds(forest_pipe_kernel<SS>, lds);                                  \
+        if (rc__) return rc__;                                                                \
+        hipLaunchKernelGGL(forest_pipe_kernel<SS>, dim3(grid), dim3(LDS_C * (SS)), lds,       \
+                           ctx->stream, f->nodes, f->root, f->big_roff, f->tree_staged, f->T, \
+                           f->F, tiles, d_status, c0, cn, d_prob, region_words,               \
+                           (int)g_opt.forest_dbg, ctx->dbg_buf + 65535);                      \
+    } while (0)
+
+// The barrier-free pipeline needs a private region per slot that holds the
+// largest (stageable) tree.  Measured on config 2 (largest tree 13.7 KB, only 6
+// regions fit): 9.05 ms vs 7.5 ms for the barrier-separated groups with 16
+// waves; its time scales as 1/slots, so it is chosen automatically only when 8
+// regions fit (forest_pipe=1), or forced for experiments (forest_pipe=2, >= 4).
+static int pipe_shape(pk_forest *f, size_t fea_bytes, int *slots, int *region_words)
+{
+    int rw = f->max_tree_words > PIPE_REGION_MAX ? PIPE_REGION_MAX : f->max_tree_words;
+    rw = ((rw + 1) & ~1) + 2;
+    const size_t fixed = fea_bytes + (size_t)PIPE_R * LDS_C * sizeof(double) + 256;
+    if (fixed >= (size_t)160 * 1024) return 0;
+    int s = (int)(((size_t)160 * 1024 - fixed) / ((size_t)rw * sizeof(uint2)));
+    if (s > 8) s = 8;
+    *slots = s;
+    *region_words = rw;
+    return g_opt.forest_pipe >= 2 ? s >= 4 : s >= 8;
+}
+
 int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int blk,
                      const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob)
 {
@@ -412,7 +591,23 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
     const unsigned grid = (unsigned)((cn + blk - 1) / blk);
     const size_t fea_bytes = (size_t)f->F * blk * sizeof(float);
     const int ilp = (int)g_opt.forest_ilp;
-    if (blk == LDS_C && g_opt.forest_lds > 0) {
+    int pslots = 0, region_words = 0;
+    if (blk == LDS_C && g_opt.forest_lds > 0 && g_opt.forest_pipe &&
+        pipe_shape(f, fea_bytes, &pslots, &region_words)) {
+        int rc = pk_forest_stage_flags(f, region_words - 2);
+        if (rc) return rc;
+        if (g_opt.forest_pipe_slots >= 4 && g_opt.forest_pipe_slots < pslots)
+            pslots = (int)g_opt.forest_pipe_slots;
+        const size_t lds = fea_bytes + (size_t)PIPE_R * LDS_C * sizeof(double) + 256 +
+                           (size_t)pslots * region_words * sizeof(uint2);
+        switch (pslots) {
+        case 4: PK_LAUNCH_PIPE(4); break;
+        case 5: PK_LAUNCH_PIPE(5); break;
+        case 6: PK_LAUNCH_PIPE(6); break;
+        case 7: PK_LAUNCH_PIPE(7); break;
+        default: PK_LAUNCH_PIPE(8); break;
+        }
+    } else if (blk == LDS_C && g_opt.forest_lds > 0) {
         switch ((int)g_opt.forest_slots) {
         case 2: PK_LAUNCH_LDS(2); break;
         case 4: PK_LAUNCH_LDS(4); break;

@@ -44,19 +44,25 @@ def test_extract_golden(hip_lib, name):
 
 
 @pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
-@pytest.mark.parametrize("ilp,lds,slots", [(4, 0, 8), (1, 0, 8), (8, 0, 8), (4, 160, 8),
-                                           (4, 160, 4), (4, 160, 2), (4, 160, 6), (4, 2, 8),
-                                           (4, 1, 4)])
-def test_forest_golden(hip_lib, tag, ilp, lds, slots):
+@pytest.mark.parametrize("ilp,lds,slots,pipe", [(4, 0, 8, 0), (1, 0, 8, 0), (8, 0, 8, 0),
+                                                (4, 160, 8, 0), (4, 160, 4, 0), (4, 160, 2, 0),
+                                                (4, 160, 6, 0), (4, 2, 8, 0), (4, 1, 4, 0),
+                                                (4, 160, 8, 1), (4, 160, 4, 4), (4, 160, 8, 6)])
+def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe):
     """Every forest kernel variant: nodes via L2 (lds=0) with 1/4/8 chains per
-    lane; trees streamed through LDS with 2..8 tree slots; a tree buffer so
-    small (1-2 KiB) that some trees are walked from global memory."""
+    lane; trees streamed through LDS in barrier-separated groups with 2..8
+    tree slots; a tree buffer so small (1-2 KiB) that some trees are walked
+    from global memory; the barrier-free per-wave pipeline (pipe>0: number of
+    waves, 1 = as many as fit)."""
     z = gio.load("g2_forest_%s.npz" % tag)
     X = gio.load("g2_forest_plain.npz")["X"]
-    old = {k: _lib.load().pk_get_option(k.encode()) for k in ("forest_ilp", "forest_lds", "forest_slots")}
+    old = {k: _lib.load().pk_get_option(k.encode())
+           for k in ("forest_ilp", "forest_lds", "forest_slots", "forest_pipe", "forest_pipe_slots")}
     _lib.set_option("forest_ilp", ilp)
     _lib.set_option("forest_lds", lds)
     _lib.set_option("forest_slots", slots)
+    _lib.set_option("forest_pipe", 2 if pipe else 0)
+    _lib.set_option("forest_pipe_slots", pipe if pipe >= 4 else 0)
     try:
         hf = _lib.HipForest(flat(gio.forest(z)))
         p = hf.predict(X)
