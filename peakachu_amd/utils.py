@@ -27,23 +27,31 @@ def canonical_csr(M):
 
 def band_filter(M, width, upper):
     """peakachu/scoreUtils.py:30-33: keep finite entries with
-    -2w < col-row < upper+2w (both strict)."""
-    coo = sparse.csr_matrix(M).tocoo()
-    R, C, data = coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data
-    ok = (data != 0) & np.isfinite(data) & (C - R > -2 * width) & (C - R < upper + 2 * width)
-    out = sparse.csr_matrix((data[ok], (R[ok], C[ok])), shape=M.shape, dtype=np.float64)
-    out.sum_duplicates()
-    out.sort_indices()
+    -2w < col-row < upper+2w (both strict).  Works on the CSR arrays directly
+    (no COO round trip): the result is canonical because the input is."""
+    M = canonical_csr(M)
+    n = M.shape[0]
+    indices = M.indices.astype(np.int32, copy=False)
+    R = np.repeat(np.arange(n, dtype=np.int32), np.diff(M.indptr))
+    k = indices - R
+    data = M.data
+    ok = (data != 0) & np.isfinite(data) & (k > -2 * width) & (k < upper + 2 * width)
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(R[ok], minlength=n), out=indptr[1:])
+    out = sparse.csr_matrix((data[ok], indices[ok], indptr.astype(np.int32)), shape=M.shape)
+    out.has_sorted_indices = True
     return out
 
 
-def _dense_diagonals(R, C, data, n, maxdis):
-    """D[k, r] = M[r, r+k] for 0 <= k <= maxdis (upper band, dense)."""
-    k = C - R
-    ok = (k >= 0) & (k <= maxdis)
-    D = np.zeros((maxdis + 1, n), np.float64)
-    D[k[ok], R[ok]] = data[ok]
-    return D
+def _dense_diagonals(indptr, indices, data, keep, n, maxdis):
+    """D[k, r] = M[r, r+k] for 0 <= k <= maxdis over the entries flagged in
+    `keep` (upper band, dense; one gather + one scatter, int32 arithmetic)."""
+    R = np.repeat(np.arange(n, dtype=np.int32), np.diff(indptr))
+    k = indices - R
+    sel = np.flatnonzero(keep & (k >= 0) & (k <= maxdis))
+    D = np.zeros((maxdis + 1) * n, np.float64)
+    D[k[sel].astype(np.int64) * n + R[sel]] = data[sel]
+    return D.reshape(maxdis + 1, n)
 
 
 def calculate_expected(M, maxdis, raw=False):
@@ -53,24 +61,28 @@ def calculate_expected(M, maxdis, raw=False):
 
     M = canonical_csr(M)
     n = M.shape[0]
-    coo = M.tocoo()
-    R, C, data = coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data
+    indices = M.indices.astype(np.int32, copy=False)
+    data = M.data
     nz = data != 0  # M.nonzero() semantics
-    R, C, data = R[nz], C[nz], data[nz]
-    finite = np.isfinite(data)
+    finite = np.isfinite(data) & nz
     if raw:
-        R, C, data = R[finite], C[finite], data[finite]
-        marg = np.zeros(n)
-        np.add.at(marg, C, data)
+        # column sums of the finite entries; only their sign is used
+        marg = np.bincount(indices[finite], weights=data[finite], minlength=n)
         valid_cols = marg > 0
+        keep = finite
     else:
         valid_cols = np.zeros(n, dtype=bool)
-        valid_cols[R[finite]] = True
-        valid_cols[C[finite]] = True
+        valid_cols[indices[finite]] = True  # the matrix is symmetric in practice, but
+        rows_with = np.add.reduceat(finite.astype(np.int64), M.indptr[:-1].clip(max=max(finite.size - 1, 0))) \
+            if finite.size else np.zeros(n, np.int64)
+        rows_with = np.where(np.diff(M.indptr) > 0, rows_with, 0)
+        valid_cols[rows_with > 0] = True    # ... rows are marked too, as the reference does
+        keep = nz  # the reference keeps NaN entries in the diagonals here
     maxdis = int(maxdis)
-    D = _dense_diagonals(R, C, data, n, min(maxdis, n - 1))
+    top = min(maxdis, n - 1)
+    D = _dense_diagonals(M.indptr, indices, data, keep, n, top)
     exp_arr = np.zeros(maxdis + 1)
-    for i in range(min(maxdis, n - 1) + 1):
+    for i in range(top + 1):
         valid = valid_cols if i == 0 else valid_cols[:-i] * valid_cols[i:]
         diag = D[i, :n - i][valid]
         if diag.size > 10:
@@ -81,6 +93,29 @@ def calculate_expected(M, maxdis, raw=False):
     return IR.predict(list(range(maxdis + 1)))
 
 
+def _poisson_count_thresholds(mu):
+    """For each expected count mu[i] > 0 the smallest integer k >= 1 with
+    scipy.stats.poisson.sf(k, mu[i]) < 0.01, found with scipy's own sf so the
+    decision is the reference's (sf is non-increasing in k)."""
+    mu = np.asarray(mu, np.float64)
+    out = np.full(mu.size, np.iinfo(np.int64).max, np.int64)
+    good = np.isfinite(mu) & (mu > 0)
+    for i in np.flatnonzero(good):
+        hi = int(mu[i] + 10.0 * np.sqrt(mu[i]) + 30)
+        while True:
+            ks = np.arange(1, hi + 1, dtype=np.float64)
+            with np.errstate(all="ignore"):
+                p = stats.poisson.sf(ks, mu[i])
+            hit = np.flatnonzero(p < 0.01)
+            if hit.size:
+                out[i] = int(ks[hit[0]])
+                break
+            hi *= 2
+            if hi > 1 << 24:
+                break
+    return out
+
+
 def candidates(raw_M, background, weights, lower, upper):
     """peakachu/scoreUtils.py:40-68: Poisson survival p-value of every
     non-zero raw pixel on diagonals lower..upper against the expected count
@@ -88,25 +123,31 @@ def candidates(raw_M, background, weights, lower, upper):
     Order: diagonal ascending, then row ascending."""
     raw_M = canonical_csr(raw_M)
     n = raw_M.shape[0]
-    coo = raw_M.tocoo()
-    R, C, data = coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data
+    R = np.repeat(np.arange(n, dtype=np.int64), np.diff(raw_M.indptr))
+    C = raw_M.indices.astype(np.int64)
+    data = raw_M.data
     k = C - R
     e = np.asarray(background, np.float64)
     hi = min(int(upper), e.size - 1, n - 1)
-    ok = (k >= int(lower)) & (k <= hi)
+    ok = (k >= int(lower)) & (k <= hi) & (data > 0)
     R, k, data = R[ok], k[ok], data[ok]
     ok = e[k] > 0
     R, k, data = R[ok], k[ok], data[ok]
-    order = np.lexsort((R, k))
-    R, k, data = R[order], k[order], data[order]
-    if weights is None:
-        mu = np.ones(R.size, dtype=float) * e[k]
+    if weights is None and np.all(data == np.floor(data)):
+        # raw mode: the expected count is one number per diagonal, so
+        # sf(count, mu_d) < 0.01  <=>  count >= kstar[d]
+        kstar = _poisson_count_thresholds(e[:hi + 1])
+        mask = data >= kstar[k]
     else:
-        w = np.asarray(weights, np.float64)
-        mu = np.ones(R.size, dtype=float) * e[k] / (w[R] * w[R + k])
-    with np.errstate(all="ignore"):
-        p = stats.poisson.sf(data, mu)
-    mask = (data > 0) & np.isfinite(p)
-    mask &= p < 0.01
-    x = R[mask]
-    return x.astype(np.int64), (x + k[mask]).astype(np.int64)
+        if weights is None:
+            mu = np.ones(R.size, dtype=float) * e[k]
+        else:
+            w = np.asarray(weights, np.float64)
+            mu = np.ones(R.size, dtype=float) * e[k] / (w[R] * w[R + k])
+        with np.errstate(all="ignore"):
+            p = stats.poisson.sf(data, mu)
+        mask = np.isfinite(p) & (p < 0.01)
+    x, kk = R[mask], k[mask]
+    order = np.lexsort((x, kk))
+    x, kk = x[order], kk[order]
+    return x.astype(np.int64), (x + kk).astype(np.int64)
