@@ -184,6 +184,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_lds = value;
     } else if (!strcmp(name, "extract_block")) {
         g_opt.extract_block = value;
+    } else if (!strcmp(name, "extract_pair")) {
+        g_opt.extract_pair = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
         if (value != 2 && value != 4 && value != 6 && value != 8) return PK_E_INVALID;
         g_opt.forest_slots = value;
@@ -209,6 +211,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_ilp")) return g_opt.forest_ilp;
     if (!strcmp(name, "forest_lds")) return g_opt.forest_lds;
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
+    if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
     if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
     if (!strcmp(name, "extract_block")) return g_opt.extract_block;

@@ -56,6 +56,7 @@ struct pk_options {
     int64_t forest_slots = 8;   // LDS kernel: tree slots (wave pairs) per workgroup
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
     int64_t extract_block = 64; // threads per extract block
+    int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
     int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
     int64_t forest_pipe_slots = 0;  // 0 = as many as fit (max 8)
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)

@@ -204,6 +204,214 @@ __global__ __launch_bounds__(64) void extract_reg_kernel(
 }
 
 // ------------------------------------------------------------------------
+// Pair kernel: TWO lanes per candidate (default for w = 5, 6).
+//
+// The one-lane kernel above needs 346 (w=5) / 504 (w=6) registers, i.e. one
+// wave per SIMD, and its dependent FP64 chains run ~2.5x off the issue rate
+// with nothing to overlap.  Here lane A (even) owns window columns 0..w and
+// lane B (odd) owns the SAME window rotated by 180 degrees (its local cell
+// (i, q) is the global cell (2w-i, 2w-q)), so both lanes run identical code in
+// local coordinates: local column 0 is a window edge (scipy's `reflect`),
+// local column w is the centre column, and the "virtual" columns w+1..w+4
+// needed by the row blur are the partner's local columns w-1..w-4 (of its
+// local row 2w-i), fetched with one DPP lane swap each.  The Gaussian taps are
+// symmetric and IEEE addition commutes, so every sum is the sum scipy
+// computes; the column blur (axis 0) needs no exchange at all.  The half
+// window takes 132 (w=5) / 182 (w=6) registers -> 2 waves per SIMD.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ double lane_swap(double v)
+{
+    // quad_perm [1,0,3,2]: exchange with the neighbouring lane (the partner)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int lane_swap_i(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+}
+
+// row blur of one local row: own columns 0..W plus 4 virtual columns
+template <int W>
+__device__ __forceinline__ void blur_row(const double (&row)[W + 5], double (&out)[W + 1])
+{
+#define RR(q_) row[(q_) < 0 ? -(q_) - 1 : (q_)]
+#pragma unroll
+    for (int q = 0; q <= W; q++)
+        out[q] = PK_BLUR9(row[q], RR(q - 4), row[q + 4], RR(q - 3), row[q + 3], RR(q - 2),
+                          row[q + 2], RR(q - 1), row[q + 1]);
+#undef RR
+}
+
+// (w=6 needs 273 registers: one wave per SIMD; forcing two spills and is slower)
+template <int W>
+__global__ __launch_bounds__(64, (W <= 5 ? 2 : 1)) void extract_pair_kernel(
+    const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
+    const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
+    const int32_t *__restrict__ ys, int64_t c0, int64_t cn, float *__restrict__ tiles, int blk,
+    uint8_t *__restrict__ status, double *__restrict__ fea64_rows)
+{
+    constexpr int S = 2 * W + 1;
+    constexpr int F = S * S;
+    constexpr int H = W + 1;  // local columns 0..W
+    static_assert(W >= 4, "the row blur borrows 4 partner columns");
+    const int role = threadIdx.x & 1;  // 0: lane A, 1: lane B (rotated window)
+    const int64_t local = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 1);
+    // both lanes of a pair share `local`, xi, yi and therefore every decision.
+    // No early return: the DPP swaps need both lanes of every pair alive; a pair
+    // that is out of range or filtered keeps computing on safe dummy coordinates
+    // and simply stores nothing.
+    const bool in_range = local < cn;
+    const int64_t c = c0 + (in_range ? local : 0);
+    const int xi = xs[c], yi = ys[c];
+    bool ok = in_range && (xi - W >= 0 && yi + W + 1 <= n);  // scoreUtils.py:75
+    const int xc = ok ? xi : 0, yc = ok ? yi : 0;
+    const int d = yc - xc;
+    const int sgn = role ? -1 : 1;
+    const int64_t r0 = (int64_t)(xc - W);
+
+    // ---- gather: local (i, q) = global (gi, gj), diagonal k = d + gj - gi = d + sgn (q - i)
+    double win[S][H];
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const int gi = role ? 2 * W - i : i;
+            const int k = d + sgn * (q - i);
+            double v = 0.0;
+            if (ok && k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + gi];
+            win[i][q] = v;
+        }
+    }
+    // ---- utils.py:221-225: NaN -> 0, sparsity filter (B skips the shared centre column)
+    int nnz = 0;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            double v = win[i][q];
+            v = (v != v) ? 0.0 : v;
+            win[i][q] = v;
+            const bool mine = (q < W) || (role == 0);
+            nnz += (mine && v != 0.0) ? 1 : 0;
+        }
+    }
+    nnz += lane_swap_i(nnz);
+    ok = ok && !((double)nnz < (double)F * 0.1);
+    // ---- utils.py:228-232: top-left w x w mean (numba: sequential C order) = lane A's
+    // local rows / columns 0..w-1
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+#pragma unroll
+        for (int q = 0; q < W; q++) acc += win[i][q];
+    }
+    const double acc_partner = lane_swap(acc);
+    acc = role ? acc_partner : acc;
+    const double ll_mean = acc / (double)(W * W);
+    ok = ok && (ll_mean > 0.0);
+    const double p2ll = win[W][W] / ll_mean;  // the centre cell is local (W, W) in both lanes
+    ok = ok && (p2ll > 0.1);
+
+    // ---- utils.py:180-202: divide by expected(|col-row|), col-row = d + sgn (q - i)
+    const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
+    if (dmax < exp_len) {
+        double e[3 * W + 1];  // m = q - i + 2W runs over 0 .. 3W
+#pragma unroll
+        for (int m = 0; m <= 3 * W; m++) e[m] = exp_arr[iabs(d + sgn * (m - 2 * W))];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) win[i][q] = win[i][q] / e[q - i + 2 * W];
+        }
+    }
+    // ---- scipy gaussian_filter(sigma=1), axis 0: down each local column
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+        double col[S];
+#pragma unroll
+        for (int i = 0; i < S; i++) col[i] = win[i][q];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            win[i][q] = PK_BLUR9(col[i], col[reflect_idx(i - 4, S)], col[reflect_idx(i + 4, S)],
+                                 col[reflect_idx(i - 3, S)], col[reflect_idx(i + 3, S)],
+                                 col[reflect_idx(i - 2, S)], col[reflect_idx(i + 2, S)],
+                                 col[reflect_idx(i - 1, S)], col[reflect_idx(i + 1, S)]);
+        }
+    }
+    // ---- axis 1: along each local row.  My row i continues into the partner's local
+    // row 2W-i; rows i and 2W-i are processed together so that both still hold their
+    // axis-0 values when they are exchanged.
+#pragma unroll
+    for (int ip = 0; ip <= W; ip++) {
+        const int ia = ip, ib = S - 1 - ip;
+        double rowa[H + 4], rowb[H + 4], outa[H], outb[H];
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            rowa[q] = win[ia][q];
+            rowb[q] = win[ib][q];
+        }
+#pragma unroll
+        for (int u = 1; u <= 4; u++) {
+            rowa[W + u] = lane_swap(win[ib][W - u]);  // partner's row 2W-ia = ib
+            rowb[W + u] = lane_swap(win[ia][W - u]);
+        }
+        blur_row<W>(rowa, outa);
+        blur_row<W>(rowb, outb);
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            win[ia][q] = outa[q];
+            win[ib][q] = outb[q];  // ia == ib for the middle row: same values
+        }
+    }
+    // ---- utils.py:204-209 image_normalize; numpy min/max propagate NaN
+    double mn = win[0][0], mx = win[0][0];
+    int has_nan = 0;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const double v = win[i][q];
+            has_nan |= (v != v) ? 1 : 0;
+            mn = (v < mn) ? v : mn;
+            mx = (v > mx) ? v : mx;
+        }
+    }
+    {
+        const double omn = lane_swap(mn), omx = lane_swap(mx);
+        mn = (omn < mn) ? omn : mn;
+        mx = (omx > mx) ? omx : mx;
+        has_nan |= lane_swap_i(has_nan);
+    }
+    if (has_nan) {
+        mn = __builtin_nan("");
+        mx = mn;
+    }
+    const double den = mx - mn;
+    const int64_t tile = local / blk;
+    const int tl = (int)(local - tile * blk);
+    float *tp = tiles + (size_t)tile * F * blk + tl;
+    int fea_nan = 0;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const double v = (win[i][q] - mn) / den;
+            fea_nan |= (v != v) ? 1 : 0;
+            const bool mine = (q < W) || (role == 0);  // A stores the shared centre column
+            const int gi = role ? 2 * W - i : i, gj = role ? 2 * W - q : q;
+            if (ok && mine) {
+                tp[(size_t)(gi * S + gj) * blk] = (float)v;  // sklearn's float32 cast (RNE)
+                if (fea64_rows) fea64_rows[(size_t)local * F + gi * S + gj] = v;
+            }
+        }
+    }
+    fea_nan |= lane_swap_i(fea_nan);
+    if (in_range && role == 0) status[c] = ok ? (fea_nan ? 2 : 1) : 0;
+}
+
+// ------------------------------------------------------------------------
 // Generic kernel (any w <= 15): one candidate per 64-lane wave, window in LDS.
 // Used for w = 11 (23x23, 529 features) where a window no longer fits one
 // lane's registers.  Same operation order as above.
@@ -324,7 +532,17 @@ int pk_launch_extract(pk_device_ctx *ctx, const pk_matrix *m, int w, const int32
 {
     if (cn <= 0) return PK_OK;
     pk_prof_scope prof(ctx, PK_K_EXTRACT);
-    if (w == 5 || w == 6) {
+    if ((w == 5 || w == 6) && g_opt.extract_pair) {
+        const unsigned grid = (unsigned)((cn + 31) / 32);
+        if (w == 5)
+            hipLaunchKernelGGL(extract_pair_kernel<5>, dim3(grid), dim3(64), 0, ctx->stream, m->band,
+                               m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0, cn,
+                               tiles, blk, d_status, fea64_rows);
+        else
+            hipLaunchKernelGGL(extract_pair_kernel<6>, dim3(grid), dim3(64), 0, ctx->stream, m->band,
+                               m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0, cn,
+                               tiles, blk, d_status, fea64_rows);
+    } else if (w == 5 || w == 6) {
         const int threads = 64;
         const unsigned grid = (unsigned)((cn + threads - 1) / threads);
         if (w == 5)

@@ -72,11 +72,12 @@ def test_config2_properties(config2):
     assert np.array_equal(gio.bits(pr[order_in_input]), gio.bits(op))
     # invariance to chunking and kernel variant
     old = {k: _lib.load().pk_get_option(k.encode())
-           for k in ("chunk", "forest_slots", "forest_lds", "forest_pipe", "forest_pipe_slots")}
+           for k in ("chunk", "forest_slots", "forest_lds", "forest_pipe", "forest_pipe_slots",
+                     "extract_pair")}
     try:
         for opts in (dict(chunk=65536), dict(chunk=1000003), dict(forest_pipe=0),
                      dict(forest_pipe=0, forest_slots=4), dict(forest_pipe=2), dict(forest_pipe=2, forest_pipe_slots=4),
-                     dict(forest_lds=0)):
+                     dict(forest_lds=0), dict(extract_pair=0)):
             for k, v in opts.items():
                 _lib.set_option(k, v)
             cd2 = _lib.HipCands(x, y)

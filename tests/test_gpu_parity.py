@@ -23,9 +23,20 @@ def hip_matrix(Mf, exp_arr, w, upper):
                           -2 * w + 1, upper + 2 * w - 1)
 
 
+@pytest.mark.parametrize("pair", [1, 0])
 @pytest.mark.parametrize("name", ["g1_extract_w5.npz", "g1_extract_w6.npz", "g1_extract_w11.npz",
                                   "g1_extract_w5_balanced.npz"])
-def test_extract_golden(hip_lib, name):
+def test_extract_golden(hip_lib, name, pair):
+    """Both extract kernels for w=5/6 (two lanes per candidate, one lane per
+    candidate) and the LDS kernel for w=11."""
+    _lib.set_option("extract_pair", pair)
+    try:
+        _extract_golden(name)
+    finally:
+        _lib.set_option("extract_pair", 1)
+
+
+def _extract_golden(name):
     z = gio.load(name)
     w, upper = int(z["w"]), int(z["upper"])
     if "weights" in z.files:

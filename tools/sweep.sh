@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box helper: bench the forest variants back to back (one JSON line each).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for opts in ${SWEEP:-"forest_pipe=1" "forest_pipe=0" "forest_pipe=1,forest_pipe_slots=5" "forest_pipe=1,forest_pipe_slots=4"}; do
+for opts in ${SWEEP:-"extract_pair=1" "extract_pair=0"}; do
   args=""
   for o in ${opts//,/ }; do args="$args --opt $o"; done
   echo "== $opts"
