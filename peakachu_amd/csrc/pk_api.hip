@@ -38,19 +38,20 @@ static std::vector<prof_rec> g_prof_pending;
 static double g_prof_ms[PK_K_NCLASS] = {0, 0, 0, 0};
 static int64_t g_prof_n[PK_K_NCLASS] = {0, 0, 0, 0};
 
-pk_prof_scope::pk_prof_scope(pk_device_ctx *c, pk_kclass kk) : ctx(c), k(kk)
+pk_prof_scope::pk_prof_scope(pk_device_ctx *c, pk_kclass kk, hipStream_t s)
+    : ctx(c), k(kk), st(s ? s : c->stream)
 {
     if (!g_prof_on) return;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
         e0 = e1 = nullptr;
         return;
     }
-    hipEventRecord(e0, ctx->stream);
+    hipEventRecord(e0, st);
 }
 pk_prof_scope::~pk_prof_scope()
 {
     if (!e0) return;
-    hipEventRecord(e1, ctx->stream);
+    hipEventRecord(e1, st);
     g_prof_pending.push_back({e0, e1, k, ctx->device});
 }
 
@@ -101,7 +102,18 @@ pk_device_ctx *pk_ctx(int device)
     pk_device_ctx *c = new pk_device_ctx();
     c->device = device;
     c->cu_count = prop.multiProcessorCount;
-    PK_HIP_NULL(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        // the forest stream gets the highest priority, the extractor stream the lowest:
+        // extractor waves fill the registers / issue slots the forest leaves idle
+        int lo = 0, hi = 0;
+        PK_HIP_NULL(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PK_HIP_NULL(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        PK_HIP_NULL(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+        for (int i = 0; i < 2; i++) {
+            PK_HIP_NULL(hipEventCreateWithFlags(&c->ev_ext[i], hipEventDisableTiming));
+            PK_HIP_NULL(hipEventCreateWithFlags(&c->ev_for[i], hipEventDisableTiming));
+        }
+    }
     PK_HIP_NULL(hipMalloc((void **)&c->dbg_buf, 65536 * sizeof(long long)));
     PK_HIP_NULL(hipMemset(c->dbg_buf, 0, 65536 * sizeof(long long)));
     g_ctx[device] = c;
@@ -165,6 +177,7 @@ extern "C" int pk_device_synchronize(int device)
 {
     pk_device_ctx *c = pk_ctx(device);
     if (!c) return PK_E_NODEVICE;
+    PK_HIP(hipStreamSynchronize(c->stream2));
     PK_HIP(hipStreamSynchronize(c->stream));
     PK_HIP(hipDeviceSynchronize());
     return PK_OK;
@@ -184,6 +197,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_lds = value;
     } else if (!strcmp(name, "extract_block")) {
         g_opt.extract_block = value;
+    } else if (!strcmp(name, "overlap")) {
+        g_opt.overlap = value != 0;
     } else if (!strcmp(name, "extract_pair")) {
         g_opt.extract_pair = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
@@ -212,6 +227,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_lds")) return g_opt.forest_lds;
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
     if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
+    if (!strcmp(name, "overlap")) return g_opt.overlap;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
     if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
     if (!strcmp(name, "extract_block")) return g_opt.extract_block;
@@ -652,15 +668,37 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     }
     int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
     if (chunk > cd->N) chunk = (cd->N + blk - 1) / blk * blk;
-    int rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
+    const size_t tile_floats = (size_t)chunk * F;
+    int rc = pk_ctx_reserve_tiles(ctx, 2 * tile_floats * sizeof(float));
     if (rc) return rc;
-    for (int64_t c0 = 0; c0 < cd->N; c0 += chunk) {
+    // Two tile buffers: extract(k+1) runs on the low-priority stream beside forest(k).
+    // The forest kernel is LDS / latency bound and leaves ~40 % of the VALU issue slots
+    // and (at <= 72 VGPRs) room for one 216-register extractor wave per SIMD, which is
+    // FP64-VALU bound: the two kernels are complementary on a CU.
+    const bool overlap = g_opt.overlap != 0;
+    hipStream_t st_ext = overlap ? ctx->stream2 : ctx->stream;
+    if (overlap) {
+        // whatever precedes on the main stream (uploads) must be visible to the extractor
+        PK_HIP(hipEventRecord(ctx->ev_for[0], ctx->stream));
+        PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[0], 0));
+    }
+    int64_t k = 0;
+    for (int64_t c0 = 0; c0 < cd->N; c0 += chunk, k++) {
         const int64_t cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
-        rc = pk_launch_extract(ctx, m, w, cd->x, cd->y, c0, cn, ctx->fea_tiles, blk, cd->status,
+        const int buf = (int)(k & 1);
+        float *tiles = ctx->fea_tiles + (size_t)buf * tile_floats;
+        if (overlap && k >= 2)  // forest(k-2) must be done with this buffer
+            PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[buf], 0));
+        rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0, cn, tiles, blk, cd->status,
                                nullptr);
         if (rc) return rc;
-        rc = pk_launch_forest(ctx, f, ctx->fea_tiles, blk, cd->status, c0, cn, cd->prob);
+        if (overlap) {
+            PK_HIP(hipEventRecord(ctx->ev_ext[buf], st_ext));
+            PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[buf], 0));
+        }
+        rc = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob);
         if (rc) return rc;
+        if (overlap) PK_HIP(hipEventRecord(ctx->ev_for[buf], ctx->stream));
     }
     return PK_OK;
 }
@@ -790,8 +828,8 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     int64_t nk = 0;
     for (int64_t c0 = 0; !rc && c0 < N; c0 += chunk) {
         const int64_t cn = N - c0 < chunk ? N - c0 : chunk;
-        rc = pk_launch_extract(ctx, m, w, cd->x, cd->y, c0, cn, ctx->fea_tiles, blk, cd->status,
-                               d_rows);
+        rc = pk_launch_extract(ctx, ctx->stream, m, w, cd->x, cd->y, c0, cn, ctx->fea_tiles, blk,
+                               cd->status, d_rows);
         if (rc) break;
         if (hipMemcpyAsync(h_rows.data(), d_rows, (size_t)cn * F * 8, hipMemcpyDeviceToHost,
                            ctx->stream) != hipSuccess ||

@@ -37,8 +37,11 @@ void pk_set_error(const char *fmt, ...);
 // the reusable scratch (feature tiles) sized by the "chunk" option.
 struct pk_device_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
-    float *fea_tiles = nullptr;   // [tile][F][BLK] float32 feature tiles
+    hipStream_t stream = nullptr;   // forest, compaction, copies (high priority)
+    hipStream_t stream2 = nullptr;  // extractor of the NEXT chunk (low priority), see run_pipeline
+    hipEvent_t ev_ext[2] = {nullptr, nullptr};  // extract(k) done, per tile buffer
+    hipEvent_t ev_for[2] = {nullptr, nullptr};  // forest(k) done with its tile buffer
+    float *fea_tiles = nullptr;   // [tile][F][BLK] float32 feature tiles (two chunk buffers)
     size_t fea_tiles_bytes = 0;
     int64_t *scan_scratch = nullptr;  // block counts for the compaction scan
     size_t scan_scratch_bytes = 0;
@@ -56,6 +59,8 @@ struct pk_options {
     int64_t forest_slots = 8;   // LDS kernel: tree slots (wave pairs) per workgroup
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
     int64_t extract_block = 64; // threads per extract block
+    int64_t overlap = 0;        // run extract(k+1) beside forest(k) on a second stream (measured: no gain,
+                                // the forest slows by what the extractor saves -- both are VALU-issue bound)
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
     int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
     int64_t forest_pipe_slots = 0;  // 0 = as many as fit (max 8)
@@ -68,10 +73,11 @@ extern pk_options g_opt;
 // profiling is enabled (pk_prof_enable); otherwise a no-op.
 enum pk_kclass { PK_K_EXTRACT = 0, PK_K_FOREST, PK_K_COMPACT, PK_K_BAND, PK_K_NCLASS };
 struct pk_prof_scope {
-    pk_prof_scope(pk_device_ctx *ctx, pk_kclass k);
+    pk_prof_scope(pk_device_ctx *ctx, pk_kclass k, hipStream_t st = nullptr);
     ~pk_prof_scope();
     pk_device_ctx *ctx;
     pk_kclass k;
+    hipStream_t st;
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
@@ -163,9 +169,9 @@ int pk_launch_band_build(pk_device_ctx *, pk_matrix *, const int32_t *d_indptr,
 
 // features of candidates [c0, c0+cn) -> tiles (tile width BLK) + status.
 // If fea64_rows != nullptr also writes row-major float64 features [cn][F].
-int pk_launch_extract(pk_device_ctx *, const pk_matrix *, int w, const int32_t *d_x,
-                      const int32_t *d_y, int64_t c0, int64_t cn, float *tiles, int blk,
-                      uint8_t *d_status, double *fea64_rows);
+int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
+                      const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
+                      int blk, uint8_t *d_status, double *fea64_rows);
 
 // walk the forest over feature tiles of candidates [c0, c0+cn)
 int pk_launch_forest(pk_device_ctx *, pk_forest *, const float *tiles, int blk,

@@ -526,31 +526,31 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
 
 }  // namespace
 
-int pk_launch_extract(pk_device_ctx *ctx, const pk_matrix *m, int w, const int32_t *d_x,
-                      const int32_t *d_y, int64_t c0, int64_t cn, float *tiles, int blk,
-                      uint8_t *d_status, double *fea64_rows)
+int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, int w,
+                      const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
+                      int blk, uint8_t *d_status, double *fea64_rows)
 {
     if (cn <= 0) return PK_OK;
-    pk_prof_scope prof(ctx, PK_K_EXTRACT);
+    pk_prof_scope prof(ctx, PK_K_EXTRACT, st);
     if ((w == 5 || w == 6) && g_opt.extract_pair) {
         const unsigned grid = (unsigned)((cn + 31) / 32);
         if (w == 5)
-            hipLaunchKernelGGL(extract_pair_kernel<5>, dim3(grid), dim3(64), 0, ctx->stream, m->band,
+            hipLaunchKernelGGL(extract_pair_kernel<5>, dim3(grid), dim3(64), 0, st, m->band,
                                m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0, cn,
                                tiles, blk, d_status, fea64_rows);
         else
-            hipLaunchKernelGGL(extract_pair_kernel<6>, dim3(grid), dim3(64), 0, ctx->stream, m->band,
+            hipLaunchKernelGGL(extract_pair_kernel<6>, dim3(grid), dim3(64), 0, st, m->band,
                                m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0, cn,
                                tiles, blk, d_status, fea64_rows);
     } else if (w == 5 || w == 6) {
         const int threads = 64;
         const unsigned grid = (unsigned)((cn + threads - 1) / threads);
         if (w == 5)
-            hipLaunchKernelGGL(extract_reg_kernel<5>, dim3(grid), dim3(threads), 0, ctx->stream,
+            hipLaunchKernelGGL(extract_reg_kernel<5>, dim3(grid), dim3(threads), 0, st,
                                m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
                                d_y, c0, cn, tiles, blk, d_status, fea64_rows);
         else
-            hipLaunchKernelGGL(extract_reg_kernel<6>, dim3(grid), dim3(threads), 0, ctx->stream,
+            hipLaunchKernelGGL(extract_reg_kernel<6>, dim3(grid), dim3(threads), 0, st,
                                m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
                                d_y, c0, cn, tiles, blk, d_status, fea64_rows);
     } else {
@@ -561,7 +561,7 @@ int pk_launch_extract(pk_device_ctx *ctx, const pk_matrix *m, int w, const int32
         const int F = (2 * w + 1) * (2 * w + 1);
         const size_t lds = (size_t)GEN_WAVES * 2 * F * sizeof(double);
         const unsigned grid = (unsigned)((cn + GEN_WAVES - 1) / GEN_WAVES);
-        hipLaunchKernelGGL(extract_lds_kernel, dim3(grid), dim3(64 * GEN_WAVES), lds, ctx->stream,
+        hipLaunchKernelGGL(extract_lds_kernel, dim3(grid), dim3(64 * GEN_WAVES), lds, st,
                            w, m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
                            d_y, c0, cn, tiles, blk, d_status, fea64_rows);
     }

@@ -207,7 +207,8 @@ __device__ __forceinline__ double walk_tree_global(const uint2 *__restrict__ bas
 // scratch memory here.  The loads are unconditional with a clamped index:
 // nothing may consume a loaded value before the walk, or the compiler waits
 // for the load on the spot.
-#define PK_PF8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define PK_PF6(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#define PK_PF8(X) PK_PF6(X) X(6) X(7)
 #define PK_PF16(X) PK_PF8(X) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define PK_PF_DECL(q) uint4 pf##q;
 #define PK_PF_LOAD(q) pf##q = pf_src[min(pf_tid + (q) * pf_stride, pf_nv - 1)];
@@ -222,8 +223,9 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     double *__restrict__ prob, int tree_words, int dbg, long long *__restrict__ stamps)
 {
     constexpr int THREADS = LDS_C * SLOTS;
-    // 8 x uint4 registers per thread hold the prefetched group: the launcher
-    // keeps tree_words <= THREADS * 8 * 2
+    // 6 x uint4 registers per thread hold the prefetched group (the launcher keeps
+    // tree_words <= THREADS * 6 * 2); six, not eight, keeps the kernel at <= 72
+    // VGPRs so that one extractor wave (216) fits beside four of its waves on a SIMD
     extern __shared__ __attribute__((aligned(16))) float fea[];  // [F][128] | val | trees
     double *val = reinterpret_cast<double *>(fea + (size_t)F * LDS_C);  // [SLOTS][128]
     uint2 *tbuf = reinterpret_cast<uint2 *>(val + SLOTS * LDS_C);       // tree_words + 2 pad
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
 
     // group g = trees [grp[g], grp[g+1]); grp[n_grp+2+g] = staged in LDS or not
     const int32_t *gstaged = grp + n_grp + 2;
-    PK_PF8(PK_PF_DECL)  // the next group, in flight / parked in VGPRs
+    PK_PF6(PK_PF_DECL)  // the next group, in flight / parked in VGPRs
     const int pf_tid = tid, pf_stride = THREADS;
     const uint4 *pf_src;
     uint4 *const pf_dst = reinterpret_cast<uint4 *>(tbuf);
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     if (gstaged[0]) {
         pf_src = reinterpret_cast<const uint4 *>(nodes + root[t]);
         pf_nv = (root[t1] - root[t]) >> 1;
-        PK_PF8(PK_PF_LOAD)
-        PK_PF8(PK_PF_STORE)
+        PK_PF6(PK_PF_LOAD)
+        PK_PF6(PK_PF_STORE)
     }
     __syncthreads();  // feature tile and first group are in LDS
 
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
         if (next_staged) {  // loads fly while this group is walked
             pf_src = reinterpret_cast<const uint4 *>(nodes + root[tn]);
             pf_nv = (root[tn1] - root[tn]) >> 1;
-            PK_PF8(PK_PF_LOAD)
+            PK_PF6(PK_PF_LOAD)
         }
         if (active && slot < gt && !(dbg & 2)) {
             double v;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
         PK_STAMP(1);
         __syncthreads();  // every walk of the group is done: tbuf may be overwritten
         PK_STAMP(2);
-        if (next_staged) { PK_PF8(PK_PF_STORE) }
+        if (next_staged) { PK_PF6(PK_PF_STORE) }
         if (slot == 0 && active) {
             for (int j = 0; j < gt; j++) acc += val[j * LDS_C + cl];  // tree order
         }
@@ -541,7 +543,7 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
         const size_t val_bytes = (size_t)(SLOTS) * LDS_C * sizeof(double);                    \
         size_t room = (size_t)160 * 1024 - fea_bytes - val_bytes - 2 * sizeof(uint2);        \
         if ((size_t)g_opt.forest_lds * 1024 < room) room = (size_t)g_opt.forest_lds * 1024;   \
-        const size_t pf_cap = (size_t)LDS_C * (SLOTS) * 8 * 16; /* THREADS * PF * 16 B */      \
+        const size_t pf_cap = (size_t)LDS_C * (SLOTS) * 6 * 16; /* THREADS * PF * 16 B */      \
         if (room > pf_cap) room = pf_cap;                                                     \
         const int tree_words = (int)(room / sizeof(uint2)) & ~1;                              \
         const size_t lds = fea_bytes + val_bytes + (size_t)(tree_words + 2) * sizeof(uint2);  \
