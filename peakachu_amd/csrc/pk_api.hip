@@ -195,8 +195,6 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_lds")) {
         if (value < 0) return PK_E_INVALID;
         g_opt.forest_lds = value;
-    } else if (!strcmp(name, "extract_block")) {
-        g_opt.extract_block = value;
     } else if (!strcmp(name, "overlap")) {
         g_opt.overlap = value != 0;
     } else if (!strcmp(name, "extract_pair")) {
@@ -230,7 +228,6 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "overlap")) return g_opt.overlap;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
     if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
-    if (!strcmp(name, "extract_block")) return g_opt.extract_block;
     return -1;
 }
 

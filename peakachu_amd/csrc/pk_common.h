@@ -58,7 +58,6 @@ struct pk_options {
     int64_t forest_ilp = 4;     // L2 kernel: trees walked concurrently per lane
     int64_t forest_slots = 8;   // LDS kernel: tree slots (wave pairs) per workgroup
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
-    int64_t extract_block = 64; // threads per extract block
     int64_t overlap = 0;        // run extract(k+1) beside forest(k) on a second stream (measured: no gain,
                                 // the forest slows by what the extractor saves -- both are VALU-issue bound)
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate

@@ -209,7 +209,6 @@ __device__ __forceinline__ double walk_tree_global(const uint2 *__restrict__ bas
 // for the load on the spot.
 #define PK_PF6(X) X(0) X(1) X(2) X(3) X(4) X(5)
 #define PK_PF8(X) PK_PF6(X) X(6) X(7)
-#define PK_PF16(X) PK_PF8(X) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define PK_PF_DECL(q) uint4 pf##q;
 #define PK_PF_LOAD(q) pf##q = pf_src[min(pf_tid + (q) * pf_stride, pf_nv - 1)];
 #define PK_PF_STORE(q) \

@@ -71,12 +71,11 @@ def calculate_expected(M, maxdis, raw=False):
         valid_cols = marg > 0
         keep = finite
     else:
+        # bins that occur as a row or a column of a finite entry (utils.py:150-155)
+        rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(M.indptr))
         valid_cols = np.zeros(n, dtype=bool)
-        valid_cols[indices[finite]] = True  # the matrix is symmetric in practice, but
-        rows_with = np.add.reduceat(finite.astype(np.int64), M.indptr[:-1].clip(max=max(finite.size - 1, 0))) \
-            if finite.size else np.zeros(n, np.int64)
-        rows_with = np.where(np.diff(M.indptr) > 0, rows_with, 0)
-        valid_cols[rows_with > 0] = True    # ... rows are marked too, as the reference does
+        valid_cols[rows[finite]] = True
+        valid_cols[indices[finite]] = True
         keep = nz  # the reference keeps NaN entries in the diagonals here
     maxdis = int(maxdis)
     top = min(maxdis, n - 1)

@@ -294,3 +294,75 @@ def test_rccl_gather_single_rank(hip_lib):
         assert counts[0] == 1000 and np.array_equal(recv, payload)
     finally:
         L.pk_comm_destroy(comm)
+
+
+def big_tree_forest(F, seed, n_small=5, big_nodes=60001):
+    """A forest whose middle tree has ~60 000 nodes (right offsets beyond the
+    13-bit field -> side table; too large for any LDS buffer -> walked from
+    global memory) between ordinary small trees, with non-pure leaf values."""
+    rng = np.random.default_rng(seed)
+
+    def grow(n_nodes):
+        left = [-1]; right = [-1]; feat = [-2]; thr = [-2.0]; p1 = [float(rng.random())]
+        frontier = [0]
+        while frontier and len(left) + 2 <= n_nodes:
+            i = frontier.pop(int(rng.integers(0, len(frontier))))
+            feat[i] = int(rng.integers(0, F)); thr[i] = float(rng.random())
+            for side in (left, right):
+                side[i] = len(left)
+                left.append(-1); right.append(-1); feat.append(-2); thr.append(-2.0)
+                p1.append(float(rng.random()) if rng.random() < 0.7 else float(rng.integers(0, 2)))
+                frontier.append(len(left) - 1)
+        return left, right, feat, thr, p1
+
+    offs, cols = [0], {k: [] for k in ("left", "right", "feat", "thr", "miss_left", "p1")}
+    sizes = [301] * n_small + [big_nodes] + [301] * n_small
+    for n_nodes in sizes:
+        l, r, f, t, p = grow(n_nodes)
+        cols["left"] += l; cols["right"] += r; cols["feat"] += f; cols["thr"] += t; cols["p1"] += p
+        cols["miss_left"] += [int(v) for v in rng.integers(0, 2, len(l))]
+        offs.append(len(cols["left"]))
+    return dict(tree_off=np.array(offs, np.int32), left=np.array(cols["left"], np.int32),
+                right=np.array(cols["right"], np.int32), feat=np.array(cols["feat"], np.int32),
+                thr=np.array(cols["thr"], np.float64),
+                miss_left=np.array(cols["miss_left"], np.uint8),
+                p1=np.array(cols["p1"], np.float64), F=np.int32(F))
+
+
+@pytest.mark.parametrize("lds,pipe", [(160, 0), (160, 2), (0, 0)])
+def test_giant_tree_side_table(hip_lib, lds, pipe):
+    F = 121
+    fo = big_tree_forest(F, seed=9)
+    rng = np.random.default_rng(3)
+    X = rng.random((700, F)).astype(np.float32)
+    X[5, :] = np.nan
+    X[11, rng.integers(0, F, 40)] = np.nan
+    ref = onp.predict(fo, X)
+    old = {k: _lib.load().pk_get_option(k.encode()) for k in ("forest_lds", "forest_pipe")}
+    _lib.set_option("forest_lds", lds)
+    _lib.set_option("forest_pipe", pipe)
+    try:
+        hf = _lib.HipForest(flat(fo))
+        info = hf.info()
+        p = hf.predict(X)
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+    assert info["n_nodes"] > 30000
+    assert np.array_equal(gio.bits(p), gio.bits(ref))
+
+
+def test_forest_create_rejects_malformed(hip_lib):
+    fo = random_forest_arrays(121, 3, seed=1, depth=4)
+    bad = dict(fo); bad["feat"] = fo["feat"].copy()
+    bad["feat"][np.flatnonzero(fo["left"] != -1)[0]] = 500   # feature out of range
+    with pytest.raises(_lib.PeakachuHipError):
+        _lib.HipForest(flat(bad))
+    bad = dict(fo); bad["left"] = fo["left"].copy()
+    bad["left"][0] = 0                                        # a cycle
+    with pytest.raises(_lib.PeakachuHipError):
+        _lib.HipForest(flat(bad))
+    bad = dict(fo); bad["right"] = fo["right"].copy()
+    bad["right"][0] = 10 ** 6                                 # child outside the tree
+    with pytest.raises(_lib.PeakachuHipError):
+        _lib.HipForest(flat(bad))
