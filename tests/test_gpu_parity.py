@@ -366,3 +366,41 @@ def test_forest_create_rejects_malformed(hip_lib):
     bad["right"][0] = 10 ** 6                                 # child outside the tree
     with pytest.raises(_lib.PeakachuHipError):
         _lib.HipForest(flat(bad))
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_score_vs_oracle(hip_lib, seed):
+    """Seeded random configurations: window size (all extractor kernels),
+    matrix size / band, balanced values, batch size, threshold, forest shape
+    (NaN routing included), a few candidates at the matrix edges."""
+    rng = np.random.default_rng(1000 + seed)
+    w = int(rng.choice([4, 5, 5, 6, 6, 7, 8, 11]))
+    n = int(rng.integers(8 * w + 60, 700))
+    band = int(rng.integers(4 * w + 10, min(160, n // 2)))
+    upper = int(rng.integers(2 * w + 4, band))
+    M, _ = synth.synth_band(n, band, seed=seed, loops=max(2, n // 30))
+    if seed % 3 == 1:   # balanced, non-integer values with NaN weights
+        wts = synth.synth_weights(n, seed, n_nan=3)
+        M = synth.balance(M, wts)
+        e = utils.calculate_expected(M, upper + 2 * w, raw=False)
+    else:
+        e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    keep = rng.random(x.size) < 0.5
+    x, y = x[keep], y[keep]
+    # a few candidates whose window leaves the matrix (skipped, scoreUtils.py:75)
+    x = np.r_[x, [0, 1, n - w - 2]].astype(np.int32)
+    y = np.r_[y, [w + 2, w + 3, n - 1]].astype(np.int32)
+    F = (2 * w + 1) ** 2
+    fo = random_forest_arrays(F, int(rng.integers(3, 40)), seed, depth=int(rng.integers(3, 11)))
+    fo["miss_left"] = rng.integers(0, 2, fo["miss_left"].size).astype(np.uint8)
+    thre = float(rng.choice([0.0, 0.3, 0.5, 0.8]))
+    batch = int(rng.choice([1, 2, 97, 4096, 100000]))
+    hm = hip_matrix(Mf, e, w, upper)
+    hf = _lib.HipForest(flat(fo))
+    ox, oy, op, osig = hm.score(hf, w, thre, x, y, batch=batch)
+    rx, ry, rp, rs = onp.score(Mf, e, w, fo, thre, x, y, batch=batch, threads=4)
+    assert np.array_equal(ox, rx) and np.array_equal(oy, ry), (w, n, band, upper, batch, thre)
+    assert np.array_equal(gio.bits(op), gio.bits(rp))
+    assert np.array_equal(gio.bits(osig), gio.bits(rs))
