@@ -208,6 +208,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_pipe_slots")) {
         if (value != 0 && (value < 4 || value > 8)) return PK_E_INVALID;
         g_opt.forest_pipe_slots = value;
+    } else if (!strcmp(name, "forest_l2_tile")) {
+        g_opt.forest_l2_tile = value != 0;
     } else if (!strcmp(name, "forest_dbg")) {
         g_opt.forest_dbg = value;
     } else {
@@ -227,6 +229,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
     if (!strcmp(name, "overlap")) return g_opt.overlap;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
+    if (!strcmp(name, "forest_l2_tile")) return g_opt.forest_l2_tile;
     if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
     return -1;
 }

@@ -63,6 +63,7 @@ struct pk_options {
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
     int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
     int64_t forest_pipe_slots = 0;  // 0 = as many as fit (max 8)
+    int64_t forest_l2_tile = 0; // large F: 1 = keep the LDS feature tile (one wave per CU), 0 = no-LDS kernel
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
 };
 extern pk_options g_opt;

@@ -418,6 +418,12 @@ __global__ __launch_bounds__(64, (W <= 5 ? 2 : 1)) void extract_pair_kernel(
 // ------------------------------------------------------------------------
 constexpr int GEN_WAVES = 4;
 
+// scipy 'reflect' for an offset of at most 4 on a line of n >= 5: one fold
+__device__ __forceinline__ int reflect1(int q, int n)
+{
+    return q < 0 ? -q - 1 : (q >= n ? 2 * n - 1 - q : q);
+}
+
 __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     int W, const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
     const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
@@ -439,16 +445,24 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     }
     const int d = yi - xi;
     const int64_t r0 = (int64_t)(xi - W);
+    // lane -> cell mapping without div/mod: two window rows per sweep step,
+    // lanes 0..31 take row 2*it, lanes 32..63 row 2*it+1, column = lane & 31
+    // (S <= 31).  `steps` sweep steps cover the S rows.
+    const int j = lane & 31, ihalf = lane >> 5;
+    const int steps = (S + 1) >> 1;
+    const bool jok = j < S;
 
     int nnz = 0;
-    for (int f = lane; f < F; f += 64) {
-        const int i = f / S, j = f - i * S;
-        const int k = d + j - i;
-        double v = 0.0;
-        if (k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + i];
-        v = (v != v) ? 0.0 : v;
-        A[f] = v;
-        nnz += (v != 0.0) ? 1 : 0;
+    for (int it = 0; it < steps; it++) {
+        const int i = 2 * it + ihalf;
+        if (jok && i < S) {
+            const int k = d + j - i;
+            double v = 0.0;
+            if (k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + i];
+            v = (v != v) ? 0.0 : v;
+            A[i * S + j] = v;
+            nnz += (v != 0.0) ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o);
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     // sequential top-left sum, every lane computes the same value from LDS
     double acc = 0.0;
     for (int i = 0; i < W; i++)
-        for (int j = 0; j < W; j++) acc += A[i * S + j];
+        for (int q = 0; q < W; q++) acc += A[i * S + q];
     const double ll_mean = acc / (double)(W * W);
     ok = ok && (ll_mean > 0.0);
     const double p2ll = A[W * S + W] / ll_mean;
@@ -469,34 +483,38 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     }
     const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
     if (dmax < exp_len) {
-        for (int f = lane; f < F; f += 64) {
-            const int i = f / S, j = f - i * S;
-            A[f] = A[f] / exp_arr[iabs(d + j - i)];
+        for (int it = 0; it < steps; it++) {
+            const int i = 2 * it + ihalf;
+            if (jok && i < S) A[i * S + j] = A[i * S + j] / exp_arr[iabs(d + j - i)];
         }
     }
     __builtin_amdgcn_wave_barrier();
     // axis 0: A -> B
-    for (int f = lane; f < F; f += 64) {
-        const int i = f / S, j = f - i * S;
-#define AT(q) A[reflect_idx((q), S) * S + j]
-        B[f] = PK_BLUR9(A[f], AT(i - 4), AT(i + 4), AT(i - 3), AT(i + 3), AT(i - 2), AT(i + 2),
-                        AT(i - 1), AT(i + 1));
+    for (int it = 0; it < steps; it++) {
+        const int i = 2 * it + ihalf;
+        if (jok && i < S) {
+#define AT(q) A[reflect1((q), S) * S + j]
+            B[i * S + j] = PK_BLUR9(A[i * S + j], AT(i - 4), AT(i + 4), AT(i - 3), AT(i + 3),
+                                    AT(i - 2), AT(i + 2), AT(i - 1), AT(i + 1));
 #undef AT
+        }
     }
     __builtin_amdgcn_wave_barrier();
     // axis 1: B -> A
     double mn = __builtin_inf(), mx = -__builtin_inf();
     int has_nan = 0;
-    for (int f = lane; f < F; f += 64) {
-        const int i = f / S, j = f - i * S;
-#define BT(q) B[i * S + reflect_idx((q), S)]
-        const double v = PK_BLUR9(B[f], BT(j - 4), BT(j + 4), BT(j - 3), BT(j + 3), BT(j - 2),
-                                  BT(j + 2), BT(j - 1), BT(j + 1));
+    for (int it = 0; it < steps; it++) {
+        const int i = 2 * it + ihalf;
+        if (jok && i < S) {
+#define BT(q) B[i * S + reflect1((q), S)]
+            const double v = PK_BLUR9(B[i * S + j], BT(j - 4), BT(j + 4), BT(j - 3), BT(j + 3),
+                                      BT(j - 2), BT(j + 2), BT(j - 1), BT(j + 1));
 #undef BT
-        A[f] = v;
-        has_nan |= (v != v) ? 1 : 0;
-        mn = (v < mn) ? v : mn;
-        mx = (v > mx) ? v : mx;
+            A[i * S + j] = v;
+            has_nan |= (v != v) ? 1 : 0;
+            mn = (v < mn) ? v : mn;
+            mx = (v > mx) ? v : mx;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -514,11 +532,15 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     const int tl = (int)(local - tile * blk);
     float *tp = tiles + (size_t)tile * F * blk + tl;
     bool fea_nan = false;
-    for (int f = lane; f < F; f += 64) {
-        const double v = (A[f] - mn) / den;
-        fea_nan = fea_nan || (v != v);
-        tp[(size_t)f * blk] = (float)v;
-        if (fea64_rows) fea64_rows[(size_t)local * F + f] = v;
+    for (int it = 0; it < steps; it++) {
+        const int i = 2 * it + ihalf;
+        if (jok && i < S) {
+            const int f = i * S + j;
+            const double v = (A[f] - mn) / den;  // each lane reads back only what it wrote
+            fea_nan = fea_nan || (v != v);
+            tp[(size_t)f * blk] = (float)v;
+            if (fea64_rows) fea64_rows[(size_t)local * F + f] = v;
+        }
     }
     fea_nan = __any(fea_nan);
     if (lane == 0) status[c] = fea_nan ? 2 : 1;

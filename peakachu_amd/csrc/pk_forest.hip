@@ -127,6 +127,72 @@ __global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t 
 }
 
 // ------------------------------------------------------------------------
+// v1b: no LDS at all, for feature counts whose tile leaves no room for trees
+// (w = 11: a [529][64] tile is 135 KB, which would pin the LDS kernels to one
+// wave per CU).  Features are read from the tile in global memory (it stays
+// in L2 / Infinity Cache; lanes agree on the feature near the root, so those
+// reads coalesce), nodes from L2; 256-thread workgroups at full occupancy hide
+// the latency, ILP chains per lane add memory-level parallelism.
+// ------------------------------------------------------------------------
+template <int ILP>
+__global__ __launch_bounds__(256) void forest_gmem_kernel(
+    const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
+    const int32_t *__restrict__ big_roff, int T, int F, const float *__restrict__ tiles, int blk,
+    const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob)
+{
+    const int64_t local = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= cn) return;
+    const int64_t c = c0 + local;
+    if (!status[c]) {
+        prob[c] = 0.0;
+        return;
+    }
+    const int64_t tile = local / blk;
+    const float *fea = tiles + (size_t)tile * F * blk + (local - tile * blk);  // + f * blk
+    double acc = 0.0;
+    for (int t = 0; t < T; t += ILP) {
+        int idx[ILP];
+        unsigned kind[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; k++) {
+            idx[k] = root[min(t + k, T - 1)];
+            kind[k] = PK_KIND_NODE;
+        }
+        bool all_done = false;
+        while (!all_done) {
+            uint2 nd[ILP];
+            float x[ILP];
+#pragma unroll
+            for (int k = 0; k < ILP; k++) nd[k] = nodes[idx[k]];
+#pragma unroll
+            for (int k = 0; k < ILP; k++) {
+                // a finished chain sits on a leaf word (arbitrary bits): it must not
+                // be decoded into a feature index -- this is GLOBAL memory
+                const unsigned f = kind[k] == PK_KIND_NODE ? node_feat(nd[k]) : 0u;
+                x[k] = fea[(size_t)f * blk];
+            }
+            all_done = true;
+#pragma unroll
+            for (int k = 0; k < ILP; k++) {
+                if (kind[k] == PK_KIND_NODE) {
+                    const bool gl = goes_left(x[k], nd[k]);
+                    kind[k] = node_kind(nd[k], gl);
+                    idx[k] += gl ? 1 : node_roff(nd[k], big_roff, idx[k]);
+                }
+                all_done = all_done && (kind[k] != PK_KIND_NODE);
+            }
+        }
+        double v[ILP];
+#pragma unroll
+        for (int k = 0; k < ILP; k++) v[k] = leaf_value(kind[k], nodes[idx[k]]);
+#pragma unroll
+        for (int k = 0; k < ILP; k++)
+            if (t + k < T) acc += v[k];  // tree order: sklearn's sequential sum
+    }
+    prob[c] = acc / (double)T;
+}
+
+// ------------------------------------------------------------------------
 // v2: trees streamed through LDS.
 //
 // A workgroup owns LDS_C = 128 candidates (feature tile [F][128], 62 KB at
@@ -614,6 +680,15 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         case 4: PK_LAUNCH_LDS(4); break;
         case 6: PK_LAUNCH_LDS(6); break;
         default: PK_LAUNCH_LDS(8); break;
+        }
+    } else if (blk < LDS_C && !g_opt.forest_l2_tile) {
+        // large F (w = 11): no LDS, features from the L2-resident tile
+        const unsigned g2 = (unsigned)((cn + 255) / 256);
+        switch (ilp) {
+        case 1: hipLaunchKernelGGL(forest_gmem_kernel<1>, dim3(g2), dim3(256), 0, ctx->stream, f->nodes, f->root, f->big_roff, f->T, f->F, tiles, blk, d_status, c0, cn, d_prob); break;
+        case 2: hipLaunchKernelGGL(forest_gmem_kernel<2>, dim3(g2), dim3(256), 0, ctx->stream, f->nodes, f->root, f->big_roff, f->T, f->F, tiles, blk, d_status, c0, cn, d_prob); break;
+        case 8: hipLaunchKernelGGL(forest_gmem_kernel<8>, dim3(g2), dim3(256), 0, ctx->stream, f->nodes, f->root, f->big_roff, f->T, f->F, tiles, blk, d_status, c0, cn, d_prob); break;
+        default: hipLaunchKernelGGL(forest_gmem_kernel<4>, dim3(g2), dim3(256), 0, ctx->stream, f->nodes, f->root, f->big_roff, f->T, f->F, tiles, blk, d_status, c0, cn, d_prob); break;
         }
     } else {
         const size_t lds = fea_bytes;
