@@ -200,7 +200,7 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "extract_pair")) {
         g_opt.extract_pair = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
-        if (value != 2 && value != 4 && value != 6 && value != 8) return PK_E_INVALID;
+        if (value != 2 && value != 4 && value != 6 && value != 7 && value != 8) return PK_E_INVALID;
         g_opt.forest_slots = value;
     } else if (!strcmp(name, "forest_pipe")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
@@ -741,7 +741,8 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
     PK_HIP(hipStreamSynchronize(ctx->stream));
     if (err) {
         PK_HIP(hipMemset(ctx->dbg_buf + 65535, 0, sizeof(long long)));
-        pk_set_error("forest pipeline timed out waiting on its LDS ring (internal error)");
+        pk_set_error("forest kernel raised its error word (%lld): 1 = LDS ring wait timed out, "
+                     "2 = feature tile not at LDS offset 0 (internal error)", err);
         return PK_E_HIP;
     }
     if (n_out) *n_out = cd->n_out;

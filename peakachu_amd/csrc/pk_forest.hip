@@ -222,6 +222,8 @@ constexpr int LDS_C = 128;
 // Both child words are fetched together with the feature: one LDS round trip
 // per level (20 bytes read).  Fetching only the chosen child afterwards (two
 // dependent round trips, 12 bytes) was measured 8-10 % slower at 16 waves/CU.
+typedef __attribute__((address_space(3))) const float pk_lds_f32;
+
 template <bool WITH_NAN>
 __device__ __forceinline__ double walk_tree_lds(const char *fea_b, int cl4, const char *a)
 {
@@ -231,8 +233,10 @@ __device__ __forceinline__ double walk_tree_lds(const char *fea_b, int cl4, cons
     unsigned kind;
     do {
         const unsigned pk = cur.y;
-        // feature row offset is stored in place: one v_and_or_b32
-        const float x = *reinterpret_cast<const float *>(fea_b + ((pk & PK_NODE_FEAT_MASK) | cl4));
+        // feature row offset is stored in place and the tile starts at LDS offset 0
+        // (checked by the kernel): the address is one v_and_or_b32
+        const float x = *reinterpret_cast<pk_lds_f32 *>(
+            (__UINTPTR_TYPE__)((pk & PK_NODE_FEAT_MASK) | (unsigned)cl4));
         const char *ra = a + ((pk >> PK_NODE_ROFF_SHIFT) << 3);
         // (predicating these reads on the child having a word -- 46 % are pure
         // leaves -- was measured slower: the exec-mask code costs more than the
@@ -308,7 +312,11 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     const bool valid = local < cn;
     const int64_t c = c0 + (valid ? local : 0);
     const unsigned st = valid ? status[c] : 0;
-    const bool active = st != 0;
+    // walk_tree_lds addresses the tile as LDS offset 0 (no static LDS in this kernel)
+    const bool tile_at_zero =
+        (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const void *)fea == 0u;
+    if (!tile_at_zero && tid == 0 && stamps) stamps[65535] = 2;
+    const bool active = st != 0 && tile_at_zero;
     // a wave holding a candidate with NaN features takes the slow walk
     const bool wave_nan = __any(st == 2);
 
@@ -459,7 +467,11 @@ __global__ __launch_bounds__(LDS_C *S) void forest_pipe_kernel(
     const int64_t local = tile * LDS_C + cl;
     const bool valid = local < cn;
     const unsigned st = valid ? status[c0 + local] : 0;
-    const bool active = st != 0;
+    // walk_tree_lds addresses the tile as LDS offset 0 (no static LDS in this kernel)
+    const bool tile_at_zero =
+        (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const void *)fea == 0u;
+    if (!tile_at_zero && tid == 0) errword[0] = 2;
+    const bool active = st != 0 && tile_at_zero;
     const bool wave_nan = __any(st == 2);
     const char *fea_b = reinterpret_cast<const char *>(fea);
     const int cl4 = cl << 2;
@@ -679,6 +691,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         case 2: PK_LAUNCH_LDS(2); break;
         case 4: PK_LAUNCH_LDS(4); break;
         case 6: PK_LAUNCH_LDS(6); break;
+        case 7: PK_LAUNCH_LDS(7); break;
         default: PK_LAUNCH_LDS(8); break;
         }
     } else if (blk < LDS_C && !g_opt.forest_l2_tile) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box helper: bench the forest variants back to back (one JSON line each).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for opts in ${SWEEP:-"overlap=1" "overlap=0" "overlap=1,chunk=262144" "overlap=1,chunk=131072" "overlap=1,chunk=1048576"}; do
+for opts in ${SWEEP:-"forest_slots=8" "forest_slots=8" "forest_pipe=2"}; do
   args=""
   for o in ${opts//,/ }; do args="$args --opt $o"; done
   echo "== $opts"

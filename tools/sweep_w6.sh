@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for o in "extract_pair=1" "extract_pair=0"; do
+for o in "forest_slots=8" "forest_slots=7" "forest_slots=6"; do
   echo "== w=6 $o"
   timeout -k 10 300 python bench.py --no-cpu-baseline --steps 4 --warmup 1 -w 6 --band 300 --upper 300 --opt $o | python -c "
 import sys, json
