@@ -110,6 +110,25 @@ int pk_score(pk_matrix *, pk_forest *, int w, double thre, int64_t batch,
              int64_t N, const int32_t *x, const int32_t *y, int32_t *ox,
              int32_t *oy, double *op, double *osignal, int64_t *n_out);
 
+/* ---- Chromosome.get_candidate (peakachu/scoreUtils.py:40-68) ------------------
+ * Scan the raw-count band for pixels on diagonals lower..upper whose Poisson
+ * survival p-value against the expected count is < 0.01 and build the candidate
+ * list on the device, in the reference's order (diagonal ascending, row
+ * ascending).  The p-value test itself is delegated to tables the host makes
+ * with scipy, so the decision is scipy's:
+ *   raw mode (weights == NULL):  candidate  <=>  count > 0 and floor(count) >= kstar[d]
+ *   balanced mode:               mu = bg[d] / (w[r] * w[r+d]);
+ *                                candidate  <=>  mu < mustar[floor(count)]
+ *     pixels with |mu / mustar - 1| < 1e-9 are not decided here: they are counted
+ *     in *n_ambiguous and the caller must fall back to scipy for this chromosome.
+ * raw: a pk_matrix holding the RAW counts with dlo <= lower, dhi >= upper.
+ * Returns a pk_cands (NULL on error); *n_cand = its length. */
+pk_cands *pk_candidates_create(pk_matrix *raw, int lower, int upper, const int64_t *kstar,
+                               const double *bg, const double *weights, const double *mustar,
+                               int64_t n_mustar, int64_t *n_cand, int64_t *n_ambiguous);
+/* copy the candidate coordinates of a pk_cands back to the host (N entries each) */
+int pk_cands_fetch(pk_cands *, int32_t *x, int32_t *y);
+
 /* ---- tuning / measurement ------------------------------------------------ */
 /* named integer knobs ("chunk", "forest_ilp", "forest_lds", ...); returns
  * PK_E_INVALID for an unknown name */

@@ -47,6 +47,9 @@ SIGNATURES = {
     "pk_score_fetch_all": (C.c_int, [_vp, _u8p, _f64p]),
     "pk_score": (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int64, _i32p, _i32p,
                            _i32p, _i32p, _f64p, _f64p, C.POINTER(C.c_int64)]),
+    "pk_candidates_create": (_vp, [_vp, C.c_int, C.c_int, _vp, _f64p, _vp, _vp, C.c_int64,
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pk_cands_fetch": (C.c_int, [_vp, _i32p, _i32p]),
     "pk_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "pk_get_option": (C.c_int64, [C.c_char_p]),
     "pk_prof_enable": (C.c_int, [C.c_int]),
@@ -210,6 +213,35 @@ class HipMatrix:
 
 class HipCands:
     """Device-resident candidate list and per-candidate outputs (pk_cands)."""
+
+    @classmethod
+    def from_band(cls, raw_matrix, lower, upper, bg, kstar=None, weights=None, mustar=None):
+        """get_candidate on the device (pk_candidates_create).  Returns
+        (HipCands, n_ambiguous); with n_ambiguous > 0 the list is not complete
+        and the caller must use the host path."""
+        L = require_device()
+        bg = np.ascontiguousarray(bg, np.float64)
+        n = C.c_int64(0)
+        amb = C.c_int64(0)
+        ks = np.ascontiguousarray(kstar, np.int64) if kstar is not None else None
+        w = np.ascontiguousarray(weights, np.float64) if weights is not None else None
+        ms = np.ascontiguousarray(mustar, np.float64) if mustar is not None else None
+        h = L.pk_candidates_create(raw_matrix.h, int(lower), int(upper),
+                                   ks.ctypes.data if ks is not None else None, bg,
+                                   w.ctypes.data if w is not None else None,
+                                   ms.ctypes.data if ms is not None else None,
+                                   int(ms.size) if ms is not None else 0, C.byref(n), C.byref(amb))
+        if not h:
+            raise PeakachuHipError("pk_candidates_create: " + last_error())
+        self = cls.__new__(cls)
+        self._L, self.h, self.N, self.n_out = L, h, n.value, 0
+        return self, amb.value
+
+    def coords(self):
+        x = np.empty(max(self.N, 1), np.int32)
+        y = np.empty(max(self.N, 1), np.int32)
+        check(self._L.pk_cands_fetch(self.h, x, y), "pk_cands_fetch")
+        return x[:self.N], y[:self.N]
 
     def __init__(self, x, y, device=0):
         L = require_device()

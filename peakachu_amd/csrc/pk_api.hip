@@ -644,6 +644,103 @@ extern "C" void pk_cands_destroy(pk_cands *c)
     delete c;
 }
 
+static pk_cands *cands_alloc(int device, int64_t N)
+{
+    pk_cands *c = new pk_cands();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->N = N;
+    const size_t n1 = (size_t)(N > 0 ? N : 1);
+    bool ok = hipMalloc((void **)&c->x, n1 * 4) == hipSuccess &&
+              hipMalloc((void **)&c->y, n1 * 4) == hipSuccess &&
+              hipMalloc((void **)&c->prob, n1 * 8) == hipSuccess &&
+              hipMalloc((void **)&c->status, n1) == hipSuccess &&
+              hipMalloc((void **)&c->ox, n1 * 4) == hipSuccess &&
+              hipMalloc((void **)&c->oy, n1 * 4) == hipSuccess &&
+              hipMalloc((void **)&c->op, n1 * 8) == hipSuccess &&
+              hipMalloc((void **)&c->osig, n1 * 8) == hipSuccess &&
+              hipMalloc((void **)&c->n_out_dev, 8) == hipSuccess;
+    if (!ok) {
+        pk_set_error("candidate buffers: device allocation failed (N=%lld)", (long long)N);
+        pk_cands_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" pk_cands *pk_candidates_create(pk_matrix *raw, int lower, int upper,
+                                          const int64_t *kstar, const double *bg,
+                                          const double *weights, const double *mustar,
+                                          int64_t n_mustar, int64_t *n_cand, int64_t *n_ambiguous)
+{
+    if (!raw || !bg || !n_cand || !n_ambiguous || lower < 0 || upper < lower ||
+        (!weights && !kstar) || (weights && (!mustar || n_mustar <= 0))) {
+        pk_set_error("pk_candidates_create: bad arguments");
+        return nullptr;
+    }
+    if (lower < raw->dlo || upper > raw->dhi || upper >= raw->n) {
+        pk_set_error("pk_candidates_create: diagonals %d..%d not inside the band %d..%d / n=%d",
+                     lower, upper, raw->dlo, raw->dhi, raw->n);
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(raw->device);
+    if (!ctx) return nullptr;
+    const size_t nk = (size_t)upper + 1;
+    int64_t *d_kstar = nullptr, *d_tot = nullptr;
+    double *d_bg = nullptr, *d_w = nullptr, *d_ms = nullptr;
+    pk_cands *out = nullptr;
+    int64_t h[2] = {0, 0};
+    bool ok = hipMalloc((void **)&d_bg, nk * 8) == hipSuccess &&
+              hipMalloc((void **)&d_tot, 16) == hipSuccess &&
+              hipMemcpyAsync(d_bg, bg, nk * 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+              hipMemsetAsync(d_tot, 0, 16, ctx->stream) == hipSuccess;
+    if (ok && !weights)
+        ok = hipMalloc((void **)&d_kstar, nk * 8) == hipSuccess &&
+             hipMemcpyAsync(d_kstar, kstar, nk * 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    if (ok && weights)
+        ok = hipMalloc((void **)&d_w, (size_t)raw->n * 8) == hipSuccess &&
+             hipMalloc((void **)&d_ms, (size_t)n_mustar * 8) == hipSuccess &&
+             hipMemcpyAsync(d_w, weights, (size_t)raw->n * 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(d_ms, mustar, (size_t)n_mustar * 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    if (!ok) pk_set_error("pk_candidates_create: table upload failed");
+    if (ok) ok = pk_launch_candidates(ctx, raw, lower, upper, d_kstar, d_bg, d_w, d_ms, n_mustar,
+                                      d_tot, d_tot + 1, nullptr, nullptr) == PK_OK;
+    if (ok)
+        ok = hipMemcpyAsync(h, d_tot, 16, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (ok) {
+        out = cands_alloc(raw->device, h[0]);
+        ok = out != nullptr;
+    }
+    if (ok && h[0] > 0)
+        ok = pk_launch_candidates(ctx, raw, lower, upper, d_kstar, d_bg, d_w, d_ms, n_mustar, d_tot,
+                                  d_tot + 1, out->x, out->y) == PK_OK &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    void *tmp[] = {d_kstar, d_tot, d_bg, d_w, d_ms};
+    for (void *p : tmp)
+        if (p) hipFree(p);
+    if (!ok) {
+        if (out) pk_cands_destroy(out);
+        if (!g_err[0]) pk_set_error("pk_candidates_create failed");
+        return nullptr;
+    }
+    *n_cand = h[0];
+    *n_ambiguous = h[1];
+    return out;
+}
+
+extern "C" int pk_cands_fetch(pk_cands *cd, int32_t *x, int32_t *y)
+{
+    if (!cd) return PK_E_INVALID;
+    pk_device_ctx *ctx = pk_ctx(cd->device);
+    if (!ctx) return PK_E_NODEVICE;
+    if (cd->N == 0) return PK_OK;
+    if (x) PK_HIP(hipMemcpyAsync(x, cd->x, (size_t)cd->N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (y) PK_HIP(hipMemcpyAsync(y, cd->y, (size_t)cd->N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
 // The reference raises on coordinates whose window leaves the matrix in the
 // row direction (scipy fancy indexing) or wraps negative columns; the build
 // requires 0 <= x <= y < n, for which neither can happen.

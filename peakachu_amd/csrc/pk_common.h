@@ -184,3 +184,7 @@ int pk_forest_tile_width(int F);  // candidates per feature tile for F features
 
 int pk_launch_compact(pk_device_ctx *, const pk_matrix *, pk_cands *, double thre,
                       int64_t batch);
+int pk_launch_candidates(pk_device_ctx *, const pk_matrix *raw, int lower, int upper,
+                         const int64_t *d_kstar, const double *d_bg, const double *d_w,
+                         const double *d_mustar, int64_t n_mustar, int64_t *d_total,
+                         int64_t *d_amb, int32_t *ox, int32_t *oy);

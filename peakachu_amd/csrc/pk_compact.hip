@@ -184,7 +184,129 @@ __global__ void compact_scatter_kernel(const uint8_t *__restrict__ status,
     }
 }
 
+// ---- get_candidate: flag every band pixel, then ordered compaction -----------
+// index space: q = (k - lower) * n + r, k = diagonal, r = row; flag 1 = candidate,
+// 2 = inside the guard band of the mustar table (host decides)
+__device__ __forceinline__ int cand_flag(const double *__restrict__ band, int64_t ld, int dlo,
+                                         int n, int lower, int64_t q, const int64_t *kstar,
+                                         const double *bg, const double *w, const double *mustar,
+                                         int64_t n_mustar)
+{
+    const int k = lower + (int)(q / n);
+    const int r = (int)(q - (int64_t)(k - lower) * n);
+    if (r + k >= n) return 0;
+    const double v = band[(int64_t)(k - dlo) * ld + r];
+    if (!(v > 0.0) || !(bg[k] > 0.0)) return 0;  // diag > 0, e > 0 (scoreUtils.py:49,61)
+    const double fv = floor(v);
+    if (!w) return (fv >= (double)kstar[k]) ? 1 : 0;
+    // exp = 1.0 * e / (b1 * b2)   (scoreUtils.py:57)
+    const double mu = (1.0 * bg[k]) / (w[r] * w[r + k]);
+    if (!(mu > 0.0) || mu > 1.7e308) return 0;  // NaN / non-positive mu: p is NaN, dropped at :61
+    if (!(fv < (double)n_mustar)) return 2;
+    const double ms = mustar[(int64_t)fv];
+    if (mu < ms * (1.0 - 1e-9)) return 1;
+    if (mu > ms * (1.0 + 1e-9)) return 0;
+    return 2;
+}
+
+__global__ void cand_count_kernel(const double *__restrict__ band, int64_t ld, int dlo, int n,
+                                  int lower, int64_t Q, const int64_t *__restrict__ kstar,
+                                  const double *__restrict__ bg, const double *__restrict__ w,
+                                  const double *__restrict__ mustar, int64_t n_mustar,
+                                  int64_t *__restrict__ block_cnt, int64_t *__restrict__ n_amb)
+{
+    __shared__ int wsum[CB / 64];
+    const int64_t base = (int64_t)blockIdx.x * CTILE + (int64_t)threadIdx.x * CITEMS;
+    int cnt = 0, amb = 0;
+#pragma unroll
+    for (int i = 0; i < CITEMS; i++) {
+        const int64_t q = base + i;
+        const int f = q < Q ? cand_flag(band, ld, dlo, n, lower, q, kstar, bg, w, mustar, n_mustar) : 0;
+        cnt += f == 1;
+        amb += f == 2;
+    }
+    if (amb) atomicAdd((unsigned long long *)n_amb, (unsigned long long)amb);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int i = 0; i < CB / 64; i++) s += wsum[i];
+        block_cnt[blockIdx.x] = s;
+    }
+}
+
+__global__ void cand_scatter_kernel(const double *__restrict__ band, int64_t ld, int dlo, int n,
+                                    int lower, int64_t Q, const int64_t *__restrict__ kstar,
+                                    const double *__restrict__ bg, const double *__restrict__ w,
+                                    const double *__restrict__ mustar, int64_t n_mustar,
+                                    const int64_t *__restrict__ block_off, int32_t *__restrict__ ox,
+                                    int32_t *__restrict__ oy)
+{
+    __shared__ int wsum[CB / 64];
+    const int64_t base = (int64_t)blockIdx.x * CTILE + (int64_t)threadIdx.x * CITEMS;
+    bool kf[CITEMS];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < CITEMS; i++) {
+        const int64_t q = base + i;
+        kf[i] = q < Q && cand_flag(band, ld, dlo, n, lower, q, kstar, bg, w, mustar, n_mustar) == 1;
+        cnt += kf[i];
+    }
+    int incl = cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int i = 0; i < wave; i++) woff += wsum[i];
+    int64_t pos = block_off[blockIdx.x] + woff + incl - cnt;
+#pragma unroll
+    for (int i = 0; i < CITEMS; i++) {
+        if (!kf[i]) continue;
+        const int64_t q = base + i;
+        const int k = lower + (int)(q / n);
+        const int r = (int)(q - (int64_t)(k - lower) * n);
+        ox[pos] = r;
+        oy[pos] = r + k;
+        pos++;
+    }
+}
+
 }  // namespace
+
+// two-pass ordered compaction of the candidate flags; fills *total and, on the
+// second call (ox != nullptr), the coordinate arrays
+int pk_launch_candidates(pk_device_ctx *ctx, const pk_matrix *raw, int lower, int upper,
+                         const int64_t *d_kstar, const double *d_bg, const double *d_w,
+                         const double *d_mustar, int64_t n_mustar, int64_t *d_total,
+                         int64_t *d_amb, int32_t *ox, int32_t *oy)
+{
+    const int64_t Q = (int64_t)(upper - lower + 1) * raw->n;
+    if (Q <= 0) return PK_OK;
+    pk_prof_scope prof(ctx, PK_K_COMPACT);
+    const int64_t nblocks = (Q + CTILE - 1) / CTILE;
+    int rc = pk_ctx_reserve_scan(ctx, sizeof(int64_t) * (size_t)nblocks);
+    if (rc) return rc;
+    if (!ox) {
+        hipLaunchKernelGGL(cand_count_kernel, dim3((unsigned)nblocks), dim3(CB), 0, ctx->stream,
+                           raw->band, raw->ld, raw->dlo, raw->n, lower, Q, d_kstar, d_bg, d_w,
+                           d_mustar, n_mustar, ctx->scan_scratch, d_amb);
+        hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                           ctx->scan_scratch, nblocks, d_total);
+    } else {
+        hipLaunchKernelGGL(cand_scatter_kernel, dim3((unsigned)nblocks), dim3(CB), 0, ctx->stream,
+                           raw->band, raw->ld, raw->dlo, raw->n, lower, Q, d_kstar, d_bg, d_w,
+                           d_mustar, n_mustar, ctx->scan_scratch, ox, oy);
+    }
+    PK_HIP(hipGetLastError());
+    return PK_OK;
+}
 
 int pk_launch_band_build(pk_device_ctx *ctx, pk_matrix *m, const int32_t *d_indptr,
                          const int32_t *d_indices, const double *d_data, int64_t nnz)

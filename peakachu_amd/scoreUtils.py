@@ -31,9 +31,9 @@ class Chromosome():
 
         self.raw_M = raw_M
         self.weights = weights
+        self._raw_is_M = M is raw_M
         # peakachu/scoreUtils.py:30-33
         self.M = utils.band_filter(M, width, upper)
-        self.get_candidate(lower, upper)
         self.chromname = cname
         self.r = res
         self.w = width
@@ -42,12 +42,61 @@ class Chromosome():
         self.device = device
         self._hm = None
         self._hf = None
+        self._cands = None
+        self.get_candidate(lower, upper)
 
     # ----------------------------------------------------------- host side
     def get_candidate(self, lower, upper):
-        """peakachu/scoreUtils.py:40-68."""
-        self.ridx, self.cidx = utils.candidates(self.raw_M, self.background, self.weights,
-                                                lower, upper)
+        """peakachu/scoreUtils.py:40-68.  On the device when the raw counts are
+        integers (pk_candidates_create: the Poisson test runs against tables made
+        with scipy); otherwise, or when a pixel falls inside the table's guard
+        band, on the host with scipy directly."""
+        self._cands = None
+        try:
+            got = self._candidates_on_device(lower, upper)
+        except _lib.PeakachuHipError:
+            got = None
+        if got is None:
+            self.ridx, self.cidx = utils.candidates(self.raw_M, self.background, self.weights,
+                                                    lower, upper)
+        else:
+            self._cands = got
+            x, y = got.coords()
+            self.ridx, self.cidx = x.astype(np.int64), y.astype(np.int64)
+        self._cands_key = (self.ridx, self.cidx)
+
+    def _candidates_on_device(self, lower, upper):
+        raw = utils.canonical_csr(self.raw_M)
+        n = raw.shape[0]
+        hi = min(int(upper), self.background.size - 1, n - 1)
+        if hi < lower or raw.nnz == 0:
+            return None
+        if not np.all(raw.data[np.isfinite(raw.data)] == np.floor(raw.data[np.isfinite(raw.data)])):
+            return None  # the tables assume integer counts
+        if self.weights is None and self._raw_is_M:
+            rawm = self._matrix()  # the scoring band already holds these counts
+            own = False
+        else:
+            rawm = _lib.HipMatrix(raw.indptr, raw.indices, raw.data, n, self.background,
+                                  lower, hi, device=self.device)
+            own = True
+        try:
+            bg = np.ascontiguousarray(self.background[:hi + 1], np.float64)
+            if self.weights is None:
+                kstar = utils._poisson_count_thresholds(bg)
+                cands, amb = _lib.HipCands.from_band(rawm, lower, hi, bg, kstar=kstar)
+            else:
+                kmax = int(np.nanmax(raw.data)) if raw.nnz else 0
+                cands, amb = _lib.HipCands.from_band(rawm, lower, hi, bg,
+                                                     weights=np.asarray(self.weights, np.float64),
+                                                     mustar=utils.poisson_mu_thresholds(kmax))
+        finally:
+            if own:
+                rawm.close()
+        if amb:
+            cands.close()
+            return None
+        return cands
 
     # --------------------------------------------------------- device side
     def _matrix(self):
@@ -81,8 +130,12 @@ class Chromosome():
         """peakachu/scoreUtils.py:95-125."""
         print('scoring matrix {}'.format(self.chromname))
         print('number of candidates {}'.format(self.ridx.size))
-        ri, ci, prob_pool, signal = self._matrix().score(self._forest(), self.w, thre,
-                                                         self.ridx, self.cidx, batch=100000)
+        # the device-resident candidate list is reused unless ridx / cidx were replaced
+        same = (self._cands is not None and self._cands_key[0] is self.ridx
+                and self._cands_key[1] is self.cidx)
+        cd = self._cands if same else _lib.HipCands(self.ridx, self.cidx, device=self.device)
+        cd.run(self._matrix(), self._forest(), self.w, thre, batch=100000)
+        ri, ci, prob_pool, signal = cd.fetch()
         ri = ri.astype(int)
         ci = ci.astype(int)
         result = sparse.csr_matrix((prob_pool, (ri, ci)), shape=self.M.shape)

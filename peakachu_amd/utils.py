@@ -115,6 +115,34 @@ def _poisson_count_thresholds(mu):
     return out
 
 
+_MUSTAR = np.zeros(0)
+
+
+def poisson_mu_thresholds(kmax):
+    """mustar[k] (k = 0..kmax): the smallest float64 mu for which scipy's
+    poisson.sf(k, mu) is NOT < 0.01, found by bisection on scipy's own sf (it is
+    increasing in mu), so that  sf(k, mu) < 0.01  <=>  mu < mustar[k]  up to the
+    last-bit wiggle the GPU kernel's 1e-9 guard band leaves to scipy.  Cached."""
+    global _MUSTAR
+    kmax = int(kmax)
+    if _MUSTAR.size > kmax:
+        return _MUSTAR[:kmax + 1]
+    k = np.arange(kmax + 1, dtype=np.float64)
+    lo = np.zeros(kmax + 1)
+    hi = k + 12.0 * np.sqrt(k + 1.0) + 20.0
+    with np.errstate(all="ignore"):
+        assert np.all(stats.poisson.sf(k, hi) >= 0.01)
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            below = stats.poisson.sf(k, mid) < 0.01
+            lo = np.where(below, mid, lo)
+            hi = np.where(below, hi, mid)
+            if np.all((hi - lo) <= np.spacing(lo)):
+                break
+    _MUSTAR = hi
+    return _MUSTAR
+
+
 def candidates(raw_M, background, weights, lower, upper):
     """peakachu/scoreUtils.py:40-68: Poisson survival p-value of every
     non-zero raw pixel on diagonals lower..upper against the expected count

@@ -404,3 +404,47 @@ def test_randomised_score_vs_oracle(hip_lib, seed):
     assert np.array_equal(ox, rx) and np.array_equal(oy, ry), (w, n, band, upper, batch, thre)
     assert np.array_equal(gio.bits(op), gio.bits(rp))
     assert np.array_equal(gio.bits(osig), gio.bits(rs))
+
+
+@pytest.mark.parametrize("mode", ["raw", "weights", "separate_raw"])
+def test_candidates_on_device_match_scipy(hip_lib, mode):
+    """get_candidate on the device (tables made with scipy) against the host
+    path that calls scipy.stats.poisson.sf per pixel, on a 6 000-bin map."""
+    from peakachu_amd import scoreUtils
+    n, band, w, upper = 6000, 200, 5, 200
+    raw, _ = synth.synth_band(n, band, seed=11)
+    model = flat(gio.forest("g2_forest_plain.npz"))
+    if mode == "raw":
+        ch = scoreUtils.Chromosome(raw, model, raw_M=raw, weights=None, upper=upper, width=w)
+        ref = utils.candidates(raw, ch.background, None, ch.lower, ch.upper)
+    elif mode == "weights":
+        wts = synth.synth_weights(n, 11, n_nan=7)
+        ch = scoreUtils.Chromosome(synth.balance(raw, wts), model, raw_M=raw, weights=wts,
+                                   upper=upper, width=w)
+        ref = utils.candidates(raw, ch.background, wts, ch.lower, ch.upper)
+    else:
+        ch = scoreUtils.Chromosome(raw * 0.37, model, raw_M=raw, weights=None, upper=upper, width=w)
+        ref = utils.candidates(raw, ch.background, None, ch.lower, ch.upper)
+    assert ch._cands is not None, "device path was not taken"
+    assert ref[0].size > 1000
+    assert np.array_equal(ch.ridx, ref[0]) and np.array_equal(ch.cidx, ref[1])
+    # scoring from the device-resident list equals scoring from host coordinates
+    res1, _ = ch.score(0.5)
+    ch2 = scoreUtils.Chromosome(ch.raw_M if mode != "separate_raw" else raw * 0.37, model,
+                                raw_M=raw, weights=ch.weights, upper=upper, width=w) \
+        if mode != "weights" else None
+    if ch2 is not None:
+        ch2.ridx, ch2.cidx = ref[0].copy(), ref[1].copy()   # forces the host-coordinate path
+        res2, _ = ch2.score(0.5)
+        assert (res1 != res2).nnz == 0
+
+
+def test_candidates_fall_back_for_non_integer_counts(hip_lib):
+    from peakachu_amd import scoreUtils
+    raw, _ = synth.synth_band(800, 90, seed=5)
+    raw = raw * 1.5
+    model = flat(gio.forest("g2_forest_plain.npz"))
+    ch = scoreUtils.Chromosome(raw, model, raw_M=raw, weights=None, upper=70, width=5)
+    assert ch._cands is None
+    ref = utils.candidates(raw, ch.background, None, ch.lower, ch.upper)
+    assert np.array_equal(ch.ridx, ref[0]) and np.array_equal(ch.cidx, ref[1])
