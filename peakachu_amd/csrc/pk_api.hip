@@ -25,6 +25,11 @@ void pk_set_error(const char *fmt, ...)
 
 pk_options g_opt;
 static std::mutex g_mu;
+// One coarse lock for every entry point that touches a device: the library keeps
+// per-device scratch, cached launch tables inside handles and profiling lists, so
+// calls are serialised (include/peakachu_hip.h, 'Threading').
+std::recursive_mutex g_api_mu;
+#define PK_API_LOCK std::lock_guard<std::recursive_mutex> api_lock__(g_api_mu)
 static std::map<int, pk_device_ctx *> g_ctx;
 
 // --------------------------------------------------------------- profiling
@@ -175,6 +180,7 @@ extern "C" int pk_device_name(int device, char *buf, int buflen)
 
 extern "C" int pk_device_synchronize(int device)
 {
+    PK_API_LOCK;
     pk_device_ctx *c = pk_ctx(device);
     if (!c) return PK_E_NODEVICE;
     PK_HIP(hipStreamSynchronize(c->stream2));
@@ -185,6 +191,7 @@ extern "C" int pk_device_synchronize(int device)
 
 extern "C" int pk_set_option(const char *name, int64_t value)
 {
+    PK_API_LOCK;
     if (!name) return PK_E_INVALID;
     if (!strcmp(name, "chunk")) {
         if (value < 64) return PK_E_INVALID;
@@ -236,6 +243,7 @@ extern "C" int64_t pk_get_option(const char *name)
 
 extern "C" int pk_debug_read(int device, int64_t *out, int64_t n)
 {
+    PK_API_LOCK;
     pk_device_ctx *c = pk_ctx(device);
     if (!c) return PK_E_NODEVICE;
     if (!out || n < 0 || n > 65536) return PK_E_INVALID;
@@ -246,11 +254,13 @@ extern "C" int pk_debug_read(int device, int64_t *out, int64_t n)
 
 extern "C" int pk_prof_enable(int on)
 {
+    PK_API_LOCK;
     g_prof_on = on != 0;
     return PK_OK;
 }
 extern "C" int pk_prof_reset(void)
 {
+    PK_API_LOCK;
     prof_drain();
     for (int i = 0; i < PK_K_NCLASS; i++) {
         g_prof_ms[i] = 0;
@@ -260,6 +270,7 @@ extern "C" int pk_prof_reset(void)
 }
 extern "C" int pk_prof_get(const char *name, double *ms_total, int64_t *launches)
 {
+    PK_API_LOCK;
     static const char *names[PK_K_NCLASS] = {"extract", "forest", "compact", "band"};
     prof_drain();
     for (int i = 0; i < PK_K_NCLASS; i++)
@@ -286,6 +297,7 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
                                        const int32_t *feat, const double *thr,
                                        const uint8_t *miss_left, const double *p1)
 {
+    PK_API_LOCK;
     if (T <= 0 || F <= 0 || !tree_off || !left || !right || !feat || !thr || !p1) {
         pk_set_error("pk_forest_create: bad arguments");
         return nullptr;
@@ -509,6 +521,7 @@ int pk_forest_stage_flags(pk_forest *f, int region_words)
 
 extern "C" void pk_forest_destroy(pk_forest *f)
 {
+    PK_API_LOCK;
     if (!f) return;
     hipSetDevice(f->device);
     if (f->nodes) hipFree(f->nodes);
@@ -535,6 +548,7 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
                                        const double *exp_arr, int32_t exp_len, int32_t dlo,
                                        int32_t dhi)
 {
+    PK_API_LOCK;
     if (n <= 0 || !indptr || !exp_arr || exp_len <= 0 || dhi < dlo) {
         pk_set_error("pk_matrix_create: bad arguments");
         return nullptr;
@@ -591,6 +605,7 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
 
 extern "C" void pk_matrix_destroy(pk_matrix *m)
 {
+    PK_API_LOCK;
     if (!m) return;
     hipSetDevice(m->device);
     if (m->band) hipFree(m->band);
@@ -601,6 +616,7 @@ extern "C" void pk_matrix_destroy(pk_matrix *m)
 // --------------------------------------------------------------- candidates
 extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y)
 {
+    PK_API_LOCK;
     if (N < 0 || (N > 0 && (!x || !y))) {
         pk_set_error("pk_cands_create: bad arguments");
         return nullptr;
@@ -635,6 +651,7 @@ extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, co
 
 extern "C" void pk_cands_destroy(pk_cands *c)
 {
+    PK_API_LOCK;
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->x, c->y, c->prob, c->status, c->ox, c->oy, c->op, c->osig, c->n_out_dev,
@@ -673,6 +690,7 @@ extern "C" pk_cands *pk_candidates_create(pk_matrix *raw, int lower, int upper,
                                           const double *weights, const double *mustar,
                                           int64_t n_mustar, int64_t *n_cand, int64_t *n_ambiguous)
 {
+    PK_API_LOCK;
     if (!raw || !bg || !n_cand || !n_ambiguous || lower < 0 || upper < lower ||
         (!weights && !kstar) || (weights && (!mustar || n_mustar <= 0))) {
         pk_set_error("pk_candidates_create: bad arguments");
@@ -731,6 +749,7 @@ extern "C" pk_cands *pk_candidates_create(pk_matrix *raw, int lower, int upper,
 
 extern "C" int pk_cands_fetch(pk_cands *cd, int32_t *x, int32_t *y)
 {
+    PK_API_LOCK;
     if (!cd) return PK_E_INVALID;
     pk_device_ctx *ctx = pk_ctx(cd->device);
     if (!ctx) return PK_E_NODEVICE;
@@ -803,6 +822,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
 extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, double thre,
                             int64_t batch, int64_t *n_out)
 {
+    PK_API_LOCK;
     if (!m || !f || !cd || w < 1) {
         pk_set_error("pk_score_run: bad arguments");
         return PK_E_INVALID;
@@ -848,6 +868,7 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
 
 extern "C" int pk_score_fetch(pk_cands *cd, int32_t *ox, int32_t *oy, double *op, double *osignal)
 {
+    PK_API_LOCK;
     if (!cd) return PK_E_INVALID;
     pk_device_ctx *ctx = pk_ctx(cd->device);
     if (!ctx) return PK_E_NODEVICE;
@@ -863,6 +884,7 @@ extern "C" int pk_score_fetch(pk_cands *cd, int32_t *ox, int32_t *oy, double *op
 
 extern "C" int pk_score_fetch_all(pk_cands *cd, uint8_t *status, double *prob)
 {
+    PK_API_LOCK;
     if (!cd) return PK_E_INVALID;
     pk_device_ctx *ctx = pk_ctx(cd->device);
     if (!ctx) return PK_E_NODEVICE;
@@ -879,6 +901,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
                         const int32_t *x, const int32_t *y, int32_t *ox, int32_t *oy, double *op,
                         double *osignal, int64_t *n_out)
 {
+    PK_API_LOCK;
     if (!m || !f || !n_out) {
         pk_set_error("pk_score: bad arguments");
         return PK_E_INVALID;
@@ -897,6 +920,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
 extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, const int32_t *y,
                           double *fea64, float *fea32, int64_t *keep, int64_t *n_keep)
 {
+    PK_API_LOCK;
     if (!m || !keep || !n_keep || N < 0 || w < 1 || w > 15) {
         pk_set_error("pk_extract: bad arguments");
         return PK_E_INVALID;
@@ -956,6 +980,7 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
 // --------------------------------------------------------- predict_proba API
 extern "C" int pk_predict(pk_forest *f, int64_t N, const float *fea32, double *p1)
 {
+    PK_API_LOCK;
     if (!f || N < 0 || (N > 0 && (!fea32 || !p1))) {
         pk_set_error("pk_predict: bad arguments");
         return PK_E_INVALID;

@@ -49,7 +49,8 @@ def main(args):
     Lib = io.open_map(args.path)
     queue = select_chromosomes(Lib.chromnames[:], args.chroms)
 
-    if world == 1:
+    # PK_FORCE_DIST=1 sends a single rank down the multi-rank branch (tests)
+    if world == 1 and os.environ.get("PK_FORCE_DIST") != "1":
         for key in queue:
             cname = key if key.startswith('chr') else 'chr' + key
             X = build_chromosome(Lib, key, cname, model, correct, args, width, local_rank)

@@ -448,3 +448,25 @@ def test_candidates_fall_back_for_non_integer_counts(hip_lib):
     assert ch._cands is None
     ref = utils.candidates(raw, ch.background, None, ch.lower, ch.upper)
     assert np.array_equal(ch.ridx, ref[0]) and np.array_equal(ch.cidx, ref[1])
+
+
+def test_score_genome_distributed_branch_single_rank(hip_lib, tmp_path):
+    """The multi-rank branch of score_genome (chromosome dealing, RCCL transport,
+    packed-record gather, ordered merge on rank 0) with a 1-rank group launched
+    like the driver launches ranks; output must equal the reference's bedpe."""
+    import os, socket, subprocess, sys
+    z = gio.load("g6_driver.npz")
+    model = tmp_path / "forest.npz"
+    flat(gio.forest(str(z["forest"]))).save(str(model))
+    out = tmp_path / "dist.bedpe"
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "scripts", "peakachu-amd"), "score_genome", "-p",
+           os.path.join(gio.GOLD, str(z["container"])), "-m", str(model), "-O", str(out),
+           "--clr-weight-name", "weight", "-u", str(int(z["upper"]))]
+    env = dict(os.environ, PK_FORCE_DIST="1")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert out.read_text() == str(z["genome_weight"])
