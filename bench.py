@@ -246,6 +246,23 @@ def main():
     L.pk_prof_enable(0)
     kern = {k: _lib.prof_get(k) for k in ("extract", "forest", "compact")}
 
+    # extra, not the headline: the same pass with exact early termination (option
+    # early_exit: candidates that provably end at p <= thre stop walking; same pixels)
+    early = None
+    if world == 1:
+        _lib.set_option("early_exit", 1)
+        step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            n_early = step()
+        sync()
+        e_el = time.perf_counter() - t0
+        _lib.set_option("early_exit", 0)
+        early = {"value": int(x.size) * a.steps / e_el, "ms_per_step": e_el / a.steps * 1e3,
+                 "scored_pixels": int(n_early), "same_pixels_as_full_evaluation": bool(n_early == n_out),
+                 "note": "opt-in exact pruning at threshold %g; NOT the headline value" % a.thre}
+
     n_local = int(x.size)
     if dist:
         import torch
@@ -325,6 +342,8 @@ def main():
             "whole_path_alg_GBs": value * b_alg(F) / 1e9,
             "upload_s": upload_s,
         }
+        if early is not None:
+            out["early_exit"] = early
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Mf, exp_arr, w, fo, a.thre, x, y, a.batch)
         print(json.dumps(out))

@@ -215,6 +215,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_pipe_slots")) {
         if (value != 0 && (value < 4 || value > 8)) return PK_E_INVALID;
         g_opt.forest_pipe_slots = value;
+    } else if (!strcmp(name, "early_exit")) {
+        g_opt.early_exit = value != 0;
     } else if (!strcmp(name, "forest_l2_tile")) {
         g_opt.forest_l2_tile = value != 0;
     } else if (!strcmp(name, "forest_dbg")) {
@@ -237,6 +239,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "overlap")) return g_opt.overlap;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
     if (!strcmp(name, "forest_l2_tile")) return g_opt.forest_l2_tile;
+    if (!strcmp(name, "early_exit")) return g_opt.early_exit;
     if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
     return -1;
 }
@@ -774,7 +777,8 @@ static int check_coords(const char *who, int32_t n, int64_t N, const int32_t *x,
     return PK_OK;
 }
 
-static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands *cd, int w)
+static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands *cd, int w,
+                        double prune_sum)
 {
     const int F = (2 * w + 1) * (2 * w + 1);
     const int blk = pk_forest_tile_width(F);
@@ -812,7 +816,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
             PK_HIP(hipEventRecord(ctx->ev_ext[buf], st_ext));
             PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[buf], 0));
         }
-        rc = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob);
+        rc = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob, prune_sum);
         if (rc) return rc;
         if (overlap) PK_HIP(hipEventRecord(ctx->ev_for[buf], ctx->stream));
     }
@@ -846,7 +850,9 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
         PK_HIP(hipMalloc((void **)&cd->batch_cnt, sizeof(int32_t) * (size_t)nb));
         cd->n_batches_cap = nb;
     }
-    int rc = run_pipeline(ctx, m, f, cd, w);
+    // optional exact early termination (option early_exit): only meaningful for thre >= 0
+    const double prune_sum = (g_opt.early_exit && thre >= 0.0) ? thre * (double)f->T : -INFINITY;
+    int rc = run_pipeline(ctx, m, f, cd, w, prune_sum);
     if (rc) return rc;
     rc = pk_launch_compact(ctx, m, cd, thre, batch);
     if (rc) return rc;
@@ -1017,7 +1023,7 @@ extern "C" int pk_predict(pk_forest *f, int64_t N, const float *fea32, double *p
         }
         rc = pk_launch_tile_rows(ctx, d_rows, cn, F, ctx->fea_tiles, blk, d_status);
         if (rc) break;
-        rc = pk_launch_forest(ctx, f, ctx->fea_tiles, blk, d_status, 0, cn, d_prob);
+        rc = pk_launch_forest(ctx, f, ctx->fea_tiles, blk, d_status, 0, cn, d_prob, -INFINITY);
         if (rc) break;
         if (hipMemcpyAsync(p1 + c0, d_prob, (size_t)cn * 8, hipMemcpyDeviceToHost, ctx->stream) !=
                 hipSuccess ||

@@ -64,6 +64,8 @@ struct pk_options {
     int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
     int64_t forest_pipe_slots = 0;  // 0 = as many as fit (max 8)
     int64_t forest_l2_tile = 0; // large F: 1 = keep the LDS feature tile (one wave per CU), 0 = no-LDS kernel
+    int64_t early_exit = 0;     // pk_score_run: stop walking candidates that provably end at p <= thre
+                                // (identical output pixels; per-candidate probabilities of pruned pixels read 0)
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
 };
 extern pk_options g_opt;
@@ -174,8 +176,11 @@ int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
                       int blk, uint8_t *d_status, double *fea64_rows);
 
 // walk the forest over feature tiles of candidates [c0, c0+cn)
+// prune_sum: -inf (full evaluation) or thre*T: candidates whose sum provably cannot reach it
+// are dropped early (grouped LDS kernel only; their reported probability is 0)
 int pk_launch_forest(pk_device_ctx *, pk_forest *, const float *tiles, int blk,
-                     const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob);
+                     const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob,
+                     double prune_sum);
 // row-major float32 features [N][F] -> tiles (for pk_predict); status[i] = 1,
 // or 2 if row i holds a NaN
 int pk_launch_tile_rows(pk_device_ctx *, const float *d_rows, int64_t N, int F, float *tiles,

@@ -284,12 +284,13 @@ __device__ __forceinline__ double walk_tree_global(const uint2 *__restrict__ bas
 #define PK_PF_STORE(q) \
     if (pf_tid + (q) * pf_stride < pf_nv) pf_dst[pf_tid + (q) * pf_stride] = pf##q;
 
-template <int SLOTS>
+template <int SLOTS, bool PRUNE>
 __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
     const int32_t *__restrict__ big_roff, const int32_t *__restrict__ grp, int n_grp, int T, int F,
     const float *__restrict__ tiles, const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
-    double *__restrict__ prob, int tree_words, int dbg, long long *__restrict__ stamps)
+    double *__restrict__ prob, int tree_words, int dbg, long long *__restrict__ stamps,
+    double prune_sum)
 {
     constexpr int THREADS = LDS_C * SLOTS;
     // 6 x uint4 registers per thread hold the prefetched group (the launcher keeps
@@ -297,10 +298,19 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     // VGPRs so that one extractor wave (216) fits beside four of its waves on a SIMD
     extern __shared__ __attribute__((aligned(16))) float fea[];  // [F][128] | val | trees
     double *val = reinterpret_cast<double *>(fea + (size_t)F * LDS_C);  // [SLOTS][128]
-    uint2 *tbuf = reinterpret_cast<uint2 *>(val + SLOTS * LDS_C);       // tree_words + 2 pad
+    // (the leaf-value area has SLOTS+1 rows: the last one holds the "decided" flags
+    // of the optional early termination, one int per candidate)
+    int *decided = reinterpret_cast<int *>(val + SLOTS * LDS_C);
+    uint2 *tbuf = reinterpret_cast<uint2 *>(val + (SLOTS + (PRUNE ? 1 : 0)) * LDS_C);  // tree_words + 2 pad
     const int tid = threadIdx.x;
     const int cl = tid & (LDS_C - 1);
     const int slot = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform -> SGPR
+    constexpr bool prune = PRUNE;  // early termination compiled in (separate instantiation)
+    // decided[0..127]: per-candidate flags; decided[128..130]: three rotating vote words
+    // (a vote word is set before barrier g, read after it, and cleared two groups ahead,
+    // so a clear and a set of the same word are always separated by a barrier).
+    // No __syncthreads_and here: it would add static LDS in front of the feature tile.
+    if (PRUNE && tid < LDS_C + 3) decided[tid] = 0;
     const int64_t tile = blockIdx.x;
     {
         const float4 *src = reinterpret_cast<const float4 *>(tiles + (size_t)tile * F * LDS_C);
@@ -358,7 +368,10 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
             pf_nv = (root[tn1] - root[tn]) >> 1;
             PK_PF6(PK_PF_LOAD)
         }
-        if (active && slot < gt && !(dbg & 2)) {
+        // early termination: a candidate whose sum can no longer reach thre*T is not
+        // walked any more (its flag was set by slot 0 before the last barrier)
+        const bool undecided = !prune || decided[cl] == 0;
+        if (active && undecided && slot < gt && !(dbg & 2)) {
             double v;
             if (staged) {
                 const char *a = reinterpret_cast<const char *>(tbuf + (root[t + slot] - g0));
@@ -372,14 +385,32 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
         __syncthreads();  // every walk of the group is done: tbuf may be overwritten
         PK_STAMP(2);
         if (next_staged) { PK_PF6(PK_PF_STORE) }
-        if (slot == 0 && active) {
+        if (slot == 0 && active && undecided) {
             for (int j = 0; j < gt; j++) acc += val[j * LDS_C + cl];  // tree order
+            if (prune) {
+                // every remaining tree adds at most 1.0: if even that cannot lift the
+                // sum to thre*T (1e-12 covers the rounding of at most T additions), the
+                // final p is <= thre and the pixel is not reported -- stop walking it
+                const bool out = (acc + (double)(T - tn)) * (1.0 + 1e-12) < prune_sum;
+                if (out) {
+                    decided[cl] = 1;
+                    acc = 0.0;  // reported probability of a pruned candidate: 0
+                } else {
+                    decided[LDS_C + (g % 3)] = 1;  // this workgroup still has an open candidate
+                }
+            }
         }
         PK_STAMP(3);
-        __syncthreads();  // next group staged; val consumed
+        __syncthreads();  // next group staged; val consumed; votes cast
+        bool all_done = false;
+        if (prune) {
+            all_done = decided[LDS_C + (g % 3)] == 0;
+            if (tid == 0) decided[LDS_C + ((g + 2) % 3)] = 0;
+        }
         PK_STAMP(4);
         t = tn;
         t1 = tn1;
+        if (all_done) break;
     }
     if (slot == 0 && valid) prob[c] = active ? acc / (double)T : 0.0;
 #undef PK_STAMP
@@ -615,23 +646,28 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
                            cn, d_prob);                                                       \
     } while (0)
 
-#define PK_LAUNCH_LDS(SLOTS)                                                                  \
+#define PK_LAUNCH_LDS_P(SLOTS, PRUNE)                                                         \
     do {                                                                                      \
-        const size_t val_bytes = (size_t)(SLOTS) * LDS_C * sizeof(double);                    \
+        const size_t val_bytes = (size_t)((SLOTS) + ((PRUNE) ? 1 : 0)) * LDS_C * sizeof(double); \
         size_t room = (size_t)160 * 1024 - fea_bytes - val_bytes - 2 * sizeof(uint2);        \
         if ((size_t)g_opt.forest_lds * 1024 < room) room = (size_t)g_opt.forest_lds * 1024;   \
         const size_t pf_cap = (size_t)LDS_C * (SLOTS) * 6 * 16; /* THREADS * PF * 16 B */      \
         if (room > pf_cap) room = pf_cap;                                                     \
         const int tree_words = (int)(room / sizeof(uint2)) & ~1;                              \
         const size_t lds = fea_bytes + val_bytes + (size_t)(tree_words + 2) * sizeof(uint2);  \
-        int rc__ = set_max_lds(forest_lds_kernel<SLOTS>, lds);                                \
+        int rc__ = set_max_lds(forest_lds_kernel<SLOTS, PRUNE>, lds);                         \
         if (rc__) return rc__;                                                                \
         rc__ = pk_forest_groups(f, tree_words, SLOTS);                                        \
         if (rc__) return rc__;                                                                \
-        hipLaunchKernelGGL(forest_lds_kernel<SLOTS>, dim3(grid), dim3(LDS_C *(SLOTS)), lds,   \
-                           ctx->stream, f->nodes, f->root, f->big_roff, f->grp, f->n_grp,     \
+        hipLaunchKernelGGL((forest_lds_kernel<SLOTS, PRUNE>), dim3(grid), dim3(LDS_C *(SLOTS)), \
+                           lds, ctx->stream, f->nodes, f->root, f->big_roff, f->grp, f->n_grp, \
                            f->T, f->F, tiles, d_status, c0, cn, d_prob, tree_words,           \
-                           (int)g_opt.forest_dbg, ctx->dbg_buf);                              \
+                           (int)g_opt.forest_dbg, ctx->dbg_buf, prune_sum);                   \
+    } while (0)
+#define PK_LAUNCH_LDS(SLOTS)                                                                  \
+    do {                                                                                      \
+        if (prune_sum > -1e300) PK_LAUNCH_LDS_P(SLOTS, true);                                 \
+        else PK_LAUNCH_LDS_P(SLOTS, false);                                                   \
     } while (0)
 
 #define PK_LAUNCH_PIPE(SS)                                                                    \
@@ -663,7 +699,8 @@ static int pipe_shape(pk_forest *f, size_t fea_bytes, int *slots, int *region_wo
 }
 
 int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int blk,
-                     const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob)
+                     const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob,
+                     double prune_sum)
 {
     if (cn <= 0) return PK_OK;
     pk_prof_scope prof(ctx, PK_K_FOREST);
@@ -671,7 +708,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
     const size_t fea_bytes = (size_t)f->F * blk * sizeof(float);
     const int ilp = (int)g_opt.forest_ilp;
     int pslots = 0, region_words = 0;
-    if (blk == LDS_C && g_opt.forest_lds > 0 && g_opt.forest_pipe &&
+    if (blk == LDS_C && g_opt.forest_lds > 0 && g_opt.forest_pipe && !(prune_sum > -1e300) &&
         pipe_shape(f, fea_bytes, &pslots, &region_words)) {
         int rc = pk_forest_stage_flags(f, region_words - 2);
         if (rc) return rc;

@@ -151,3 +151,34 @@ def test_other_configs_sampled_parity(hip_lib, w, T, n, band, upper, stride):
     p_ref = onp.predict(fo, fea.astype(np.float32))
     assert np.array_equal(np.flatnonzero(st[sel]), keep)
     assert np.array_equal(gio.bits(pr[sel][keep]), gio.bits(p_ref))
+
+
+@pytest.mark.parametrize("thre", [0.5, 0.2, 0.9, 0.0])
+def test_early_exit_same_pixels(config2, thre):
+    """Option early_exit: candidates whose sum provably cannot exceed thre*T stop
+    walking.  The scored pixels (indices, probabilities, signal) are identical;
+    only the diagnostic probability of a pruned candidate reads 0."""
+    c = config2
+    w = c["w"]
+    sl = slice(0, 1_500_000)
+    x, y = c["x"][sl], c["y"][sl]
+    cd = _lib.HipCands(x, y)
+    n1 = cd.run(c["hm"], c["hf"], w, thre)
+    base = digest(*cd.fetch())
+    st, pr = cd.fetch_all()
+    _lib.set_option("early_exit", 1)
+    try:
+        cd2 = _lib.HipCands(x, y)
+        assert cd2.run(c["hm"], c["hf"], w, thre) == n1
+        assert digest(*cd2.fetch()) == base
+        st2, pr2 = cd2.fetch_all()
+    finally:
+        _lib.set_option("early_exit", 0)
+    assert np.array_equal(st2, st)
+    same = gio.bits(pr2) == gio.bits(pr)
+    assert np.all(same | (pr2 == 0.0))
+    assert np.all(pr[~same] <= thre)          # only losers were pruned
+    if thre >= 0.2:
+        assert (~same).mean() > 0.3           # and pruning actually happened
+    else:
+        assert np.all(same) or thre > 0.0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU-box helper: bench the forest variants back to back (one JSON line each).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for opts in ${SWEEP:-"forest_slots=8" "forest_slots=8" "forest_pipe=2"}; do
+for opts in ${SWEEP:-"early_exit=0" "early_exit=1"}; do
   args=""
   for o in ${opts//,/ }; do args="$args --opt $o"; done
   echo "== $opts"
