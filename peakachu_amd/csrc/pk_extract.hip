@@ -23,6 +23,10 @@
 //    kernel that keeps the window in LDS.
 #include "pk_common.h"
 
+#ifndef PK_EXTRACT_OCC
+#define PK_EXTRACT_OCC 2  // waves per SIMD the two-lane extractor (w=5) is compiled for
+#endif
+
 namespace {
 
 // scipy.ndimage._filters._gaussian_kernel1d(sigma=1, order=0, radius=4):
@@ -246,7 +250,7 @@ __device__ __forceinline__ void blur_row(const double (&row)[W + 5], double (&ou
 
 // (w=6 needs 273 registers: one wave per SIMD; forcing two spills and is slower)
 template <int W>
-__global__ __launch_bounds__(64, (W <= 5 ? 2 : 1)) void extract_pair_kernel(
+__global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pair_kernel(
     const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
     const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
     const int32_t *__restrict__ ys, int64_t c0, int64_t cn, float *__restrict__ tiles, int blk,
