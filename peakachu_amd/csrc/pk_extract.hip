@@ -236,15 +236,17 @@ __device__ __forceinline__ int lane_swap_i(int v)
     return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
 }
 
-// row blur of one local row: own columns 0..W plus 4 virtual columns
+// row blur of one local row: own columns 0..W (`own`) plus the 4 virtual columns
+// W+1..W+4 (`recv`, the partner's columns W-1..W-4 of the matching row)
 template <int W>
-__device__ __forceinline__ void blur_row(const double (&row)[W + 5], double (&out)[W + 1])
+__device__ __forceinline__ void blur_row(const double (&own)[W + 1], const double (&recv)[4],
+                                         double (&out)[W + 1])
 {
-#define RR(q_) row[(q_) < 0 ? -(q_) - 1 : (q_)]
+#define RR(q_) ((q_) < 0 ? own[-(q_) - 1] : ((q_) <= W ? own[(q_)] : recv[(q_) - W - 1]))
 #pragma unroll
     for (int q = 0; q <= W; q++)
-        out[q] = PK_BLUR9(row[q], RR(q - 4), row[q + 4], RR(q - 3), row[q + 3], RR(q - 2),
-                          row[q + 2], RR(q - 1), row[q + 1]);
+        out[q] = PK_BLUR9(own[q], RR(q - 4), RR(q + 4), RR(q - 3), RR(q + 3), RR(q - 2), RR(q + 2),
+                          RR(q - 1), RR(q + 1));
 #undef RR
 }
 
@@ -350,23 +352,25 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 #pragma unroll
     for (int ip = 0; ip <= W; ip++) {
         const int ia = ip, ib = S - 1 - ip;
-        double rowa[H + 4], rowb[H + 4], outa[H], outb[H];
-#pragma unroll
-        for (int q = 0; q < H; q++) {
-            rowa[q] = win[ia][q];
-            rowb[q] = win[ib][q];
-        }
+        // exchange first (both rows still hold their axis-0 values) ...
+        double ra[4], rb[4];
 #pragma unroll
         for (int u = 1; u <= 4; u++) {
-            rowa[W + u] = lane_swap(win[ib][W - u]);  // partner's row 2W-ia = ib
-            rowb[W + u] = lane_swap(win[ia][W - u]);
+            ra[u - 1] = lane_swap(win[ib][W - u]);  // partner's row 2W-ia = ib
+            rb[u - 1] = lane_swap(win[ia][W - u]);
         }
-        blur_row<W>(rowa, outa);
-        blur_row<W>(rowb, outb);
+        // ... then blur and write back one row at a time (few live temporaries)
+        {
+            double out[H];
+            blur_row<W>(win[ia], ra, out);
+            if (ia != ib) {
+                double outb[H];
+                blur_row<W>(win[ib], rb, outb);
 #pragma unroll
-        for (int q = 0; q < H; q++) {
-            win[ia][q] = outa[q];
-            win[ib][q] = outb[q];  // ia == ib for the middle row: same values
+                for (int q = 0; q < H; q++) win[ib][q] = outb[q];
+            }
+#pragma unroll
+            for (int q = 0; q < H; q++) win[ia][q] = out[q];
         }
     }
     // ---- utils.py:204-209 image_normalize; numpy min/max propagate NaN
