@@ -52,10 +52,7 @@ class Chromosome():
         with scipy); otherwise, or when a pixel falls inside the table's guard
         band, on the host with scipy directly."""
         self._cands = None
-        try:
-            got = self._candidates_on_device(lower, upper)
-        except _lib.PeakachuHipError:
-            got = None
+        got = self._candidates_on_device(lower, upper)  # device errors propagate
         if got is None:
             self.ridx, self.cidx = utils.candidates(self.raw_M, self.background, self.weights,
                                                     lower, upper)
