@@ -426,10 +426,12 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 // ------------------------------------------------------------------------
 constexpr int GEN_WAVES = 4;
 
-// scipy 'reflect' for an offset of at most 4 on a line of n >= 5: one fold
+// scipy 'reflect' at run time; windows narrower than the 9-tap kernel (w < 4) fold
+// more than once
 __device__ __forceinline__ int reflect1(int q, int n)
 {
-    return q < 0 ? -q - 1 : (q >= n ? 2 * n - 1 - q : q);
+    while (q < 0 || q >= n) q = q < 0 ? -q - 1 : 2 * n - 1 - q;
+    return q;
 }
 
 __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(

@@ -623,7 +623,7 @@ int pk_forest_tile_width(int F)
         return LDS_C;
     int blk = (int)((156 * 1024) / ((size_t)F * 4)) / 64 * 64;
     if (blk > 256) blk = 256;
-    if (blk < 64) blk = 0;  // F too large for an LDS-resident tile
+    if (blk < 64) blk = 64;  // no LDS-resident tile possible: the no-LDS kernel reads tiles from L2
     return blk;
 }
 
@@ -731,7 +731,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         case 7: PK_LAUNCH_LDS(7); break;
         default: PK_LAUNCH_LDS(8); break;
         }
-    } else if (blk < LDS_C && !g_opt.forest_l2_tile) {
+    } else if (blk < LDS_C && (!g_opt.forest_l2_tile || fea_bytes > (size_t)156 * 1024)) {
         // large F (w = 11): no LDS, features from the L2-resident tile
         const unsigned g2 = (unsigned)((cn + 255) / 256);
         switch (ilp) {
