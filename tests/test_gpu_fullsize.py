@@ -182,3 +182,26 @@ def test_early_exit_same_pixels(config2, thre):
         assert (~same).mean() > 0.3           # and pruning actually happened
     else:
         assert np.all(same) or thre > 0.0
+
+
+def test_extract_and_predict_across_chunks(config2):
+    """pk_extract (65 536-candidate staging chunks) and pk_predict (512 k chunks)
+    on inputs larger than one chunk: survivor order and sampled values vs the oracle."""
+    c = config2
+    w = c["w"]
+    x, y = c["x"][:200_000], c["y"][:200_000]
+    f64, f32, keep = c["hm"].extract(w, x, y, want64=True, want32=True)
+    assert np.all(np.diff(keep) > 0) and keep.size > 190_000
+    rng = np.random.default_rng(5)
+    sel = np.sort(rng.choice(keep.size, 2000, replace=False))
+    fea_ref, keep_ref = onp.extract(c["Mf"], c["e"], w, x[keep[sel]], y[keep[sel]])
+    assert keep_ref.size == sel.size
+    assert np.array_equal(gio.bits(f64[sel]), gio.bits(fea_ref))
+    assert np.array_equal(f32[sel], fea_ref.astype(np.float32))
+    # predict on > 524 288 rows: tile the extracted features three times
+    X = np.concatenate([f32, f32, f32[:200_000]])
+    p = c["hf"].predict(X)
+    fod = {k: getattr(c["fo"], k) for k in FlatForest.FIELDS}
+    sel2 = np.sort(rng.choice(X.shape[0], 3000, replace=False))
+    assert np.array_equal(gio.bits(p[sel2]), gio.bits(onp.predict(fod, X[sel2])))
+    assert np.array_equal(gio.bits(p[:keep.size]), gio.bits(p[keep.size:2 * keep.size]))
