@@ -110,6 +110,15 @@ int pk_score(pk_matrix *, pk_forest *, int w, double thre, int64_t batch,
              int64_t N, const int32_t *x, const int32_t *y, int32_t *ox,
              int32_t *oy, double *op, double *osignal, int64_t *n_out);
 
+/* ---- the diagonal means of utils.calculate_expected (peakachu/utils.py:157-170) ---
+ * means[i] = mean of M.diagonal(i) over the bins with valid[r] && valid[r+i] when
+ * more than 10 such pixels exist, else 0, for i = 0..top; summed in numpy's own
+ * order (8192-element buffers, pairwise inside) so the values are bit-identical to
+ * ndarray.mean().  `band0` is a pk_matrix built with dlo = 0 and dhi >= top from the
+ * entries calculate_expected keeps (finite ones in raw mode).  The isotonic fit that
+ * follows stays on the host (sklearn). */
+int pk_expected_means(pk_matrix *band0, int top, const uint8_t *valid, double *means);
+
 /* ---- Chromosome.get_candidate (peakachu/scoreUtils.py:40-68) ------------------
  * Scan the raw-count band for pixels on diagonals lower..upper whose Poisson
  * survival p-value against the expected count is < 0.01 and build the candidate

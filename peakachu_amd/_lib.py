@@ -47,6 +47,7 @@ SIGNATURES = {
     "pk_score_fetch_all": (C.c_int, [_vp, _u8p, _f64p]),
     "pk_score": (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.c_int64, C.c_int64, _i32p, _i32p,
                            _i32p, _i32p, _f64p, _f64p, C.POINTER(C.c_int64)]),
+    "pk_expected_means": (C.c_int, [_vp, C.c_int, _u8p, _f64p]),
     "pk_candidates_create": (_vp, [_vp, C.c_int, C.c_int, _vp, _f64p, _vp, _vp, C.c_int64,
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pk_cands_fetch": (C.c_int, [_vp, _i32p, _i32p]),
@@ -170,6 +171,13 @@ class HipMatrix:
         if not self.h:
             raise PeakachuHipError("pk_matrix_create: " + last_error())
         self.n, self.dlo, self.dhi, self.device = int(n), int(dlo), int(dhi), device
+
+    def expected_means(self, top, valid):
+        """Diagonal means of calculate_expected (this band must start at diagonal 0)."""
+        means = np.empty(int(top) + 1, np.float64)
+        check(self._L.pk_expected_means(self.h, int(top), np.ascontiguousarray(valid, np.uint8),
+                                        means), "pk_expected_means")
+        return means
 
     def extract(self, w, x, y, want64=True, want32=False):
         x = np.ascontiguousarray(x, np.int32)

@@ -664,6 +664,41 @@ extern "C" void pk_cands_destroy(pk_cands *c)
     delete c;
 }
 
+extern "C" int pk_expected_means(pk_matrix *m, int top, const uint8_t *valid, double *means)
+{
+    PK_API_LOCK;
+    if (!m || !valid || !means || top < 0 || m->dlo != 0 || top > m->dhi || top >= m->n) {
+        pk_set_error("pk_expected_means: bad arguments (needs a band with dlo = 0, dhi >= top)");
+        return PK_E_INVALID;
+    }
+    pk_device_ctx *ctx = pk_ctx(m->device);
+    if (!ctx) return PK_E_NODEVICE;
+    uint8_t *d_valid = nullptr;
+    double *d_scr = nullptr, *d_means = nullptr;
+    int rc = PK_OK;
+    const size_t scr = (size_t)(top + 1) * m->ld * sizeof(double);
+    if (hipMalloc((void **)&d_valid, (size_t)m->n) != hipSuccess ||
+        hipMalloc((void **)&d_scr, scr) != hipSuccess ||
+        hipMalloc((void **)&d_means, (size_t)(top + 1) * 8) != hipSuccess) {
+        pk_set_error("pk_expected_means: device allocation failed");
+        rc = PK_E_NOMEM;
+    }
+    if (!rc && hipMemcpyAsync(d_valid, valid, (size_t)m->n, hipMemcpyHostToDevice, ctx->stream) !=
+                   hipSuccess)
+        rc = PK_E_HIP;
+    if (!rc) rc = pk_launch_expected_means(ctx, m, top, d_valid, d_scr, d_means);
+    if (!rc && (hipMemcpyAsync(means, d_means, (size_t)(top + 1) * 8, hipMemcpyDeviceToHost,
+                               ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        pk_set_error("pk_expected_means: kernel / download failed");
+        rc = PK_E_HIP;
+    }
+    if (d_valid) hipFree(d_valid);
+    if (d_scr) hipFree(d_scr);
+    if (d_means) hipFree(d_means);
+    return rc;
+}
+
 static pk_cands *cands_alloc(int device, int64_t N)
 {
     pk_cands *c = new pk_cands();

@@ -189,6 +189,8 @@ int pk_forest_tile_width(int F);  // candidates per feature tile for F features
 
 int pk_launch_compact(pk_device_ctx *, const pk_matrix *, pk_cands *, double thre,
                       int64_t batch);
+int pk_launch_expected_means(pk_device_ctx *, const pk_matrix *m, int top, const uint8_t *d_valid,
+                             double *d_scratch, double *d_means);
 int pk_launch_candidates(pk_device_ctx *, const pk_matrix *raw, int lower, int upper,
                          const int64_t *d_kstar, const double *d_bg, const double *d_w,
                          const double *d_mustar, int64_t n_mustar, int64_t *d_total,

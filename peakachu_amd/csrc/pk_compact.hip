@@ -278,7 +278,150 @@ __global__ void cand_scatter_kernel(const double *__restrict__ band, int64_t ld,
     }
 }
 
+// ---- calculate_expected (peakachu/utils.py:139-178): mean of every diagonal over
+// the valid bins, summed exactly as numpy does ---------------------------------
+// numpy's add.reduce walks a contiguous float64 array in buffers of 8192 elements;
+// each buffer is summed pairwise (blocks of <= 128 elements with 8 interleaved
+// accumulators, split at n/2 rounded down to a multiple of 8) and the buffer sums are
+// added one after the other (checked against np.sum / ndarray.mean in
+// tests/test_host_golden.py::test_numpy_sum_model).
+__device__ double np_block_sum(const double *a, int n)  // n <= 128
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+constexpr int EXP_THREADS = 256;
+constexpr int EXP_MAXLEAF = 128;  // an 8192-element buffer splits into at most 128 blocks
+
+// one workgroup per diagonal
+__global__ __launch_bounds__(EXP_THREADS) void expected_means_kernel(
+    const double *__restrict__ band, int64_t ld, int n, int top,
+    const uint8_t *__restrict__ valid, double *__restrict__ scratch, double *__restrict__ means)
+{
+    __shared__ int cnt[EXP_THREADS + 1];
+    __shared__ int leaf_lo[EXP_MAXLEAF], leaf_n[EXP_MAXLEAF];
+    __shared__ double leaf_sum[EXP_MAXLEAF];
+    __shared__ int n_leaf;
+    __shared__ double total;
+    const int i = blockIdx.x;  // diagonal
+    if (i > top) return;
+    const int tid = threadIdx.x;
+    const int len = n - i;
+    const double *diag = band + (int64_t)i * ld;
+    double *vals = scratch + (int64_t)i * ld;
+    // 1. ordered compaction of diag[r] over valid[r] & valid[r+i] (thread t owns a
+    //    contiguous run of rows, so thread order = row order)
+    const int seg = (len + EXP_THREADS - 1) / EXP_THREADS;
+    const int r0 = tid * seg, r1 = min(len, r0 + seg);
+    int c = 0;
+    for (int r = r0; r < r1; r++) c += (valid[r] && valid[r + i]) ? 1 : 0;
+    cnt[tid + 1] = c;
+    if (tid == 0) cnt[0] = 0;
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 1; t <= EXP_THREADS; t++) cnt[t] += cnt[t - 1];
+    __syncthreads();
+    int pos = cnt[tid];
+    for (int r = r0; r < r1; r++)
+        if (valid[r] && valid[r + i]) vals[pos++] = diag[r];
+    const int nv = cnt[EXP_THREADS];
+    __syncthreads();
+    if (nv <= 10) {  // utils.py:168: only diagonals with more than 10 valid pixels
+        if (tid == 0) means[i] = 0.0;
+        return;
+    }
+    // 2. numpy-order sum: buffers of 8192, pairwise inside
+    if (tid == 0) total = 0.0;
+    for (int b0 = 0; b0 < nv; b0 += 8192) {
+        const int bn = min(8192, nv - b0);
+        __syncthreads();
+        if (tid == 0) {
+            // enumerate the blocks of the pairwise recursion in order (explicit stack)
+            int slo[16], sn[16], sp = 0, nl = 0;
+            slo[0] = 0; sn[0] = bn; sp = 1;
+            while (sp > 0) {
+                sp--;
+                const int lo = slo[sp], m = sn[sp];
+                if (m <= 128) {
+                    leaf_lo[nl] = lo; leaf_n[nl] = m; nl++;
+                } else {
+                    int h = m / 2;
+                    h -= h % 8;
+                    slo[sp] = lo + h; sn[sp] = m - h; sp++;   // right, visited second
+                    slo[sp] = lo; sn[sp] = h; sp++;           // left first
+                }
+            }
+            n_leaf = nl;
+        }
+        __syncthreads();
+        for (int l = tid; l < n_leaf; l += EXP_THREADS)
+            leaf_sum[l] = np_block_sum(vals + b0 + leaf_lo[l], leaf_n[l]);
+        __syncthreads();
+        if (tid == 0) {
+            // combine in recursion order: post-order walk with a value stack
+            // frame: (n, state) ; leaves are consumed in the order they were listed
+            int fn[16], fs[16], sp = 0, nextleaf = 0;
+            double val[16];
+            fn[0] = bn; fs[0] = 0; sp = 1;
+            double ret = 0.0;
+            while (sp > 0) {
+                const int m = fn[sp - 1];
+                if (m <= 128) {
+                    ret = leaf_sum[nextleaf++];
+                    sp--;
+                    // hand the value to the parent
+                    while (sp > 0) {
+                        if (fs[sp - 1] == 1) {  // parent waits for its left value
+                            val[sp - 1] = ret;
+                            fs[sp - 1] = 2;
+                            int h = fn[sp - 1] / 2;
+                            h -= h % 8;
+                            fn[sp] = fn[sp - 1] - h; fs[sp] = 0; sp++;
+                            break;
+                        } else {  // fs == 2: right value arrived
+                            ret = val[sp - 1] + ret;
+                            sp--;
+                        }
+                    }
+                } else {
+                    int h = m / 2;
+                    h -= h % 8;
+                    fs[sp - 1] = 1;
+                    fn[sp] = h; fs[sp] = 0; sp++;
+                }
+            }
+            total = (b0 == 0) ? ret : total + ret;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) means[i] = total / (double)nv;  // ndarray.mean: sum / count
+}
+
 }  // namespace
+
+// diagonal means for calculate_expected; `m` is a band with dlo == 0
+int pk_launch_expected_means(pk_device_ctx *ctx, const pk_matrix *m, int top,
+                             const uint8_t *d_valid, double *d_scratch, double *d_means)
+{
+    pk_prof_scope prof(ctx, PK_K_BAND);
+    hipLaunchKernelGGL(expected_means_kernel, dim3((unsigned)(top + 1)), dim3(EXP_THREADS), 0,
+                       ctx->stream, m->band, m->ld, m->n, top, d_valid, d_scratch, d_means);
+    PK_HIP(hipGetLastError());
+    return PK_OK;
+}
 
 // two-pass ordered compaction of the candidate flags; fills *total and, on the
 // second call (ox != nullptr), the coordinate arrays

@@ -19,14 +19,16 @@ class Chromosome():
         lower = max(lower, width + 1)
         upper = min(upper, M.shape[0] - 2 * width)
         # expected values (peakachu/scoreUtils.py:16-24)
+        # (diagonal means on the device, isotonic fit on the host)
         if weights is None:
-            self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=True)
+            self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=True, device=device)
             if M is raw_M:
                 self.background = self.exp_arr
             else:
-                self.background = utils.calculate_expected(raw_M, upper + 2 * width, raw=True)
+                self.background = utils.calculate_expected(raw_M, upper + 2 * width, raw=True,
+                                                           device=device)
         else:
-            self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=False)
+            self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=False, device=device)
             self.background = self.exp_arr
 
         self.raw_M = raw_M

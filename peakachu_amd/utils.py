@@ -54,9 +54,14 @@ def _dense_diagonals(indptr, indices, data, keep, n, maxdis):
     return D.reshape(maxdis + 1, n)
 
 
-def calculate_expected(M, maxdis, raw=False):
+def calculate_expected(M, maxdis, raw=False, device=None):
     """peakachu/utils.py:139-178: mean of each diagonal over valid bins, then
-    a non-increasing isotonic fit (sklearn IsotonicRegression)."""
+    a non-increasing isotonic fit (sklearn IsotonicRegression).
+
+    With `device` set, the diagonal means come from the GPU (pk_expected_means:
+    dense diagonals built on the device, summed in numpy's own order, so they are
+    bit-identical to the host path below); validity flags and the isotonic fit
+    stay on the host."""
     from sklearn.isotonic import IsotonicRegression
 
     M = canonical_csr(M)
@@ -79,17 +84,36 @@ def calculate_expected(M, maxdis, raw=False):
         keep = nz  # the reference keeps NaN entries in the diagonals here
     maxdis = int(maxdis)
     top = min(maxdis, n - 1)
-    D = _dense_diagonals(M.indptr, indices, data, keep, n, top)
     exp_arr = np.zeros(maxdis + 1)
-    for i in range(top + 1):
-        valid = valid_cols if i == 0 else valid_cols[:-i] * valid_cols[i:]
-        diag = D[i, :n - i][valid]
-        if diag.size > 10:
-            exp_arr[i] = diag.mean()
+    if device is not None:
+        exp_arr[:top + 1] = _diagonal_means_device(M, keep, n, top, valid_cols, device)
+    else:
+        D = _dense_diagonals(M.indptr, indices, data, keep, n, top)
+        for i in range(top + 1):
+            valid = valid_cols if i == 0 else valid_cols[:-i] * valid_cols[i:]
+            diag = D[i, :n - i][valid]
+            if diag.size > 10:
+                exp_arr[i] = diag.mean()
     IR = IsotonicRegression(increasing=False, out_of_bounds="clip")
     _d = np.where(exp_arr > 0)[0]
     IR.fit(_d, exp_arr[_d])
     return IR.predict(list(range(maxdis + 1)))
+
+
+def _diagonal_means_device(M, keep, n, top, valid_cols, device):
+    from . import _lib
+    if keep.all():
+        indptr, indices, data = M.indptr, M.indices, M.data
+    else:  # drop the entries calculate_expected ignores (non-finite ones in raw mode)
+        rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(M.indptr))
+        indptr = np.zeros(n + 1, np.int64)
+        np.cumsum(np.bincount(rows[keep], minlength=n), out=indptr[1:])
+        indices, data = M.indices[keep], M.data[keep]
+    hm = _lib.HipMatrix(indptr, indices, data, n, np.ones(1), 0, top, device=device)
+    try:
+        return hm.expected_means(top, valid_cols)
+    finally:
+        hm.close()
 
 
 def _poisson_count_thresholds(mu):

@@ -470,3 +470,34 @@ def test_score_genome_distributed_branch_single_rank(hip_lib, tmp_path):
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert out.read_text() == str(z["genome_weight"])
+
+
+@pytest.mark.parametrize("name", ["g3_score_raw.npz", "g3_score_weights.npz",
+                                  "g3_score_hicstyle.npz", "g5_buildmatrix.npz"])
+def test_expected_on_device_golden(hip_lib, name):
+    """calculate_expected with the diagonal means from the device equals the
+    reference's exp_arr bit for bit."""
+    z = gio.load(name)
+    if name.startswith("g5"):
+        M = gio.sym_matrix(z, "M")
+        e = utils.calculate_expected(M, int(z["maxdis"]), raw=False, device=0)
+    else:
+        raw = gio.sym_matrix(z, "R")
+        mode = str(z["mode"])
+        w = int(z["w"])
+        M = raw if mode == "raw" else (gio.balance(raw, z["weights"]) if mode == "weights"
+                                       else gio.hicstyle(raw, z["weights"]))
+        upper = min(int(z["upper"]), M.shape[0] - 2 * w)
+        e = utils.calculate_expected(M, upper + 2 * w, raw=(mode != "weights"), device=0)
+    assert np.array_equal(gio.bits(e), gio.bits(z["exp_arr"]))
+
+
+@pytest.mark.parametrize("n,raw", [(30000, True), (9001, False), (20011, True)])
+def test_expected_on_device_matches_numpy_large(hip_lib, n, raw):
+    """Diagonals longer than numpy's 8192-element reduction buffer."""
+    M, _ = synth.synth_band(n, 150, seed=n)
+    if not raw:
+        M = synth.balance(M, synth.synth_weights(n, 3, n_nan=9))
+    host = utils.calculate_expected(M, 170, raw=raw)
+    dev = utils.calculate_expected(M, 170, raw=raw, device=0)
+    assert np.array_equal(gio.bits(host), gio.bits(dev))

@@ -113,3 +113,48 @@ def test_cli_defaults_match_reference():
         ("chr21", "raw", 400, 0.1)
     args, _ = cli.getargs(["score_genome", "-C"])
     assert args.chroms == []
+
+
+def test_numpy_sum_model():
+    """The summation order pk_expected_means reproduces on the device: numpy adds
+    8192-element buffers one after the other, each summed pairwise (128-element
+    blocks, 8 accumulators, split at n/2 rounded down to a multiple of 8)."""
+    def pairwise(a, lo, n):
+        if n < 8:
+            r = 0.0
+            for i in range(n):
+                r = r + a[lo + i]
+            return r
+        if n <= 128:
+            r = [a[lo + j] for j in range(8)]
+            i = 8
+            while i < n - (n % 8):
+                for j in range(8):
+                    r[j] = r[j] + a[lo + i + j]
+                i += 8
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            while i < n:
+                res = res + a[lo + i]
+                i += 1
+            return res
+        h = n // 2
+        h -= h % 8
+        return pairwise(a, lo, h) + pairwise(a, lo + h, n - h)
+
+    def model(a):
+        acc, lo = None, 0
+        while lo < len(a):
+            m = min(8192, len(a) - lo)
+            p = pairwise(a, lo, m)
+            acc = p if acc is None else acc + p
+            lo += m
+        return acc
+
+    assert np.getbufsize() == 8192
+    rng = np.random.default_rng(3)
+    for n in [1, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 16385, 29990]:
+        a = rng.random(n) * rng.choice([1.0, 1e4])
+        a[rng.random(n) < 0.2] = 0
+        for arr in (a, a[rng.random(n) < 0.9]):
+            if len(arr):
+                assert float(arr.mean()) == model(arr) / len(arr)
