@@ -333,6 +333,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                # measured HBM rate of that kernel: PMC bytes per launch / its average duration
+                "traffic_GBs": (traffic / (dom_ms / dom_n * 1e-3) / 1e9) if (traffic and dom_n) else None,
                 "alg_bytes_per_candidate": b_alg(F),
                 "avg_launch_ms": dom_ms / dom_n if dom_n else None,
                 "launches": dom_n,
