@@ -6,20 +6,23 @@
 // missing_go_to_left), leaf class-1 fractions added in tree order in float64
 // and divided by T.
 //
-// Design (see DESIGN.md):
-//  * one candidate per lane; the candidate's F float32 features sit in LDS
-//    as a [F][BLK] tile, so the per-node feature fetch `fea[f*BLK + lane]`
-//    is bank-conflict-free whatever f each lane asks for;
+// Design (see DESIGN.md §4.2):
+//  * one candidate per lane; the candidate's F float32 features sit in LDS as a
+//    [F][128] tile, so the per-node feature fetch `fea[f*128 + lane]` is
+//    bank-conflict-free whatever f each lane asks for;
 //  * nodes are 8-byte words in preorder (left child = next word), thresholds
-//    pre-rounded down to float32 (identical decisions for float32 x); the
-//    forest (a few MB) is served from L2 / Infinity Cache;
-//  * a lane walks ILP trees at once: ILP independent load chains in flight
-//    hide the L2 latency at the 4-waves-per-CU occupancy the feature tile
-//    allows; leaf values are then added in tree order, so the float64 sum is
-//    the same sequential sum sklearn computes;
-//  * optional LDS staging of the trees (forest_lds): a workgroup streams
-//    groups of trees through LDS, all lanes walk the staged trees, which
-//    turns the dependent L2 loads into LDS reads.
+//    pre-rounded down to float32 (identical decisions for float32 x), leaves worth
+//    exactly 0 or 1 folded into their parent; the forest (1-2 MB) lives in L2;
+//  * leaf values are added in tree order, so the float64 sum is the sequential sum
+//    sklearn computes.
+// Kernels in this file:
+//    forest_lds_kernel<SLOTS, PRUNE>  (default) trees streamed through LDS in groups,
+//        16 waves per CU, two barriers per group; PRUNE = exact early termination
+//    forest_pipe_kernel<S>            the same without workgroup barriers (per-slot LDS
+//        regions + an LDS ring); chosen automatically only when 8 regions fit
+//    forest_l2_kernel<ILP>            feature tile in LDS, nodes read through L2
+//    forest_gmem_kernel<ILP>          no LDS at all, for feature counts whose tile
+//        cannot share the LDS with trees (w = 11 ... 15)
 #include "pk_common.h"
 
 namespace {
