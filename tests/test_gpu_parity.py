@@ -501,3 +501,32 @@ def test_expected_on_device_matches_numpy_large(hip_lib, n, raw):
     host = utils.calculate_expected(M, 170, raw=raw)
     dev = utils.calculate_expected(M, 170, raw=raw, device=0)
     assert np.array_equal(gio.bits(host), gio.bits(dev))
+
+
+@pytest.mark.parametrize("w", [5, 6, 7])
+def test_extract_unnormalised_when_exp_arr_too_short(hip_lib, w):
+    """distance_normaize_core returns the window unnormalised when its largest
+    |col-row| is outside exp_arr (peakachu/utils.py:191-192); both extractor
+    kernels and the generic one must do the same."""
+    n, band, upper = 400, 90, 70
+    M, _ = synth.synth_band(n, band, seed=w)
+    e_full = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    e_short = e_full[:40 + 2 * w].copy()          # candidates with d + 2w >= len are not normalised
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    sel = (y - x > 30 - 2 * w) & (y - x < 52)     # straddle the boundary
+    x, y = x[sel][::3], y[sel][::3]
+    Mc = utils.canonical_csr(Mf)
+    for pair in (1, 0):
+        _lib.set_option("extract_pair", pair)
+        try:
+            hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e_short, -2 * w + 1,
+                                upper + 2 * w - 1)
+            f64, _, keep = hm.extract(w, x, y)
+        finally:
+            _lib.set_option("extract_pair", 1)
+        fea, keep_ref = onp.extract(Mf, e_short, w, x, y)
+        assert np.array_equal(keep, keep_ref) and keep.size > 50
+        assert np.array_equal(gio.bits(f64), gio.bits(fea))
+    d = (y - x)[keep]
+    assert (d + 2 * w >= e_short.size).any() and (d + 2 * w < e_short.size).any()
