@@ -204,6 +204,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_lds = value;
     } else if (!strcmp(name, "overlap")) {
         g_opt.overlap = value != 0;
+    } else if (!strcmp(name, "extract_clean")) {
+        g_opt.extract_clean = value != 0;
     } else if (!strcmp(name, "extract_pair")) {
         g_opt.extract_pair = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
@@ -236,6 +238,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_lds")) return g_opt.forest_lds;
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
     if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
+    if (!strcmp(name, "extract_clean")) return g_opt.extract_clean;
     if (!strcmp(name, "overlap")) return g_opt.overlap;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
     if (!strcmp(name, "forest_l2_tile")) return g_opt.forest_l2_tile;
@@ -612,6 +615,7 @@ extern "C" void pk_matrix_destroy(pk_matrix *m)
     if (!m) return;
     hipSetDevice(m->device);
     if (m->band) hipFree(m->band);
+    if (m->norm) hipFree(m->norm);
     if (m->exp_arr) hipFree(m->exp_arr);
     delete m;
 }
@@ -826,6 +830,10 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     const size_t tile_floats = (size_t)chunk * F;
     int rc = pk_ctx_reserve_tiles(ctx, 2 * tile_floats * sizeof(float));
     if (rc) return rc;
+    if ((w == 5 || w == 6) && g_opt.extract_pair && g_opt.extract_clean) {
+        rc = pk_matrix_prepare_norm(ctx, m);
+        if (rc) return rc;
+    }
     // Two tile buffers: extract(k+1) runs on the low-priority stream beside forest(k).
     // The forest kernel is LDS / latency bound and leaves ~40 % of the VALU issue slots
     // and (at <= 72 VGPRs) room for one 216-register extractor wave per SIMD, which is
@@ -984,6 +992,8 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     std::vector<double> h_rows((size_t)chunk * F);
     std::vector<uint8_t> h_status((size_t)chunk);
     rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
+    if (!rc && (w == 5 || w == 6) && g_opt.extract_pair && g_opt.extract_clean)
+        rc = pk_matrix_prepare_norm(ctx, m);
     if (!rc && hipMalloc((void **)&d_rows, (size_t)chunk * F * sizeof(double)) != hipSuccess) {
         pk_set_error("pk_extract: staging allocation failed");
         rc = PK_E_NOMEM;

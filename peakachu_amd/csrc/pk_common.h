@@ -60,6 +60,7 @@ struct pk_options {
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
     int64_t overlap = 0;        // run extract(k+1) beside forest(k) on a second stream (measured: no gain,
                                 // the forest slows by what the extractor saves -- both are VALU-issue bound)
+    int64_t extract_clean = 1;  // use the pre-divided band + shortcuts when the matrix qualifies
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
     int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
     int64_t forest_pipe_slots = 0;  // 0 = as many as fit (max 8)
@@ -146,6 +147,11 @@ struct pk_matrix {
     double *band;          // device
     double *exp_arr;       // device
     int32_t exp_len;
+    // the band divided by the expected values, built on first use for the two-lane
+    // extractor when the matrix passes its checks (see norm_band_kernel)
+    double *norm = nullptr;
+    bool norm_tried = false;
+    bool clean = false;
 };
 
 struct pk_cands {
@@ -171,6 +177,7 @@ int pk_launch_band_build(pk_device_ctx *, pk_matrix *, const int32_t *d_indptr,
 
 // features of candidates [c0, c0+cn) -> tiles (tile width BLK) + status.
 // If fea64_rows != nullptr also writes row-major float64 features [cn][F].
+int pk_matrix_prepare_norm(pk_device_ctx *, pk_matrix *);
 int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
                       int blk, uint8_t *d_status, double *fea64_rows);

@@ -251,9 +251,16 @@ __device__ __forceinline__ void blur_row(const double (&own)[W + 1], const doubl
 }
 
 // (w=6 needs 273 registers: one wave per SIMD; forcing two spills and is slower)
-template <int W>
+// CLEAN: the matrix passed pk_norm_band_kernel's checks (no NaN, no negative or -0 cell,
+// expected values finite and positive, every quotient finite and non-zero exactly where
+// the count is).  The window is then read from the pre-divided band `norm` (the same
+// IEEE quotient count / expected, computed once per cell instead of once per window
+// cell), the NaN clean-up and NaN tracking are identities and are dropped, and min / max
+// use v_min_f64 / v_max_f64 (no -0 can arise from non-negative inputs).
+template <int W, bool CLEAN>
 __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pair_kernel(
-    const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
+    const double *__restrict__ band, const double *__restrict__ norm, int64_t ld, int dlo, int dhi,
+    int n,
     const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
     const int32_t *__restrict__ ys, int64_t c0, int64_t cn, float *__restrict__ tiles, int blk,
     uint8_t *__restrict__ status, double *__restrict__ fea64_rows)
@@ -278,6 +285,9 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
     const int64_t r0 = (int64_t)(xc - W);
 
     // ---- gather: local (i, q) = global (gi, gj), diagonal k = d + gj - gi = d + sgn (q - i)
+    const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
+    const bool normalise = dmax < exp_len;  // utils.py:180-202 (else the window stays raw)
+    const double *__restrict__ src = (CLEAN && normalise) ? norm : band;
     double win[S][H];
 #pragma unroll
     for (int i = 0; i < S; i++) {
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
             const int gi = role ? 2 * W - i : i;
             const int k = d + sgn * (q - i);
             double v = 0.0;
-            if (ok && k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + gi];
+            if (ok && k >= dlo && k <= dhi) v = src[(int64_t)(k - dlo) * ld + r0 + gi];
             win[i][q] = v;
         }
     }
@@ -297,32 +307,64 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 #pragma unroll
         for (int q = 0; q < H; q++) {
             double v = win[i][q];
-            v = (v != v) ? 0.0 : v;
-            win[i][q] = v;
+            if (!CLEAN) {
+                v = (v != v) ? 0.0 : v;
+                win[i][q] = v;
+            }
             const bool mine = (q < W) || (role == 0);
-            nnz += (mine && v != 0.0) ? 1 : 0;
+            nnz += (mine && v != 0.0) ? 1 : 0;  // CLEAN: quotient != 0 <=> count != 0
         }
     }
     nnz += lane_swap_i(nnz);
     ok = ok && !((double)nnz < (double)F * 0.1);
     // ---- utils.py:228-232: top-left w x w mean (numba: sequential C order) = lane A's
-    // local rows / columns 0..w-1
+    // local rows / columns 0..w-1, of the RAW counts
     double acc = 0.0;
+    double centre = win[W][W];  // the centre cell is local (W, W) in both lanes
+    if (CLEAN) {
+        if (normalise) {
+            if (role == 0) {
+                double tl[W][W];
 #pragma unroll
-    for (int i = 0; i < W; i++) {
+                for (int i = 0; i < W; i++) {
 #pragma unroll
-        for (int q = 0; q < W; q++) acc += win[i][q];
+                    for (int q = 0; q < W; q++) {
+                        const int k = d + q - i;
+                        double v = 0.0;
+                        if (ok && k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + i];
+                        tl[i][q] = v;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < W; i++) {
+#pragma unroll
+                    for (int q = 0; q < W; q++) acc += tl[i][q];
+                }
+            }
+            centre = (d >= dlo && d <= dhi) ? band[(int64_t)(d - dlo) * ld + xc] : 0.0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+#pragma unroll
+                for (int q = 0; q < W; q++) acc += win[i][q];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+#pragma unroll
+            for (int q = 0; q < W; q++) acc += win[i][q];
+        }
     }
     const double acc_partner = lane_swap(acc);
     acc = role ? acc_partner : acc;
     const double ll_mean = acc / (double)(W * W);
     ok = ok && (ll_mean > 0.0);
-    const double p2ll = win[W][W] / ll_mean;  // the centre cell is local (W, W) in both lanes
+    const double p2ll = centre / ll_mean;
     ok = ok && (p2ll > 0.1);
 
     // ---- utils.py:180-202: divide by expected(|col-row|), col-row = d + sgn (q - i)
-    const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
-    if (dmax < exp_len) {
+    if (!CLEAN && normalise) {
         double e[3 * W + 1];  // m = q - i + 2W runs over 0 .. 3W
 #pragma unroll
         for (int m = 0; m <= 3 * W; m++) e[m] = exp_arr[iabs(d + sgn * (m - 2 * W))];
@@ -375,26 +417,40 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
     }
     // ---- utils.py:204-209 image_normalize; numpy min/max propagate NaN
     double mn = win[0][0], mx = win[0][0];
-    int has_nan = 0;
+    if (CLEAN) {
+        // finite, non-negative, bounded inputs: no NaN, no infinity, no -0 after the blur
 #pragma unroll
-    for (int i = 0; i < S; i++) {
+        for (int i = 0; i < S; i++) {
 #pragma unroll
-        for (int q = 0; q < H; q++) {
-            const double v = win[i][q];
-            has_nan |= (v != v) ? 1 : 0;
-            mn = (v < mn) ? v : mn;
-            mx = (v > mx) ? v : mx;
+            for (int q = 0; q < H; q++) {
+                mn = __builtin_fmin(mn, win[i][q]);
+                mx = __builtin_fmax(mx, win[i][q]);
+            }
         }
-    }
-    {
-        const double omn = lane_swap(mn), omx = lane_swap(mx);
-        mn = (omn < mn) ? omn : mn;
-        mx = (omx > mx) ? omx : mx;
-        has_nan |= lane_swap_i(has_nan);
-    }
-    if (has_nan) {
-        mn = __builtin_nan("");
-        mx = mn;
+        mn = __builtin_fmin(mn, lane_swap(mn));
+        mx = __builtin_fmax(mx, lane_swap(mx));
+    } else {
+        int has_nan = 0;
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+                const double v = win[i][q];
+                has_nan |= (v != v) ? 1 : 0;
+                mn = (v < mn) ? v : mn;
+                mx = (v > mx) ? v : mx;
+            }
+        }
+        {
+            const double omn = lane_swap(mn), omx = lane_swap(mx);
+            mn = (omn < mn) ? omn : mn;
+            mx = (omx > mx) ? omx : mx;
+            has_nan |= lane_swap_i(has_nan);
+        }
+        if (has_nan) {
+            mn = __builtin_nan("");
+            mx = mn;
+        }
     }
     const double den = mx - mn;
     const int64_t tile = local / blk;
@@ -556,7 +612,73 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     if (lane == 0) status[c] = fea_nan ? 2 : 1;
 }
 
+// ---- pre-divided band for the CLEAN extractor ---------------------------------
+// norm[kk][r] = count / expected(|k|) (count NaN -> 0 first), the quotient
+// distance_normalize computes per window cell (utils.py:180-202).  flags collects
+// everything that would make the CLEAN kernel's shortcuts differ from the reference.
+__global__ void norm_band_kernel(const double *__restrict__ band, double *__restrict__ norm,
+                                 int64_t ld, int ndiag, int dlo, int n,
+                                 const double *__restrict__ exp_arr, int exp_len,
+                                 int *__restrict__ flags)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kk = blockIdx.y;
+    if (r >= ld || kk >= ndiag) return;
+    const int k = kk + dlo;
+    const double raw = band[(int64_t)kk * ld + r];
+    int bad = 0;
+    double q = raw;
+    if (raw != raw) bad = 1;                                   // NaN count
+    if (__double2hiint(raw) < 0) bad = 1;                      // negative or -0
+    if (!(raw < 1e150)) bad = 1;                               // inf / huge
+    const int ak = iabs(k);
+    if (ak < exp_len) {
+        const double e = exp_arr[ak];
+        if (!(e > 0.0) || !(e < 1e300)) bad = 1;
+        q = raw / e;
+        if (!(q < 1e150) || ((raw != 0.0) != (q != 0.0))) bad = 1;
+    }
+    norm[(int64_t)kk * ld + r] = q;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+}
+
 }  // namespace
+
+int pk_matrix_prepare_norm(pk_device_ctx *ctx, pk_matrix *m)
+{
+    if (m->norm_tried) return PK_OK;
+    m->norm_tried = true;
+    m->clean = false;
+    const int ndiag = m->dhi - m->dlo + 1;
+    const size_t bytes = (size_t)ndiag * m->ld * sizeof(double);
+    int *d_flags = nullptr;
+    if (hipMalloc((void **)&m->norm, bytes) != hipSuccess) {
+        (void)hipGetLastError();  // no room for the second band: keep the general kernel
+        m->norm = nullptr;
+        return PK_OK;
+    }
+    PK_HIP(hipMalloc((void **)&d_flags, sizeof(int)));
+    PK_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(norm_band_kernel, dim3((unsigned)((m->ld + 255) / 256), (unsigned)ndiag),
+                       dim3(256), 0, ctx->stream, m->band, m->norm, m->ld, ndiag, m->dlo, m->n,
+                       m->exp_arr, m->exp_len, d_flags);
+    int h_flags = 1;
+    const bool ok = hipGetLastError() == hipSuccess &&
+                    hipMemcpyAsync(&h_flags, d_flags, sizeof(int), hipMemcpyDeviceToHost,
+                                   ctx->stream) == hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess;
+    hipFree(d_flags);
+    if (!ok) {
+        pk_set_error("pk_matrix_prepare_norm: HIP error");
+        return PK_E_HIP;
+    }
+    m->clean = (h_flags == 0);
+    if (!m->clean) {  // the second band is of no use then
+        hipFree(m->norm);
+        m->norm = nullptr;
+    }
+    return PK_OK;
+}
 
 int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
@@ -566,14 +688,19 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
     pk_prof_scope prof(ctx, PK_K_EXTRACT, st);
     if ((w == 5 || w == 6) && g_opt.extract_pair) {
         const unsigned grid = (unsigned)((cn + 31) / 32);
-        if (w == 5)
-            hipLaunchKernelGGL(extract_pair_kernel<5>, dim3(grid), dim3(64), 0, st, m->band,
-                               m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0, cn,
-                               tiles, blk, d_status, fea64_rows);
-        else
-            hipLaunchKernelGGL(extract_pair_kernel<6>, dim3(grid), dim3(64), 0, st, m->band,
-                               m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0, cn,
-                               tiles, blk, d_status, fea64_rows);
+        const bool clean = m->norm != nullptr && m->clean && g_opt.extract_clean != 0;
+#define PK_PAIR(WW, CC)                                                                          \
+    hipLaunchKernelGGL((extract_pair_kernel<WW, CC>), dim3(grid), dim3(64), 0, st, m->band,      \
+                       m->norm, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y,   \
+                       c0, cn, tiles, blk, d_status, fea64_rows)
+        if (w == 5) {
+            if (clean) PK_PAIR(5, true);
+            else PK_PAIR(5, false);
+        } else {
+            if (clean) PK_PAIR(6, true);
+            else PK_PAIR(6, false);
+        }
+#undef PK_PAIR
     } else if (w == 5 || w == 6) {
         const int threads = 64;
         const unsigned grid = (unsigned)((cn + threads - 1) / threads);

@@ -205,3 +205,22 @@ def test_extract_and_predict_across_chunks(config2):
     sel2 = np.sort(rng.choice(X.shape[0], 3000, replace=False))
     assert np.array_equal(gio.bits(p[sel2]), gio.bits(onp.predict(fod, X[sel2])))
     assert np.array_equal(gio.bits(p[:keep.size]), gio.bits(p[keep.size:2 * keep.size]))
+
+
+def test_clean_and_general_extractor_agree_on_config2(config2):
+    """Config 2 qualifies for the pre-divided band; switching the shortcut off must not
+    change a single reported pixel, probability or survivor flag."""
+    c = config2
+    out = {}
+    for clean in (1, 0):
+        _lib.set_option("extract_clean", clean)
+        try:
+            M = c["Mf"]
+            hm = _lib.HipMatrix(M.indptr, M.indices, M.data, M.shape[0], c["e"], -2 * c["w"] + 1,
+                                200 + 2 * c["w"] - 1)
+            cd = _lib.HipCands(c["x"], c["y"])
+            cd.run(hm, c["hf"], c["w"], 0.5)
+            out[clean] = digest(*cd.fetch(), *cd.fetch_all())
+        finally:
+            _lib.set_option("extract_clean", 1)
+    assert out[0] == out[1]

@@ -530,3 +530,66 @@ def test_extract_unnormalised_when_exp_arr_too_short(hip_lib, w):
         assert np.array_equal(gio.bits(f64), gio.bits(fea))
     d = (y - x)[keep]
     assert (d + 2 * w >= e_short.size).any() and (d + 2 * w < e_short.size).any()
+
+
+@pytest.mark.parametrize("w", [5, 6])
+@pytest.mark.parametrize("poison", ["none", "nan", "negative", "negzero", "inf", "huge",
+                                    "exp_zero", "exp_nan", "exp_inf", "exp_tiny"])
+def test_clean_extractor_and_its_fallback(hip_lib, w, poison):
+    """The two-lane extractor reads a pre-divided band and drops NaN handling when the
+    matrix qualifies (non-negative finite counts, positive finite expected values).  A
+    single offending cell or expected value must send the whole matrix down the general
+    kernel; either way the float64 features equal the oracle's bit for bit, and the
+    clean kernel equals the general one on clean input."""
+    n, band, upper = 500, 80, 60
+    M, _ = synth.synth_band(n, band, seed=11 + w)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    x, y = x[::2], y[::2]
+    Mc = utils.canonical_csr(Mf).copy()
+    Mc.data = Mc.data.astype(np.float64)
+    e = e.copy()
+    k = Mc.data.size // 2
+    if poison == "nan":
+        Mc.data[k] = np.nan
+    elif poison == "negative":
+        Mc.data[k] = -3.0
+    elif poison == "negzero":
+        Mc.data[k] = -0.0
+    elif poison == "inf":
+        Mc.data[k] = np.inf
+    elif poison == "huge":
+        Mc.data[k] = 1e200
+    elif poison == "exp_zero":
+        e[7] = 0.0
+    elif poison == "exp_nan":
+        e[7] = np.nan
+    elif poison == "exp_inf":
+        e[7] = np.inf
+    elif poison == "exp_tiny":
+        e[7] = 1e-200
+    got = {}
+    for clean in (1, 0):
+        _lib.set_option("extract_clean", clean)
+        try:
+            hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e, -2 * w + 1,
+                                upper + 2 * w - 1)
+            got[clean] = hm.extract(w, x, y)
+        finally:
+            _lib.set_option("extract_clean", 1)
+    with np.errstate(all="ignore"):
+        fea, keep_ref = onp.extract(Mc, e, w, x, y)
+    # NaN features (a NaN expected value poisons every window that touches its diagonal):
+    # the positions must agree; the sign bit of a NaN is not defined by IEEE 754 and
+    # differs between x86 (subsd keeps it) and gfx950 (v_add_f64 with a negated operand
+    # flips it), so NaNs are compared as NaNs, everything else bit for bit
+    nan_ref = np.isnan(fea)
+    for clean in (1, 0):
+        f64, _, keep = got[clean]
+        assert np.array_equal(keep, keep_ref) and keep.size > 100, (poison, clean)
+        assert np.array_equal(np.isnan(f64), nan_ref), (poison, clean)
+        assert np.array_equal(gio.bits(f64)[~nan_ref], gio.bits(fea)[~nan_ref]), (poison, clean)
+    assert np.array_equal(gio.bits(got[0][0]), gio.bits(got[1][0]))   # general == clean path
+    if poison in ("none", "exp_tiny"):
+        assert not nan_ref.any()
