@@ -81,7 +81,9 @@ void pk_matrix_destroy(pk_matrix *);
  * (2w+1)^2 window, distance_normalize (peakachu/utils.py:211-237), gaussian
  * blur (sigma=1), image_normalize (peakachu/utils.py:204-209), ravel.
  * keep[i] = index into the input of survivor i (input order).
- * fea64 / fea32: [n_keep, F] row-major, either may be NULL. */
+ * fea64 / fea32: [n_keep, F] row-major, either may be NULL.  A feature that is
+ * NaN in the reference is NaN here; the sign bit / payload of a NaN is not
+ * reproduced (IEEE 754 leaves it open and x86 and gfx950 differ). */
 int pk_extract(pk_matrix *, int w, int64_t N, const int32_t *x, const int32_t *y,
                double *fea64, float *fea32, int64_t *keep, int64_t *n_keep);
 
