@@ -578,7 +578,10 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
     int32_t *d_indptr = nullptr, *d_indices = nullptr;
     double *d_data = nullptr;
     const size_t band_bytes = (size_t)(dhi - dlo + 1) * m->ld * sizeof(double);
-    bool ok = hipMalloc((void **)&m->band, band_bytes) == hipSuccess &&
+    // room for the quotient band of the clean extractor right behind the raw band, when
+    // 32-bit byte offsets reach both
+    const bool with_norm = 2 * band_bytes < (1ull << 32) - 4096;
+    bool ok = hipMalloc((void **)&m->band, with_norm ? 2 * band_bytes : band_bytes) == hipSuccess &&
               hipMalloc((void **)&m->exp_arr, sizeof(double) * (size_t)exp_len) == hipSuccess &&
               hipMalloc((void **)&d_indptr, sizeof(int32_t) * (size_t)(n + 1)) == hipSuccess &&
               hipMalloc((void **)&d_indices, sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)) == hipSuccess &&
@@ -593,6 +596,7 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
                                 hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
                  hipMemcpyAsync(d_data, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice,
                                 ctx->stream) == hipSuccess;
+        if (ok && with_norm) m->norm = m->band + band_bytes / sizeof(double);
         if (ok) ok = pk_launch_band_build(ctx, m, d_indptr, d_indices, d_data, nnz) == PK_OK;
         if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
         if (!ok && !g_err[0]) pk_set_error("pk_matrix_create: upload / band build failed");
@@ -614,8 +618,7 @@ extern "C" void pk_matrix_destroy(pk_matrix *m)
     PK_API_LOCK;
     if (!m) return;
     hipSetDevice(m->device);
-    if (m->band) hipFree(m->band);
-    if (m->norm) hipFree(m->norm);
+    if (m->band) hipFree(m->band);  // the quotient band lives in the same allocation
     if (m->exp_arr) hipFree(m->exp_arr);
     delete m;
 }

@@ -23,6 +23,12 @@
 //    kernel that keeps the window in LDS.
 #include "pk_common.h"
 
+// scoreUtils.py:75 tests two edges only; candidates come from the upper triangle
+// (x <= y, scoreUtils.py:40-68), where the other two follow.  For x > y the reference's
+// fancy index raises IndexError (x + w >= n) or wraps (y - w < 0); such a window is
+// filtered here, so no kernel ever reads outside the band.
+#define PK_OTHER_EDGES(xi, yi, W, n) ((xi) + (W) < (n) && (yi) - (W) >= 0)
+
 #ifndef PK_EXTRACT_OCC
 #define PK_EXTRACT_OCC 2  // waves per SIMD the two-lane extractor (w=5) is compiled for
 #endif
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(64) void extract_reg_kernel(
     const int xi = xs[c], yi = ys[c];
 
     // scoreUtils.py:75: the window must lie inside the matrix
-    if (!(xi - W >= 0 && yi + W + 1 <= n)) {
+    if (!(xi - W >= 0 && yi + W + 1 <= n && PK_OTHER_EDGES(xi, yi, W, n))) {
         status[c] = 0;
         return;
     }
@@ -251,16 +257,9 @@ __device__ __forceinline__ void blur_row(const double (&own)[W + 1], const doubl
 }
 
 // (w=6 needs 273 registers: one wave per SIMD; forcing two spills and is slower)
-// CLEAN: the matrix passed pk_norm_band_kernel's checks (no NaN, no negative or -0 cell,
-// expected values finite and positive, every quotient finite and non-zero exactly where
-// the count is).  The window is then read from the pre-divided band `norm` (the same
-// IEEE quotient count / expected, computed once per cell instead of once per window
-// cell), the NaN clean-up and NaN tracking are identities and are dropped, and min / max
-// use v_min_f64 / v_max_f64 (no -0 can arise from non-negative inputs).
-template <int W, bool CLEAN>
+template <int W>
 __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pair_kernel(
-    const double *__restrict__ band, const double *__restrict__ norm, int64_t ld, int dlo, int dhi,
-    int n,
+    const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
     const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
     const int32_t *__restrict__ ys, int64_t c0, int64_t cn, float *__restrict__ tiles, int blk,
     uint8_t *__restrict__ status, double *__restrict__ fea64_rows)
@@ -278,16 +277,14 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
     const bool in_range = local < cn;
     const int64_t c = c0 + (in_range ? local : 0);
     const int xi = xs[c], yi = ys[c];
-    bool ok = in_range && (xi - W >= 0 && yi + W + 1 <= n);  // scoreUtils.py:75
+    bool ok = in_range && (xi - W >= 0 && yi + W + 1 <= n) &&  // scoreUtils.py:75
+              PK_OTHER_EDGES(xi, yi, W, n);
     const int xc = ok ? xi : 0, yc = ok ? yi : 0;
     const int d = yc - xc;
     const int sgn = role ? -1 : 1;
     const int64_t r0 = (int64_t)(xc - W);
 
     // ---- gather: local (i, q) = global (gi, gj), diagonal k = d + gj - gi = d + sgn (q - i)
-    const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
-    const bool normalise = dmax < exp_len;  // utils.py:180-202 (else the window stays raw)
-    const double *__restrict__ src = (CLEAN && normalise) ? norm : band;
     double win[S][H];
 #pragma unroll
     for (int i = 0; i < S; i++) {
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
             const int gi = role ? 2 * W - i : i;
             const int k = d + sgn * (q - i);
             double v = 0.0;
-            if (ok && k >= dlo && k <= dhi) v = src[(int64_t)(k - dlo) * ld + r0 + gi];
+            if (ok && k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + gi];
             win[i][q] = v;
         }
     }
@@ -307,64 +304,32 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 #pragma unroll
         for (int q = 0; q < H; q++) {
             double v = win[i][q];
-            if (!CLEAN) {
-                v = (v != v) ? 0.0 : v;
-                win[i][q] = v;
-            }
+            v = (v != v) ? 0.0 : v;
+            win[i][q] = v;
             const bool mine = (q < W) || (role == 0);
-            nnz += (mine && v != 0.0) ? 1 : 0;  // CLEAN: quotient != 0 <=> count != 0
+            nnz += (mine && v != 0.0) ? 1 : 0;
         }
     }
     nnz += lane_swap_i(nnz);
     ok = ok && !((double)nnz < (double)F * 0.1);
     // ---- utils.py:228-232: top-left w x w mean (numba: sequential C order) = lane A's
-    // local rows / columns 0..w-1, of the RAW counts
+    // local rows / columns 0..w-1
     double acc = 0.0;
-    double centre = win[W][W];  // the centre cell is local (W, W) in both lanes
-    if (CLEAN) {
-        if (normalise) {
-            if (role == 0) {
-                double tl[W][W];
 #pragma unroll
-                for (int i = 0; i < W; i++) {
+    for (int i = 0; i < W; i++) {
 #pragma unroll
-                    for (int q = 0; q < W; q++) {
-                        const int k = d + q - i;
-                        double v = 0.0;
-                        if (ok && k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + i];
-                        tl[i][q] = v;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < W; i++) {
-#pragma unroll
-                    for (int q = 0; q < W; q++) acc += tl[i][q];
-                }
-            }
-            centre = (d >= dlo && d <= dhi) ? band[(int64_t)(d - dlo) * ld + xc] : 0.0;
-        } else {
-#pragma unroll
-            for (int i = 0; i < W; i++) {
-#pragma unroll
-                for (int q = 0; q < W; q++) acc += win[i][q];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < W; i++) {
-#pragma unroll
-            for (int q = 0; q < W; q++) acc += win[i][q];
-        }
+        for (int q = 0; q < W; q++) acc += win[i][q];
     }
     const double acc_partner = lane_swap(acc);
     acc = role ? acc_partner : acc;
     const double ll_mean = acc / (double)(W * W);
     ok = ok && (ll_mean > 0.0);
-    const double p2ll = centre / ll_mean;
+    const double p2ll = win[W][W] / ll_mean;  // the centre cell is local (W, W) in both lanes
     ok = ok && (p2ll > 0.1);
 
     // ---- utils.py:180-202: divide by expected(|col-row|), col-row = d + sgn (q - i)
-    if (!CLEAN && normalise) {
+    const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
+    if (dmax < exp_len) {
         double e[3 * W + 1];  // m = q - i + 2W runs over 0 .. 3W
 #pragma unroll
         for (int m = 0; m <= 3 * W; m++) e[m] = exp_arr[iabs(d + sgn * (m - 2 * W))];
@@ -417,40 +382,26 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
     }
     // ---- utils.py:204-209 image_normalize; numpy min/max propagate NaN
     double mn = win[0][0], mx = win[0][0];
-    if (CLEAN) {
-        // finite, non-negative, bounded inputs: no NaN, no infinity, no -0 after the blur
+    int has_nan = 0;
 #pragma unroll
-        for (int i = 0; i < S; i++) {
+    for (int i = 0; i < S; i++) {
 #pragma unroll
-            for (int q = 0; q < H; q++) {
-                mn = __builtin_fmin(mn, win[i][q]);
-                mx = __builtin_fmax(mx, win[i][q]);
-            }
+        for (int q = 0; q < H; q++) {
+            const double v = win[i][q];
+            has_nan |= (v != v) ? 1 : 0;
+            mn = (v < mn) ? v : mn;
+            mx = (v > mx) ? v : mx;
         }
-        mn = __builtin_fmin(mn, lane_swap(mn));
-        mx = __builtin_fmax(mx, lane_swap(mx));
-    } else {
-        int has_nan = 0;
-#pragma unroll
-        for (int i = 0; i < S; i++) {
-#pragma unroll
-            for (int q = 0; q < H; q++) {
-                const double v = win[i][q];
-                has_nan |= (v != v) ? 1 : 0;
-                mn = (v < mn) ? v : mn;
-                mx = (v > mx) ? v : mx;
-            }
-        }
-        {
-            const double omn = lane_swap(mn), omx = lane_swap(mx);
-            mn = (omn < mn) ? omn : mn;
-            mx = (omx > mx) ? omx : mx;
-            has_nan |= lane_swap_i(has_nan);
-        }
-        if (has_nan) {
-            mn = __builtin_nan("");
-            mx = mn;
-        }
+    }
+    {
+        const double omn = lane_swap(mn), omx = lane_swap(mx);
+        mn = (omn < mn) ? omn : mn;
+        mx = (omx > mx) ? omx : mx;
+        has_nan |= lane_swap_i(has_nan);
+    }
+    if (has_nan) {
+        mn = __builtin_nan("");
+        mx = mn;
     }
     const double den = mx - mn;
     const int64_t tile = local / blk;
@@ -473,6 +424,256 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
     }
     fea_nan |= lane_swap_i(fea_nan);
     if (in_range && role == 0) status[c] = ok ? (fea_nan ? 2 : 1) : 0;
+}
+
+// ------------------------------------------------------------------------
+// Two lanes per candidate, CLEAN matrices (the default scoring kernel).
+//
+// norm_band_kernel (below) has checked on the device that no count is NaN, negative, -0
+// or >= 1e150, that non-zero counts and quotients are >= 1e-100, that every expected
+// value is finite and positive and every quotient finite and < 1e150, and it has stored
+// the quotients count / expected(|col-row|) -- the values distance_normalize computes
+// for every window cell (utils.py:180-202) -- once per band cell, behind the raw band.
+// Under those conditions
+//  * the window is read from the quotient band (same IEEE division, same operands);
+//    only the top-left mean and the centre test (utils.py:228-235) read raw counts;
+//  * NaN -> 0, NaN tracking and the compare-select form of min / max are identities: no
+//    NaN, infinity or -0 can reach them (sums and products of finite non-negative
+//    doubles below 1e150); v_min_f64 / v_max_f64 are used;
+//  * blurred values are 0 or in [1e-108, 1e152], so a = v - min is 0 or >= 1e-124 and
+//    den = max - min is 0 or in [1e-124, 1e152].  For such operands v_div_scale_f64
+//    leaves both unscaled and v_div_fixup_f64 passes the quotient through, i.e. the
+//    IEEE division a / den the compiler emits is exactly
+//        r = rcp(den); r = fma(r, fma(-den, r, 1), r) twice;
+//        m = a * r;  q = fma(fma(-den, m, a), r, m)
+//    (LLVM's f64 fdiv lowering); r depends on den only and is computed once per window
+//    instead of once per feature.  den == 0 (constant window) takes the true division.
+//  * addresses are 32-bit byte offsets from a scalar base (the launcher checks that the
+//    two bands and the tile buffer stay below 4 GiB), one v_mad_i32_i24 per access; a
+//    wave whose windows all lie inside the band (always, for candidates of the band)
+//    gathers without per-cell range tests; lanes without a valid candidate shadow a
+//    valid one of the wave and store nothing.
+// The arithmetic order is unchanged; tests compare this kernel bit for bit with the
+// general one and with the oracle.
+// ------------------------------------------------------------------------
+template <int W, bool FEA64>
+__global__ __launch_bounds__(64, ((W <= 5 && !FEA64) ? PK_EXTRACT_OCC : 1)) void extract_pair_clean_kernel(
+    const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
+    const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
+    float *__restrict__ tiles, int blk, uint8_t *__restrict__ status,
+    double *__restrict__ fea64_rows)
+{
+    constexpr int S = 2 * W + 1;
+    constexpr int F = S * S;
+    constexpr int H = W + 1;
+    static_assert(W >= 4, "the row blur borrows 4 partner columns");
+    const int role = threadIdx.x & 1;
+    const int64_t wave0 = (int64_t)blockIdx.x * 32;
+    const int64_t local = wave0 + (threadIdx.x >> 1);
+    const bool in_range = local < cn;
+    const int64_t c = c0 + (in_range ? local : 0);
+    const int xi = xs[c], yi = ys[c];
+    bool ok = in_range && (xi - W >= 0 && yi + W + 1 <= n) && PK_OTHER_EDGES(xi, yi, W, n);
+    // lanes without a window shadow the first valid candidate of the wave
+    const unsigned long long okmask = __ballot(ok);
+    if (okmask == 0ull) {  // wave-uniform
+        if (in_range && role == 0) status[c] = 0;
+        return;
+    }
+    const int lead = __builtin_ctzll(okmask);
+    const int xc = ok ? xi : __builtin_amdgcn_readlane(xi, lead);
+    const int yc = ok ? yi : __builtin_amdgcn_readlane(yi, lead);
+    const int d = yc - xc;
+    const int sgn = role ? -1 : 1;
+    const bool normalise = max(iabs(d - 2 * W), iabs(d + 2 * W)) < exp_len;
+    const bool inside = (d - 2 * W >= dlo) && (d + 2 * W <= dhi);
+
+    // byte offset of local cell (i, q): row0 + sgn * (i * 8 + (q - i) * ld * 8)
+    const char *bbase = reinterpret_cast<const char *>(band);
+    const int ld8 = ld * 8;
+    const unsigned raw0 = (unsigned)(((int64_t)(d - dlo) * ld + (xc - W) + (role ? 2 * W : 0)) * 8);
+    const unsigned row0 = raw0 + (normalise ? norm_off : 0u);
+    const int sld8 = sgn * ld8, s8 = sgn * 8;
+#define PK_CELL(base_, i_, q_) \
+    (*reinterpret_cast<const double *>(bbase + (unsigned)((base_) + (i_) * s8 + __mul24((q_) - (i_), sld8))))
+    double win[S][H];
+    if (__all(inside)) {
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) win[i][q] = PK_CELL(row0, i, q);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+                const int k = d + sgn * (q - i);
+                double v = 0.0;
+                if (k >= dlo && k <= dhi) v = PK_CELL(row0, i, q);
+                win[i][q] = v;
+            }
+        }
+    }
+    // ---- utils.py:221-225 sparsity filter (quotient != 0 <=> count != 0)
+    int nnz = 0;
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            const bool mine = (q < W) || (role == 0);
+            nnz += (mine && win[i][q] != 0.0) ? 1 : 0;
+        }
+    }
+    nnz += lane_swap_i(nnz);
+    ok = ok && !((double)nnz < (double)F * 0.1);
+    // ---- utils.py:228-235 on the raw counts: top-left w x w mean (lane A's local block,
+    // sequential C order) and the centre cell
+    double acc = 0.0;
+    double centre = win[W][W];
+    if (normalise) {
+        if (role == 0) {
+            double tl[W][W];
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+#pragma unroll
+                for (int q = 0; q < W; q++) {
+                    const int k = d + q - i;
+                    tl[i][q] = (k >= dlo && k <= dhi) ? PK_CELL(raw0, i, q) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+#pragma unroll
+                for (int q = 0; q < W; q++) acc += tl[i][q];
+            }
+        }
+        centre = (d >= dlo && d <= dhi)
+                     ? *reinterpret_cast<const double *>(
+                           bbase + (unsigned)(((int64_t)(d - dlo) * ld + xc) * 8))
+                     : 0.0;
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+#pragma unroll
+            for (int q = 0; q < W; q++) acc += win[i][q];
+        }
+    }
+#undef PK_CELL
+    const double acc_partner = lane_swap(acc);
+    acc = role ? acc_partner : acc;
+    const double ll_mean = acc / (double)(W * W);
+    ok = ok && (ll_mean > 0.0);
+    const double p2ll = centre / ll_mean;
+    ok = ok && (p2ll > 0.1);
+
+    // ---- scipy gaussian_filter(sigma=1), axis 0: down each local column
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+        double col[S];
+#pragma unroll
+        for (int i = 0; i < S; i++) col[i] = win[i][q];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            win[i][q] = PK_BLUR9(col[i], col[reflect_idx(i - 4, S)], col[reflect_idx(i + 4, S)],
+                                 col[reflect_idx(i - 3, S)], col[reflect_idx(i + 3, S)],
+                                 col[reflect_idx(i - 2, S)], col[reflect_idx(i + 2, S)],
+                                 col[reflect_idx(i - 1, S)], col[reflect_idx(i + 1, S)]);
+        }
+    }
+    // ---- axis 1 (see extract_pair_kernel)
+#pragma unroll
+    for (int ip = 0; ip <= W; ip++) {
+        const int ia = ip, ib = S - 1 - ip;
+        double ra[4], rb[4];
+#pragma unroll
+        for (int u = 1; u <= 4; u++) {
+            ra[u - 1] = lane_swap(win[ib][W - u]);
+            rb[u - 1] = lane_swap(win[ia][W - u]);
+        }
+        {
+            double out[H];
+            blur_row<W>(win[ia], ra, out);
+            if (ia != ib) {
+                double outb[H];
+                blur_row<W>(win[ib], rb, outb);
+#pragma unroll
+                for (int q = 0; q < H; q++) win[ib][q] = outb[q];
+            }
+#pragma unroll
+            for (int q = 0; q < H; q++) win[ia][q] = out[q];
+        }
+    }
+    // ---- utils.py:204-209 image_normalize
+    double mn = win[0][0], mx = win[0][0];
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            mn = __builtin_fmin(mn, win[i][q]);
+            mx = __builtin_fmax(mx, win[i][q]);
+        }
+    }
+    mn = __builtin_fmin(mn, lane_swap(mn));
+    mx = __builtin_fmax(mx, lane_swap(mx));
+    const double den = mx - mn;
+    float out32[S][H];
+    const bool flat = !(den > 0.0);  // constant window: 0 / 0
+    if (flat) {
+        const double qn = (mn - mn) / den;  // the true division
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+                out32[i][q] = (float)qn;
+                if (FEA64) win[i][q] = qn;
+            }
+        }
+    } else {
+        double r = __builtin_amdgcn_rcp(den);
+        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+                const double a = win[i][q] - mn;
+                const double m = a * r;
+                const double v = __builtin_fma(__builtin_fma(-den, m, a), r, m);
+                out32[i][q] = (float)v;  // sklearn's float32 cast (RNE)
+                if (FEA64) win[i][q] = v;
+            }
+        }
+    }
+    // ---- stores: tile cell (e, tl) with e = gi * S + gj; B's e is F-1 minus A's
+    if (ok) {
+        const int64_t first = wave0 / blk;  // the 32 candidates of a wave share a tile
+        char *tbase = reinterpret_cast<char *>(tiles + (size_t)first * F * blk);
+        const int tl = (int)(wave0 - first * blk) + (threadIdx.x >> 1);
+        const int t0 = (tl + (role ? (F - 1) * blk : 0)) * 4;
+        const int sblk4 = sgn * blk * 4;
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+                if (q < W || role == 0)  // A stores the shared centre column
+                    *reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24(i * S + q, sblk4))) =
+                        out32[i][q];
+            }
+        }
+        if (FEA64) {
+            double *rp = fea64_rows + (size_t)local * F;
+#pragma unroll
+            for (int i = 0; i < S; i++) {
+#pragma unroll
+                for (int q = 0; q < H; q++) {
+                    const int e = i * S + q;
+                    if (q < W || role == 0) rp[role ? F - 1 - e : e] = win[i][q];
+                }
+            }
+        }
+    }
+    if (in_range && role == 0) status[c] = ok ? (flat ? 2 : 1) : 0;
 }
 
 // ------------------------------------------------------------------------
@@ -505,7 +706,7 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     if (local >= cn) return;  // wave-uniform; no block barriers are used below
     const int64_t c = c0 + local;
     const int xi = xs[c], yi = ys[c];
-    if (!(xi - W >= 0 && yi + W + 1 <= n)) {
+    if (!(xi - W >= 0 && yi + W + 1 <= n && PK_OTHER_EDGES(xi, yi, W, n))) {
         if (lane == 0) status[c] = 0;
         return;
     }
@@ -631,12 +832,14 @@ __global__ void norm_band_kernel(const double *__restrict__ band, double *__rest
     if (raw != raw) bad = 1;                                   // NaN count
     if (__double2hiint(raw) < 0) bad = 1;                      // negative or -0
     if (!(raw < 1e150)) bad = 1;                               // inf / huge
+    if (raw != 0.0 && !(raw >= 1e-100)) bad = 1;               // tiny
     const int ak = iabs(k);
     if (ak < exp_len) {
         const double e = exp_arr[ak];
         if (!(e > 0.0) || !(e < 1e300)) bad = 1;
         q = raw / e;
         if (!(q < 1e150) || ((raw != 0.0) != (q != 0.0))) bad = 1;
+        if (q != 0.0 && !(q >= 1e-100)) bad = 1;
     }
     norm[(int64_t)kk * ld + r] = q;
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
@@ -649,14 +852,9 @@ int pk_matrix_prepare_norm(pk_device_ctx *ctx, pk_matrix *m)
     if (m->norm_tried) return PK_OK;
     m->norm_tried = true;
     m->clean = false;
+    if (!m->norm) return PK_OK;  // pk_matrix_create found the bands too large for 32-bit offsets
     const int ndiag = m->dhi - m->dlo + 1;
-    const size_t bytes = (size_t)ndiag * m->ld * sizeof(double);
     int *d_flags = nullptr;
-    if (hipMalloc((void **)&m->norm, bytes) != hipSuccess) {
-        (void)hipGetLastError();  // no room for the second band: keep the general kernel
-        m->norm = nullptr;
-        return PK_OK;
-    }
     PK_HIP(hipMalloc((void **)&d_flags, sizeof(int)));
     PK_HIP(hipMemsetAsync(d_flags, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(norm_band_kernel, dim3((unsigned)((m->ld + 255) / 256), (unsigned)ndiag),
@@ -673,10 +871,6 @@ int pk_matrix_prepare_norm(pk_device_ctx *ctx, pk_matrix *m)
         return PK_E_HIP;
     }
     m->clean = (h_flags == 0);
-    if (!m->clean) {  // the second band is of no use then
-        hipFree(m->norm);
-        m->norm = nullptr;
-    }
     return PK_OK;
 }
 
@@ -688,19 +882,34 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
     pk_prof_scope prof(ctx, PK_K_EXTRACT, st);
     if ((w == 5 || w == 6) && g_opt.extract_pair) {
         const unsigned grid = (unsigned)((cn + 31) / 32);
-        const bool clean = m->norm != nullptr && m->clean && g_opt.extract_clean != 0;
-#define PK_PAIR(WW, CC)                                                                          \
-    hipLaunchKernelGGL((extract_pair_kernel<WW, CC>), dim3(grid), dim3(64), 0, st, m->band,      \
-                       m->norm, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y,   \
-                       c0, cn, tiles, blk, d_status, fea64_rows)
-        if (w == 5) {
-            if (clean) PK_PAIR(5, true);
-            else PK_PAIR(5, false);
+        const int F = (2 * w + 1) * (2 * w + 1);
+        // the clean kernel addresses the bands and the tile buffer with 32-bit offsets
+        const bool clean = m->norm != nullptr && m->clean && g_opt.extract_clean != 0 &&
+                           ((size_t)((cn + blk - 1) / blk) * blk * F * sizeof(float) < (1ull << 31)) &&
+                           (blk % 32 == 0) && m->ld < (1 << 20);
+        if (clean) {
+            const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
+#define PK_CLEAN(WW, FF)                                                                         \
+    hipLaunchKernelGGL((extract_pair_clean_kernel<WW, FF>), dim3(grid), dim3(64), 0, st, m->band, \
+                       norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,   \
+                       tiles, blk, d_status, fea64_rows)
+            if (w == 5) {
+                if (fea64_rows) PK_CLEAN(5, true);
+                else PK_CLEAN(5, false);
+            } else {
+                if (fea64_rows) PK_CLEAN(6, true);
+                else PK_CLEAN(6, false);
+            }
+#undef PK_CLEAN
+        } else if (w == 5) {
+            hipLaunchKernelGGL(extract_pair_kernel<5>, dim3(grid), dim3(64), 0, st, m->band,
+                               m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0,
+                               cn, tiles, blk, d_status, fea64_rows);
         } else {
-            if (clean) PK_PAIR(6, true);
-            else PK_PAIR(6, false);
+            hipLaunchKernelGGL(extract_pair_kernel<6>, dim3(grid), dim3(64), 0, st, m->band,
+                               m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0,
+                               cn, tiles, blk, d_status, fea64_rows);
         }
-#undef PK_PAIR
     } else if (w == 5 || w == 6) {
         const int threads = 64;
         const unsigned grid = (unsigned)((cn + threads - 1) / threads);
