@@ -198,17 +198,30 @@ def main():
     _lib.check(L.pk_device_synchronize(dev), "sync")
     upload_s = time.perf_counter() - t0
 
+    # the gather of the scored pixels: RCCL (pk_comm_*); if the communicator cannot be
+    # built on every rank, all ranks agree to send the (small) result through the gloo
+    # group instead -- reported as "gather" in the JSON line
     comm = None
-    if world > 1 and not a.rehearse_shared_gpu:
-        ids = [None]
-        if rank == 0:
-            buf = np.zeros(128, np.uint8)
-            _lib.check(L.pk_comm_unique_id(buf), "pk_comm_unique_id")
-            ids = [buf.tobytes()]
-        dist.broadcast_object_list(ids, src=0)
-        comm = L.pk_comm_create(dev, world, rank, np.frombuffer(ids[0], np.uint8).copy())
-        if not comm:
-            raise RuntimeError("pk_comm_create: " + _lib.last_error())
+    gather_mode = "none" if world == 1 else "rccl"
+    if world > 1:
+        import torch
+        if not a.rehearse_shared_gpu:
+            ids = [None]
+            if rank == 0:
+                buf = np.zeros(128, np.uint8)
+                _lib.check(L.pk_comm_unique_id(buf), "pk_comm_unique_id")
+                ids = [buf.tobytes()]
+            dist.broadcast_object_list(ids, src=0)
+            comm = L.pk_comm_create(dev, world, rank, np.frombuffer(ids[0], np.uint8).copy())
+            if not comm:
+                sys.stderr.write("rank %d: pk_comm_create failed: %s\n" % (rank, _lib.last_error()))
+        flag = torch.tensor([1 if comm else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            if comm:
+                L.pk_comm_destroy(comm)
+            comm = None
+            gather_mode = "gloo"
     cap = int(x.size) * world
     counts = np.zeros(world, np.int64)
     if rank == 0 and world > 1:
@@ -225,6 +238,17 @@ def main():
             else:
                 _lib.check(L.pk_comm_gather_scored(comm, cd.h, counts, 0, None, None, None,
                                                    None), "gather")
+        elif gather_mode == "gloo":
+            mine = cd.fetch()
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(mine, parts, dst=0)
+            if rank == 0:
+                o = 0
+                for r, (px, py, pp, ps) in enumerate(parts):
+                    counts[r] = px.size
+                    gx[o:o + px.size] = px; gy[o:o + px.size] = py
+                    gp[o:o + px.size] = pp; gs[o:o + px.size] = ps
+                    o += px.size
         return n_out
 
     def sync():
@@ -322,8 +346,12 @@ def main():
                 "threshold": a.thre,
                 "reference_batch": a.batch,
                 "scored_pixels_rank0": int(n_out),
-                "parallelism": "chromosome-sharded x%d, one RCCL gather%s"
-                               % (world, " (REHEARSAL: shared GPU, no gather)" if a.rehearse_shared_gpu else ""),
+                "parallelism": "chromosome-sharded x%d, one %s gather of the scored pixels%s"
+                               % (world, {"rccl": "RCCL", "gloo": "gloo (RCCL unavailable)",
+                                          "none": "(single rank: no)"}[gather_mode],
+                                  " (REHEARSAL: shared GPU)" if a.rehearse_shared_gpu else ""),
+                "gather": gather_mode,
+                "gathered_pixels": int(counts.sum()) if world > 1 else int(n_out),
             },
             "roofline": {
                 "bound": "hbm",

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 //    gathers without per-cell range tests; lanes without a valid candidate shadow a
 //    valid one of the wave and store nothing.
 // The arithmetic order is unchanged; tests compare this kernel bit for bit with the
-// general one and with the oracle.
+// general one and with the CPU restatement of the reference.
 // ------------------------------------------------------------------------
 template <int W, bool FEA64>
 __global__ __launch_bounds__(64, ((W <= 5 && !FEA64) ? PK_EXTRACT_OCC : 1)) void extract_pair_clean_kernel(
