@@ -55,10 +55,14 @@ class PkMap:
         self.weight_name = str(self._z["weight_name"])
 
     def _raw(self, chrom):
-        z = self._z
-        n = int(z[chrom + "/n"])
-        return sparse.csr_matrix((z[chrom + "/data"], z[chrom + "/indices"],
-                                  z[chrom + "/indptr"]), shape=(n, n))
+        # score_genome fetches a chromosome twice in balanced mode (raw counts for the
+        # Poisson candidates, balanced values for the windows): decompress it once
+        if getattr(self, "_last", (None, None))[0] != chrom:
+            z = self._z
+            n = int(z[chrom + "/n"])
+            self._last = (chrom, sparse.csr_matrix((z[chrom + "/data"], z[chrom + "/indices"],
+                                                    z[chrom + "/indptr"]), shape=(n, n)))
+        return self._last[1]
 
     def _weights(self, chrom):
         key = chrom + "/weights"
