@@ -1,11 +1,12 @@
-"""Command line of the MI355X scoring path: the `score_chromosome` and
-`score_genome` sub-commands of `scripts/peakachu` (scripts/peakachu:5-93)
-with the same flags and defaults.  The reference's other sub-commands
-(train, depth, pool) are outside this build's scope."""
+"""Command line of the MI355X scoring path: the `score_chromosome`,
+`score_genome` and `pool` sub-commands of `scripts/peakachu`
+(scripts/peakachu:5-93) with the same flags and defaults.  `pool` is host-only
+(the reference runs it on the CPU as well).  The reference's other sub-commands
+(train, depth) are outside this build's scope."""
 import argparse
 import sys
 
-from . import score_chromosome, score_genome
+from . import call_loops, score_chromosome, score_genome
 
 
 def getargs(argv=None):
@@ -18,9 +19,13 @@ def getargs(argv=None):
     subgen = subparsers.add_parser('score_genome',
                                    help='''Calculate interaction probability per pixel for the whole genome''')
     subgen.set_defaults(func=score_genome.main)
-    for i in (subchrom, subgen):
+    subpool = subparsers.add_parser('pool',
+                                    help='Print centroid loci from score_genome/score_chromosome output')
+    subpool.set_defaults(func=call_loops.main)
+    for i in (subchrom, subgen, subpool):
         i.add_argument('-r', '--resolution', help='Resolution in bp (default 10000)',
                        type=int, default=10000)
+    for i in (subchrom, subgen):
         i.add_argument('-p', '--path', help='Path to a .cool URI string (or a .pkmap.npz container)')
         i.add_argument('--clr-weight-name', default='weight',
                        help='''The name of the weight column in your Cooler URI for normalizing
@@ -42,8 +47,13 @@ def getargs(argv=None):
         i.add_argument('--minimum-prob', type=float, default=0.5,
                        help='''Only output pixels with probability score greater than this value (default 0.5)''')
         i.add_argument('-O', '--output', help='Output file name.')
+    subpool.add_argument('-i', '--infile',
+                         help='Path to the bedpe file outputted from score_chromosome or score_genome')
+    subpool.add_argument('-o', '--outfile', help='Output file name.')
+    subpool.add_argument('-t', '--threshold', type=float, default=0.9,
+                         help='Probability threshold applied before peak calling (default 0.9)')
     commands = sys.argv[1:] if argv is None else list(argv)
-    if ((not commands) or ((commands[0] in ['score_chromosome', 'score_genome'])
+    if ((not commands) or ((commands[0] in ['score_chromosome', 'score_genome', 'pool'])
                            and len(commands) == 1)):
         commands.append('-h')
     args = parser.parse_args(commands)

@@ -477,11 +477,87 @@ def g6_driver(forests):
     del sys.modules["cooler"]
 
 
+def pool_input(seed, n_chrom=3, res=10000):
+    """A scored-pixel bedpe as score_genome writes it: blobs of pixels around planted
+    loops (probabilities 0.5..1, decaying away from the summit), stripes (many pixels on
+    one row / column, which is what find_anchors looks for), isolated pixels, and ties."""
+    rng = np.random.default_rng(seed)
+    lines = []
+    for c in range(n_chrom):
+        chrom = "chr%d" % (c + 1) if c < n_chrom - 1 else "chrX"
+        pix = {}
+        n = 2500
+        for _ in range(40):                       # blobs
+            a = int(rng.integers(20, n - 300)); d = int(rng.integers(8, 250))
+            rad = int(rng.integers(1, 5)); peak = rng.uniform(0.75, 1.0)
+            sig = rng.uniform(5, 60)
+            for di in range(-rad, rad + 1):
+                for dj in range(-rad, rad + 1):
+                    if rng.random() < 0.75 - 0.08 * (abs(di) + abs(dj)):
+                        pr = peak - 0.05 * (abs(di) + abs(dj)) - rng.uniform(0, 0.05)
+                        if pr > 0.5:
+                            pix[(a + di, a + d + dj)] = (pr, sig * (1 - 0.1 * (abs(di) + abs(dj))))
+        for _ in range(6):                        # stripes along a row or a column
+            a = int(rng.integers(20, n - 300)); horiz = rng.random() < 0.5
+            for k in range(int(rng.integers(6, 25))):
+                o = a + 8 + 2 * k + int(rng.integers(0, 2))
+                key = (a, o) if horiz else (o - 200 if o - 200 > 0 else o, a + 300)
+                if key[0] < key[1]:
+                    pix[key] = (rng.uniform(0.55, 1.0), rng.uniform(3, 40))
+        for _ in range(120):                      # isolated pixels
+            a = int(rng.integers(20, n - 300)); d = int(rng.integers(8, 250))
+            pix[(a, a + d)] = (rng.uniform(0.5, 1.0), float(rng.integers(2, 30)))
+        keys = sorted(pix)
+        for k in keys[::17]:                      # exact ties in value
+            pix[k] = (pix[k][0], 12.0)
+        for (i, j) in keys:
+            pr, sg = pix[(i, j)]
+            lines.append("\t".join([chrom, str(i * res), str(i * res + res), chrom, str(j * res),
+                                    str(j * res + res), str(np.float64(pr)), str(np.float64(sg))]))
+    return "\n".join(lines) + "\n"
+
+
+def g7_pool():
+    """`peakachu pool` (peakachu/call_loops.py:3-26, peakachu/peakacluster.py:7-172):
+    the reference's own main() on synthetic scored-pixel files."""
+    import argparse
+    from peakachu import call_loops, peakacluster
+    tmp = tempfile.mkdtemp()
+    out = {}
+    for seed, res in ((1, 10000), (2, 5000)):
+        text = pool_input(seed, res=res)
+        fin = os.path.join(tmp, "in%d.bedpe" % seed)
+        open(fin, "w").write(text)
+        out["in%d" % seed] = np.frombuffer(text.encode(), np.uint8)
+        out["res%d" % seed] = np.int64(res)
+        for thre in (0.9, 0.5, 0.97):
+            fo = os.path.join(tmp, "out.bedpe")
+            call_loops.main(argparse.Namespace(resolution=res, infile=fin, outfile=fo, threshold=thre))
+            got = open(fo).read()
+            out["out%d_t%g" % (seed, thre)] = np.frombuffer(got.encode(), np.uint8)
+            print("g7 seed %d thre %g: %d -> %d lines" % (seed, thre, text.count("\n"), got.count("\n")))
+        # function level: the representatives local_clustering returns for one chromosome
+        D = {}
+        for line in text.splitlines():
+            q = line.split()
+            if q[0] == "chr1" and float(q[6]) >= 0.5:
+                D[(int(q[1]) // res, int(q[4]) // res)] = float(q[7])
+        reps = sorted(set(t[0] for t in peakacluster.local_clustering(D, min_count=3, r=2)))
+        out["reps%d" % seed] = np.array(reps, np.int64)
+        xa = sorted(peakacluster.find_anchors(np.r_[[k[0] for k in D]], min_count=3, min_dis=2))
+        out["xanchors%d" % seed] = np.array(xa, np.int64)
+    save("g7_pool.npz", seeds=np.array([1, 2]), **out)
+
+
 def main():
     """`make_golden.py` regenerates everything; `make_golden.py g6` only the
     named groups (g2 is always run: the later groups need its forest)."""
     os.makedirs(OUT, exist_ok=True)
-    want = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6"}
+    want = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7"}
+    if "g7" in want:
+        g7_pool()
+        if want == {"g7"}:
+            return
     if "g1" in want:
         g1_extract()
     global save
