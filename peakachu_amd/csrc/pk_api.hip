@@ -24,6 +24,7 @@ void pk_set_error(const char *fmt, ...)
 }
 
 pk_options g_opt;
+int64_t g_stat_extract_clean = 0, g_stat_extract_general = 0;
 static std::mutex g_mu;
 // One coarse lock for every entry point that touches a device: the library keeps
 // per-device scratch, cached launch tables inside handles and profiling lists, so
@@ -239,6 +240,8 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
     if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
     if (!strcmp(name, "extract_clean")) return g_opt.extract_clean;
+    if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
+    if (!strcmp(name, "stat_extract_general")) return g_stat_extract_general;
     if (!strcmp(name, "overlap")) return g_opt.overlap;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
     if (!strcmp(name, "forest_l2_tile")) return g_opt.forest_l2_tile;

@@ -70,6 +70,9 @@ struct pk_options {
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
 };
 extern pk_options g_opt;
+// launches of the two-lane extractor since load, by kernel (read-only options
+// "stat_extract_clean" / "stat_extract_general": lets tests see which one ran)
+extern int64_t g_stat_extract_clean, g_stat_extract_general;
 
 // ---------------------------------------------------------------- profiling
 // Brackets a kernel launch with HIP events on the library's stream when

@@ -887,6 +887,7 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
         const bool clean = m->norm != nullptr && m->clean && g_opt.extract_clean != 0 &&
                            ((size_t)((cn + blk - 1) / blk) * blk * F * sizeof(float) < (1ull << 31)) &&
                            (blk % 32 == 0) && m->ld < (1 << 20);
+        (clean ? g_stat_extract_clean : g_stat_extract_general)++;
         if (clean) {
             const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
 #define PK_CLEAN(WW, FF)                                                                         \

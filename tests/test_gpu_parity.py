@@ -38,6 +38,8 @@ def test_extract_golden(hip_lib, name, pair):
 
 def _extract_golden(name):
     z = gio.load(name)
+    L = _lib.load()
+    clean0 = L.pk_get_option(b"stat_extract_clean")
     w, upper = int(z["w"]), int(z["upper"])
     if "weights" in z.files:
         M = gio.balance(gio.sym_matrix(z, "R"), z["weights"])
@@ -52,6 +54,9 @@ def _extract_golden(name):
     assert np.array_equal(np.stack([x[keep], y[keep]], 1), z["clist"])
     assert np.array_equal(gio.bits(f64), gio.bits(z["fea"]))
     assert np.array_equal(f32, z["fea"].astype(np.float32))
+    if int(z["w"]) in (5, 6) and L.pk_get_option(b"extract_pair") and "balanced" in name:
+        # balanced (float, ~1e-3) values still qualify for the pre-divided band
+        assert L.pk_get_option(b"stat_extract_clean") > clean0
 
 
 @pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
@@ -570,14 +575,22 @@ def test_clean_extractor_and_its_fallback(hip_lib, w, poison):
     elif poison == "exp_tiny":
         e[7] = 1e-200
     got = {}
+    L = _lib.load()
     for clean in (1, 0):
         _lib.set_option("extract_clean", clean)
+        before = (L.pk_get_option(b"stat_extract_clean"), L.pk_get_option(b"stat_extract_general"))
         try:
             hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e, -2 * w + 1,
                                 upper + 2 * w - 1)
             got[clean] = hm.extract(w, x, y)
         finally:
             _lib.set_option("extract_clean", 1)
+        ran_clean = L.pk_get_option(b"stat_extract_clean") > before[0]
+        ran_general = L.pk_get_option(b"stat_extract_general") > before[1]
+        # the clean kernel runs exactly when it is allowed and the matrix is unpoisoned
+        # ("exp_tiny" = 1e-200 is a legal expected value but makes the quotients huge)
+        assert ran_clean == (clean == 1 and poison == "none"), (poison, clean)
+        assert ran_general == (not ran_clean)
     with np.errstate(all="ignore"):
         fea, keep_ref = onp.extract(Mc, e, w, x, y)
     # NaN features (a NaN expected value poisons every window that touches its diagonal):
