@@ -468,7 +468,13 @@ __global__ __launch_bounds__(64, ((W <= 5 && !FEA64) ? PK_EXTRACT_OCC : 1)) void
     constexpr int H = W + 1;
     static_assert(W >= 4, "the row blur borrows 4 partner columns");
     const int role = threadIdx.x & 1;
-    const int64_t wave0 = (int64_t)blockIdx.x * 32;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD
+    // has its own L2.  Consecutive candidates share band rows, so XCD x takes the x-th
+    // contiguous eighth of the chunk instead of every eighth block (the grid is a
+    // multiple of 8): the band lines a window needs are then fetched into one L2, not
+    // into all eight.
+    const unsigned per_xcd = gridDim.x >> 3;
+    const int64_t wave0 = (int64_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * 32;
     const int64_t local = wave0 + (threadIdx.x >> 1);
     const bool in_range = local < cn;
     const int64_t c = c0 + (in_range ? local : 0);
@@ -891,7 +897,7 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
         if (clean) {
             const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
 #define PK_CLEAN(WW, FF)                                                                         \
-    hipLaunchKernelGGL((extract_pair_clean_kernel<WW, FF>), dim3(grid), dim3(64), 0, st, m->band, \
+    hipLaunchKernelGGL((extract_pair_clean_kernel<WW, FF>), dim3((grid + 7u) & ~7u), dim3(64), 0, st, m->band, \
                        norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,   \
                        tiles, blk, d_status, fea64_rows)
             if (w == 5) {
