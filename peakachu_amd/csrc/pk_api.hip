@@ -205,6 +205,9 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_lds = value;
     } else if (!strcmp(name, "overlap")) {
         g_opt.overlap = value != 0;
+    } else if (!strcmp(name, "forest_warm")) {
+        if (value < 0) return PK_E_INVALID;
+        g_opt.forest_warm = value;
     } else if (!strcmp(name, "extract_clean")) {
         g_opt.extract_clean = value != 0;
     } else if (!strcmp(name, "extract_pair")) {
@@ -240,6 +243,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
     if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
     if (!strcmp(name, "extract_clean")) return g_opt.extract_clean;
+    if (!strcmp(name, "forest_warm")) return g_opt.forest_warm;
     if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
     if (!strcmp(name, "stat_extract_general")) return g_stat_extract_general;
     if (!strcmp(name, "overlap")) return g_opt.overlap;

@@ -62,6 +62,8 @@ struct pk_options {
                                 // the forest slows by what the extractor saves -- both are VALU-issue bound)
     int64_t extract_clean = 1;  // use the pre-divided band + shortcuts when the matrix qualifies
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
+    int64_t forest_warm = 1;    // last tree group: pull the tile of workgroup id + N into this XCD's L2
+                                // (0 = off, 1 = N = number of CUs: the workgroup that follows on this XCD)
     int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
     int64_t forest_pipe_slots = 0;  // 0 = as many as fit (max 8)
     int64_t forest_l2_tile = 0; // large F: 1 = keep the LDS feature tile (one wave per CU), 0 = no-LDS kernel

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
     const int32_t *__restrict__ big_roff, const int32_t *__restrict__ grp, int n_grp, int T, int F,
     const float *__restrict__ tiles, const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
     double *__restrict__ prob, int tree_words, int dbg, long long *__restrict__ stamps,
-    double prune_sum)
+    double prune_sum, int warm_ahead)
 {
     constexpr int THREADS = LDS_C * SLOTS;
     // 6 x uint4 registers per thread hold the prefetched group (the launcher keeps
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
             stamps[((tid >> 6) * 32 + g) * 5 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
     double acc = 0.0;
+    float warm_sink = 0.f;
     const char *fea_b = reinterpret_cast<const char *>(fea);
     const int cl4 = cl << 2;
     for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
@@ -370,6 +371,16 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
             pf_src = reinterpret_cast<const uint4 *>(nodes + root[tn]);
             pf_nv = (root[tn1] - root[tn]) >> 1;
             PK_PF6(PK_PF_LOAD)
+        } else if (g + 1 == n_grp && warm_ahead > 0) {
+            // last group: pull the tile of the workgroup that will follow this one on this
+            // XCD (ids are dealt round-robin over the 8 XCDs, each with its own L2) into
+            // the L2, one dword per 128-byte line; the result is never used
+            const int64_t ahead = tile + warm_ahead;
+            const int line = tid;
+            // (an ordinary load with a use the compiler cannot remove: an asm load whose
+            // result register the compiler thinks is free gets overwritten late)
+            if (ahead * LDS_C < cn && line < F * LDS_C / 32)
+                warm_sink = tiles[(size_t)ahead * F * LDS_C + (size_t)line * 32];
         }
         // early termination: a candidate whose sum can no longer reach thre*T is not
         // walked any more (its flag was set by slot 0 before the last barrier)
@@ -416,6 +427,8 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
         if (all_done) break;
     }
     if (slot == 0 && valid) prob[c] = active ? acc / (double)T : 0.0;
+    // keeps the warm-ahead load alive (features are never -inf ... practically never taken)
+    if (warm_sink == -__builtin_inff() && stamps) stamps[65534] = 1;
 #undef PK_STAMP
 }
 
@@ -665,7 +678,8 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
         hipLaunchKernelGGL((forest_lds_kernel<SLOTS, PRUNE>), dim3(grid), dim3(LDS_C *(SLOTS)), \
                            lds, ctx->stream, f->nodes, f->root, f->big_roff, f->grp, f->n_grp, \
                            f->T, f->F, tiles, d_status, c0, cn, d_prob, tree_words,           \
-                           (int)g_opt.forest_dbg, ctx->dbg_buf, prune_sum);                   \
+                           (int)g_opt.forest_dbg, ctx->dbg_buf, prune_sum,                    \
+                           g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm);  \
     } while (0)
 #define PK_LAUNCH_LDS(SLOTS)                                                                  \
     do {                                                                                      \
