@@ -838,7 +838,8 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
     if (chunk > cd->N) chunk = (cd->N + blk - 1) / blk * blk;
     const size_t tile_floats = (size_t)chunk * F;
-    int rc = pk_ctx_reserve_tiles(ctx, 2 * tile_floats * sizeof(float));
+    const bool overlap = g_opt.overlap != 0;
+    int rc = pk_ctx_reserve_tiles(ctx, (overlap ? 2 : 1) * tile_floats * sizeof(float));
     if (rc) return rc;
     if ((w == 5 || w == 6) && g_opt.extract_pair && g_opt.extract_clean) {
         rc = pk_matrix_prepare_norm(ctx, m);
@@ -848,7 +849,6 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     // The forest kernel is LDS / latency bound and leaves ~40 % of the VALU issue slots
     // and (at <= 72 VGPRs) room for one 216-register extractor wave per SIMD, which is
     // FP64-VALU bound: the two kernels are complementary on a CU.
-    const bool overlap = g_opt.overlap != 0;
     hipStream_t st_ext = overlap ? ctx->stream2 : ctx->stream;
     if (overlap) {
         // whatever precedes on the main stream (uploads) must be visible to the extractor
@@ -858,7 +858,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     int64_t k = 0;
     for (int64_t c0 = 0; c0 < cd->N; c0 += chunk, k++) {
         const int64_t cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
-        const int buf = (int)(k & 1);
+        const int buf = overlap ? (int)(k & 1) : 0;
         float *tiles = ctx->fea_tiles + (size_t)buf * tile_floats;
         if (overlap && k >= 2)  // forest(k-2) must be done with this buffer
             PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[buf], 0));
