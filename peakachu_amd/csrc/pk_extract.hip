@@ -697,13 +697,19 @@ __device__ __forceinline__ int reflect1(int q, int n)
     return q;
 }
 
+// WT > 0: the half-width is a compile-time constant (w = 11, the 23 x 23 stress
+// configuration): every loop unrolls, so the 12 gather loads of a lane are all in flight
+// together and the 121 LDS reads of the sequential top-left sum are issued back to back
+// instead of one round trip each (measured at w = 11: 6.9 -> see DESIGN.md).  WT = 0: any w.
+template <int WT>
 __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
-    int W, const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
+    int Wrt, const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
     const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
     const int32_t *__restrict__ ys, int64_t c0, int64_t cn, float *__restrict__ tiles, int blk,
     uint8_t *__restrict__ status, double *__restrict__ fea64_rows)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int W = WT > 0 ? WT : Wrt;
     const int S = 2 * W + 1, F = S * S;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *A = smem + (size_t)wave * 2 * F;
@@ -726,6 +732,7 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     const bool jok = j < S;
 
     int nnz = 0;
+#pragma unroll
     for (int it = 0; it < steps; it++) {
         const int i = 2 * it + ihalf;
         if (jok && i < S) {
@@ -744,8 +751,11 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     bool ok = !((double)nnz < (double)F * 0.1);
     // sequential top-left sum, every lane computes the same value from LDS
     double acc = 0.0;
-    for (int i = 0; i < W; i++)
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+#pragma unroll
         for (int q = 0; q < W; q++) acc += A[i * S + q];
+    }
     const double ll_mean = acc / (double)(W * W);
     ok = ok && (ll_mean > 0.0);
     const double p2ll = A[W * S + W] / ll_mean;
@@ -756,13 +766,15 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     }
     const int dmax = max(iabs(d - 2 * W), iabs(d + 2 * W));
     if (dmax < exp_len) {
-        for (int it = 0; it < steps; it++) {
+    #pragma unroll
+    for (int it = 0; it < steps; it++) {
             const int i = 2 * it + ihalf;
             if (jok && i < S) A[i * S + j] = A[i * S + j] / exp_arr[iabs(d + j - i)];
         }
     }
     __builtin_amdgcn_wave_barrier();
     // axis 0: A -> B
+#pragma unroll
     for (int it = 0; it < steps; it++) {
         const int i = 2 * it + ihalf;
         if (jok && i < S) {
@@ -776,6 +788,7 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     // axis 1: B -> A
     double mn = __builtin_inf(), mx = -__builtin_inf();
     int has_nan = 0;
+#pragma unroll
     for (int it = 0; it < steps; it++) {
         const int i = 2 * it + ihalf;
         if (jok && i < S) {
@@ -805,6 +818,7 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     const int tl = (int)(local - tile * blk);
     float *tp = tiles + (size_t)tile * F * blk + tl;
     bool fea_nan = false;
+#pragma unroll
     for (int it = 0; it < steps; it++) {
         const int i = 2 * it + ihalf;
         if (jok && i < S) {
@@ -936,9 +950,14 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
         const int F = (2 * w + 1) * (2 * w + 1);
         const size_t lds = (size_t)GEN_WAVES * 2 * F * sizeof(double);
         const unsigned grid = (unsigned)((cn + GEN_WAVES - 1) / GEN_WAVES);
-        hipLaunchKernelGGL(extract_lds_kernel, dim3(grid), dim3(64 * GEN_WAVES), lds, st,
-                           w, m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
-                           d_y, c0, cn, tiles, blk, d_status, fea64_rows);
+        if (w == 11)
+            hipLaunchKernelGGL(extract_lds_kernel<11>, dim3(grid), dim3(64 * GEN_WAVES), lds, st,
+                               w, m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
+                               d_y, c0, cn, tiles, blk, d_status, fea64_rows);
+        else
+            hipLaunchKernelGGL(extract_lds_kernel<0>, dim3(grid), dim3(64 * GEN_WAVES), lds, st,
+                               w, m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x,
+                               d_y, c0, cn, tiles, blk, d_status, fea64_rows);
     }
     PK_HIP(hipGetLastError());
     return PK_OK;
