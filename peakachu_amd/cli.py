@@ -1,70 +1,73 @@
-"""Command line of the MI355X scoring path: the `score_chromosome`,
-`score_genome` and `pool` sub-commands of `scripts/peakachu`
-(scripts/peakachu:5-93) with the same flags and defaults.  `pool` is host-only
-(the reference runs it on the CPU as well).  The reference's other sub-commands
-(train, depth) are outside this build's scope."""
+"""Command line of the MI355X scoring path.
+
+Sub-commands, flags and defaults are those of the reference's launcher
+(scripts/peakachu:5-93) for `score_chromosome`, `score_genome` and `pool`, so existing
+command lines keep working; help texts are this build's own.  `pool` is host-only (the
+reference runs it on the CPU as well).  `train` and `depth` are outside this build.
+"""
 import argparse
 import sys
 
 from . import call_loops, score_chromosome, score_genome
 
+# (flags, keyword arguments) per option group; a group is attached to the listed commands
+_COMMON_SCORING = [
+    (("-p", "--path"), dict(help="contact map: a cooler URI (needs `cooler`) or a .pkmap.npz container")),
+    (("--clr-weight-name",), dict(default="weight",
+                                  help="bin-weight column used for balancing; 'raw' scores the raw counts")),
+    (("-m", "--model"), dict(type=str, help="model: pickled sklearn forest or flat-forest .npz")),
+    (("-l", "--lower"), dict(type=int, default=6, help="smallest bin distance scored")),
+    (("-u", "--upper"), dict(type=int, default=300, help="largest bin distance scored")),
+    (("--minimum-prob",), dict(type=float, default=0.5,
+                               help="report pixels whose probability exceeds this value")),
+    (("-O", "--output"), dict(help="bedpe file to write")),
+]
+_RESOLUTION = (("-r", "--resolution"), dict(type=int, default=10000, help="bin size in bp"))
+
+
+def _build_parser():
+    parser = argparse.ArgumentParser(
+        prog="peakachu-amd", description="Peakachu scoring on MI355X (HIP); loop calling on the host.",
+        formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    sub = parser.add_subparsers(dest="subcommands")
+    commands = {
+        "score_chromosome": (score_chromosome.main, "score the candidate pixels of one chromosome"),
+        "score_genome": (score_genome.main, "score every selected chromosome of a contact map"),
+        "pool": (call_loops.main, "cluster scored pixels into loop calls"),
+    }
+    parsers = {}
+    for name, (func, text) in commands.items():
+        parsers[name] = sub.add_parser(name, help=text)
+        parsers[name].set_defaults(func=func)
+        parsers[name].add_argument(*_RESOLUTION[0], **_RESOLUTION[1])
+    for name in ("score_chromosome", "score_genome"):
+        for flags, kw in _COMMON_SCORING:
+            parsers[name].add_argument(*flags, **kw)
+    parsers["score_chromosome"].add_argument("-C", "--chrom", help="label of the chromosome to score")
+    parsers["score_genome"].add_argument(
+        "-C", "--chroms", nargs="*", default=["#", "X"],
+        help="chromosomes to score; '#' selects all numbered ones, no value selects everything")
+    parsers["pool"].add_argument("-i", "--infile", help="bedpe written by score_chromosome / score_genome")
+    parsers["pool"].add_argument("-o", "--outfile", help="bedpe of loop calls to write")
+    parsers["pool"].add_argument("-t", "--threshold", type=float, default=0.9,
+                                 help="pixels below this probability are ignored")
+    return parser, tuple(commands)
+
 
 def getargs(argv=None):
-    parser = argparse.ArgumentParser(description='''Unveil Hi-C Anchors and Peaks (MI355X scoring path).''',
-                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    subparsers = parser.add_subparsers(dest='subcommands')
-    subchrom = subparsers.add_parser('score_chromosome',
-                                     help='''Calculate interaction probability per pixel for a chromosome''')
-    subchrom.set_defaults(func=score_chromosome.main)
-    subgen = subparsers.add_parser('score_genome',
-                                   help='''Calculate interaction probability per pixel for the whole genome''')
-    subgen.set_defaults(func=score_genome.main)
-    subpool = subparsers.add_parser('pool',
-                                    help='Print centroid loci from score_genome/score_chromosome output')
-    subpool.set_defaults(func=call_loops.main)
-    for i in (subchrom, subgen, subpool):
-        i.add_argument('-r', '--resolution', help='Resolution in bp (default 10000)',
-                       type=int, default=10000)
-    for i in (subchrom, subgen):
-        i.add_argument('-p', '--path', help='Path to a .cool URI string (or a .pkmap.npz container)')
-        i.add_argument('--clr-weight-name', default='weight',
-                       help='''The name of the weight column in your Cooler URI for normalizing
-                       the contact signals. Specify it to "raw" if you want to use the raw signals.''')
-    subchrom.add_argument('-C', '--chrom', help='''Chromosome label. Only contact data within the
-                          specified chromosome will be considered.''')
-    subgen.add_argument('-C', '--chroms', nargs='*', default=['#', 'X'],
-                        help='List of chromosome labels. Only contact data within the specified '
-                        'chromosomes will be included. Specially, "#" stands for chromosomes '
-                        'with numerical labels. "--chroms" with zero argument will include '
-                        'all chromosome data. (default "#" X)')
-    for i in (subchrom, subgen):
-        i.add_argument('-m', '--model', type=str,
-                       help='''Path to pickled model file (or a flat-forest .npz).''')
-        i.add_argument('-l', '--lower', type=int, default=6,
-                       help='''Lower bound of distance between loci in bins (default 6).''')
-        i.add_argument('-u', '--upper', type=int, default=300,
-                       help='''Upper bound of distance between loci in bins (default 300).''')
-        i.add_argument('--minimum-prob', type=float, default=0.5,
-                       help='''Only output pixels with probability score greater than this value (default 0.5)''')
-        i.add_argument('-O', '--output', help='Output file name.')
-    subpool.add_argument('-i', '--infile',
-                         help='Path to the bedpe file outputted from score_chromosome or score_genome')
-    subpool.add_argument('-o', '--outfile', help='Output file name.')
-    subpool.add_argument('-t', '--threshold', type=float, default=0.9,
-                         help='Probability threshold applied before peak calling (default 0.9)')
+    parser, names = _build_parser()
     commands = sys.argv[1:] if argv is None else list(argv)
-    if ((not commands) or ((commands[0] in ['score_chromosome', 'score_genome', 'pool'])
-                           and len(commands) == 1)):
-        commands.append('-h')
-    args = parser.parse_args(commands)
-    return args, commands
+    # like the reference: nothing, or a bare sub-command, prints help
+    if not commands or (len(commands) == 1 and commands[0] in names):
+        commands.append("-h")
+    return parser.parse_args(commands), commands
 
 
 def run(argv=None):
     args, commands = getargs(argv)
-    if commands[0] not in ['-h', '--help']:
+    if commands[0] not in ("-h", "--help"):
         args.func(args)
 
 
-if __name__ == '__main__':
+if __name__ == "__main__":
     run()
