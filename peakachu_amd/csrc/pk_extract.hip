@@ -452,12 +452,13 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 //    two bands and the tile buffer stay below 4 GiB), one v_mad_i32_i24 per access; a
 //    wave whose windows all lie inside the band (always, for candidates of the band)
 //    gathers without per-cell range tests; lanes without a valid candidate shadow a
-//    valid one of the wave and store nothing.
+//    valid one of the wave and store nothing.  w = 6 is compiled for two waves per SIMD
+//    like w = 5 (14 registers go to scratch: faster than one wave without spills).
 // The arithmetic order is unchanged; tests compare this kernel bit for bit with the
 // general one and with the CPU restatement of the reference.
 // ------------------------------------------------------------------------
 template <int W, bool FEA64>
-__global__ __launch_bounds__(64, ((W <= 5 && !FEA64) ? PK_EXTRACT_OCC : 1)) void extract_pair_clean_kernel(
+__global__ __launch_bounds__(64, (!FEA64 ? PK_EXTRACT_OCC : 1)) void extract_pair_clean_kernel(
     const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
     const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
     float *__restrict__ tiles, int blk, uint8_t *__restrict__ status,
@@ -623,17 +624,31 @@ __global__ __launch_bounds__(64, ((W <= 5 && !FEA64) ? PK_EXTRACT_OCC : 1)) void
     mn = __builtin_fmin(mn, lane_swap(mn));
     mx = __builtin_fmax(mx, lane_swap(mx));
     const double den = mx - mn;
-    float out32[S][H];
     const bool flat = !(den > 0.0);  // constant window: 0 / 0
+    // tile cell (e, tl) with e = gi * S + gj; B's e is F-1 minus A's.  Every feature is
+    // stored as soon as it is computed (its window register dies with it: keeping the
+    // floats for a grouped store cost 20 registers, the difference between one and two
+    // waves per SIMD at w = 6); A stores the shared centre column.
+    const int64_t first = wave0 / blk;  // the 32 candidates of a wave share a tile
+    char *tbase = reinterpret_cast<char *>(tiles + (size_t)first * F * blk);
+    const int tl = (int)(wave0 - first * blk) + (threadIdx.x >> 1);
+    const int t0 = (tl + (role ? (F - 1) * blk : 0)) * 4;
+    const int sblk4 = sgn * blk * 4;
+    double *rp = FEA64 ? fea64_rows + (size_t)local * F : nullptr;
+#define PK_PUT(i_, q_, v_)                                                                      \
+    do {                                                                                        \
+        if (ok && ((q_) < W || role == 0)) {                                                    \
+            *reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24((i_) * S + (q_), sblk4))) = \
+                (float)(v_); /* sklearn's float32 cast (RNE) */                                 \
+            if (FEA64) rp[role ? F - 1 - ((i_) * S + (q_)) : (i_) * S + (q_)] = (v_);           \
+        }                                                                                       \
+    } while (0)
     if (flat) {
         const double qn = (mn - mn) / den;  // the true division
 #pragma unroll
         for (int i = 0; i < S; i++) {
 #pragma unroll
-            for (int q = 0; q < H; q++) {
-                out32[i][q] = (float)qn;
-                if (FEA64) win[i][q] = qn;
-            }
+            for (int q = 0; q < H; q++) PK_PUT(i, q, qn);
         }
     } else {
         double r = __builtin_amdgcn_rcp(den);
@@ -646,39 +661,11 @@ __global__ __launch_bounds__(64, ((W <= 5 && !FEA64) ? PK_EXTRACT_OCC : 1)) void
                 const double a = win[i][q] - mn;
                 const double m = a * r;
                 const double v = __builtin_fma(__builtin_fma(-den, m, a), r, m);
-                out32[i][q] = (float)v;  // sklearn's float32 cast (RNE)
-                if (FEA64) win[i][q] = v;
+                PK_PUT(i, q, v);
             }
         }
     }
-    // ---- stores: tile cell (e, tl) with e = gi * S + gj; B's e is F-1 minus A's
-    if (ok) {
-        const int64_t first = wave0 / blk;  // the 32 candidates of a wave share a tile
-        char *tbase = reinterpret_cast<char *>(tiles + (size_t)first * F * blk);
-        const int tl = (int)(wave0 - first * blk) + (threadIdx.x >> 1);
-        const int t0 = (tl + (role ? (F - 1) * blk : 0)) * 4;
-        const int sblk4 = sgn * blk * 4;
-#pragma unroll
-        for (int i = 0; i < S; i++) {
-#pragma unroll
-            for (int q = 0; q < H; q++) {
-                if (q < W || role == 0)  // A stores the shared centre column
-                    *reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24(i * S + q, sblk4))) =
-                        out32[i][q];
-            }
-        }
-        if (FEA64) {
-            double *rp = fea64_rows + (size_t)local * F;
-#pragma unroll
-            for (int i = 0; i < S; i++) {
-#pragma unroll
-                for (int q = 0; q < H; q++) {
-                    const int e = i * S + q;
-                    if (q < W || role == 0) rp[role ? F - 1 - e : e] = win[i][q];
-                }
-            }
-        }
-    }
+#undef PK_PUT
     if (in_range && role == 0) status[c] = ok ? (flat ? 2 : 1) : 0;
 }
 
