@@ -29,6 +29,9 @@
 // filtered here, so no kernel ever reads outside the band.
 #define PK_OTHER_EDGES(xi, yi, W, n) ((xi) + (W) < (n) && (yi) - (W) >= 0)
 
+#ifndef PK_CLEAN_OCC5
+#define PK_CLEAN_OCC5 2  // waves per SIMD of the clean two-lane extractor at w = 5 (3 spills 30 registers: 1.81 vs 1.20 ms)
+#endif
 #ifndef PK_EXTRACT_OCC
 #define PK_EXTRACT_OCC 2  // waves per SIMD the two-lane extractor (w=5) is compiled for
 #endif
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 // general one and with the CPU restatement of the reference.
 // ------------------------------------------------------------------------
 template <int W, bool FEA64>
-__global__ __launch_bounds__(64, (!FEA64 ? PK_EXTRACT_OCC : 1)) void extract_pair_clean_kernel(
+__global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) void extract_pair_clean_kernel(
     const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
     const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
     float *__restrict__ tiles, int blk, uint8_t *__restrict__ status,
