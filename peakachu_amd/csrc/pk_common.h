@@ -57,7 +57,8 @@ struct pk_options {
     int64_t chunk = 2097152;    // candidates per extract/forest launch pair (1 GB of tiles at w=5; measured
                                 // 524 288: 8.82 ms, 1 M: 8.66 ms, 2 M: 8.58 ms per step of config 2)
     int64_t forest_ilp = 4;     // L2 kernel: trees walked concurrently per lane
-    int64_t forest_slots = 8;   // LDS kernel: tree slots (wave pairs) per workgroup
+    int64_t forest_slots = 0;   // LDS kernel: tree slots (wave pairs) per workgroup; 0 = as many as
+                                // average trees fit beside the tile (8 at w=5, 7 at w=6)
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
     int64_t overlap = 0;        // run extract(k+1) beside forest(k) on a second stream (measured: no gain,
                                 // the forest slows by what the extractor saves -- both are VALU-issue bound)
