@@ -224,3 +224,41 @@ def test_clean_and_general_extractor_agree_on_config2(config2):
         finally:
             _lib.set_option("extract_clean", 1)
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("w", [5, 6])
+def test_clean_extractor_bitwise_equals_general_on_balanced_values(hip_lib, config2, w):
+    """The clean kernel's shortcuts (pre-divided band, shared reciprocal of the min-max
+    division, no NaN handling) against the general kernel's per-cell IEEE divisions:
+    float64 features of ~600 k windows of a BALANCED (non-integer, ~1e-3) matrix, bit for
+    bit -- 10^8 quotients that must round identically."""
+    c = config2
+    M = c["Mf"].tocoo()
+    rng = np.random.default_rng(77 + w)
+    wts = 1.0 / np.sqrt(200.0 * rng.uniform(0.7, 1.3, M.shape[0]))
+    from scipy import sparse
+    B = sparse.csr_matrix((M.data * wts[M.row] * wts[M.col], (M.row, M.col)), shape=M.shape)
+    B = utils.canonical_csr(B)
+    e = c["e"] * float(np.mean(wts)) ** 2
+    sel = np.sort(rng.choice(c["x"].size, 600_000, replace=False))
+    x, y = c["x"][sel], c["y"][sel]
+    keep_band = (y - x >= 2 * w) & (y - x <= 200 - 2 * w)
+    x, y = x[keep_band], y[keep_band]
+    L = _lib.load()
+    got = {}
+    for clean in (1, 0):
+        _lib.set_option("extract_clean", clean)
+        before = L.pk_get_option(b"stat_extract_clean")
+        try:
+            hm = _lib.HipMatrix(B.indptr, B.indices, B.data, B.shape[0], e, -2 * w + 1, 200 + 2 * w - 1)
+            parts = []
+            for s0 in range(0, x.size, 150_000):          # bounded host memory
+                f64, _, keep = hm.extract(w, x[s0:s0 + 150_000], y[s0:s0 + 150_000])
+                parts.append((hashlib.sha256(f64.tobytes()).hexdigest(), keep.size,
+                              hashlib.sha256(keep.tobytes()).hexdigest()))
+            got[clean] = parts
+        finally:
+            _lib.set_option("extract_clean", 1)
+        assert (L.pk_get_option(b"stat_extract_clean") > before) == (clean == 1)
+    assert got[0] == got[1]
+    assert sum(p[1] for p in got[1]) > 300_000
