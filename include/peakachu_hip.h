@@ -154,6 +154,19 @@ int pk_prof_get(const char *name, double *ms_total, int64_t *launches);
 /* diagnostic builds only (option "forest_dbg" bit 4): in-kernel cycle stamps of
  * one workgroup, written to a buffer no kernel reads; n <= 65536 entries */
 int pk_debug_read(int device, int64_t *out, int64_t n);
+/* diagnostic, needs no device: the "LDS image" the forest kernel walks for
+ * model.predict_proba (peakachu/scoreUtils.py:109), built for `slots` tree slots,
+ * so that tests can walk it on the CPU.  Forest arrays as in pk_forest_create.
+ * layout8 = {half-tile bytes, region A bytes, region B offset, value area offset,
+ * flag area offset, image capacity, slots, F}; words = 8-byte words of all groups;
+ * gtab = 4 ints per group (first tree, trees, offset and size in 16-byte units);
+ * troot / tdepth = per tree the word a walk starts from and its number of levels. */
+int pk_debug_forest_image(int T, int F, const int32_t *tree_off, const int32_t *left,
+                          const int32_t *right, const int32_t *feat, const double *thr,
+                          const uint8_t *miss_left, const double *p1, int slots,
+                          int32_t *layout8, int64_t cap_words, uint64_t *words,
+                          int64_t *n_words, int64_t cap_groups, int32_t *gtab,
+                          int32_t *n_groups, uint64_t *troot, int32_t *tdepth);
 
 /* ---- multi-GPU: one process per GPU, one gather of the scored pixels -----
  * Chromosomes / candidate blocks are scored independently per rank

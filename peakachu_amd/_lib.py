@@ -19,6 +19,7 @@ _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/peakachu_hip.h declares
@@ -57,6 +58,10 @@ SIGNATURES = {
     "pk_prof_reset": (C.c_int, []),
     "pk_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pk_debug_read": (C.c_int, [C.c_int, _i64p, C.c_int64]),
+    "pk_debug_forest_image": (C.c_int, [C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p, _u8p,
+                                        _f64p, C.c_int, _i32p, C.c_int64, _u64p,
+                                        C.POINTER(C.c_int64), C.c_int64, _i32p,
+                                        C.POINTER(C.c_int32), _u64p, _i32p]),
     "pk_comm_unique_id": (C.c_int, [_u8p]),
     "pk_comm_create": (_vp, [C.c_int, C.c_int, C.c_int, _u8p]),
     "pk_comm_destroy": (None, [_vp]),

@@ -213,8 +213,7 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "extract_pair")) {
         g_opt.extract_pair = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
-        if (value != 0 && value != 2 && value != 4 && value != 6 && value != 7 && value != 8)
-            return PK_E_INVALID;
+        if (value != 0 && value != 2 && (value < 4 || value > 8)) return PK_E_INVALID;
         g_opt.forest_slots = value;
     } else if (!strcmp(name, "forest_pipe")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
@@ -228,6 +227,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_l2_tile = value != 0;
     } else if (!strcmp(name, "forest_dbg")) {
         g_opt.forest_dbg = value;
+    } else if (!strcmp(name, "forest_img")) {
+        g_opt.forest_img = value != 0;
     } else {
         pk_set_error("unknown option '%s'", name);
         return PK_E_INVALID;
@@ -252,6 +253,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_l2_tile")) return g_opt.forest_l2_tile;
     if (!strcmp(name, "early_exit")) return g_opt.early_exit;
     if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
+    if (!strcmp(name, "forest_img")) return g_opt.forest_img;
     return -1;
 }
 
@@ -458,6 +460,16 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
     fo->grp_words = fo->grp_slots = -1;
     fo->h_root = root;
     fo->h_big = tree_big;
+    {
+        const size_t nn = (size_t)tree_off[T];
+        fo->h_tree_off.assign(tree_off, tree_off + T + 1);
+        fo->h_left.assign(left, left + nn);
+        fo->h_right.assign(right, right + nn);
+        fo->h_feat.assign(feat, feat + nn);
+        fo->h_thr.assign(thr, thr + nn);
+        fo->h_p1.assign(p1, p1 + nn);
+        if (miss_left) fo->h_miss.assign(miss_left, miss_left + nn);
+    }
     if (hipMalloc((void **)&fo->nodes, (nodes.size() + 2) * sizeof(uint2)) != hipSuccess ||
         hipMalloc((void **)&fo->root, root.size() * sizeof(int32_t)) != hipSuccess) {
         pk_set_error("pk_forest_create: device allocation failed");
@@ -543,6 +555,7 @@ extern "C" void pk_forest_destroy(pk_forest *f)
     if (f->big_roff) hipFree(f->big_roff);
     if (f->tree_staged) hipFree(f->tree_staged);
     if (f->grp) hipFree(f->grp);
+    pk_forest_img_release(f);
     delete f;
 }
 
@@ -831,7 +844,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
                         double prune_sum)
 {
     const int F = (2 * w + 1) * (2 * w + 1);
-    const int blk = pk_forest_tile_width(F);
+    const int blk = pk_forest_plan_blk(f);
     if (blk <= 0) {
         pk_set_error("w=%d: feature tile does not fit LDS", w);
         return PK_E_UNSUPPORTED;
@@ -1051,7 +1064,7 @@ extern "C" int pk_predict(pk_forest *f, int64_t N, const float *fea32, double *p
     pk_device_ctx *ctx = pk_ctx(f->device);
     if (!ctx) return PK_E_NODEVICE;
     const int F = f->F;
-    const int blk = pk_forest_tile_width(F);
+    const int blk = pk_forest_plan_blk(f);
     if (blk <= 0) {
         pk_set_error("pk_predict: F=%d does not fit an LDS tile", F);
         return PK_E_UNSUPPORTED;

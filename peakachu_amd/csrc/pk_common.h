@@ -72,6 +72,8 @@ struct pk_options {
     int64_t early_exit = 0;     // pk_score_run: stop walking candidates that provably end at p <= thre
                                 // (identical output pixels; per-candidate probabilities of pruned pixels read 0)
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
+    int64_t forest_img = 1;     // LDS-image forest kernel (fixed-depth walks, absolute LDS addresses)
+                                // when every tree fits; 0 = the grouped preorder kernel
 };
 extern pk_options g_opt;
 // launches of the two-lane extractor since load, by kernel (read-only options
@@ -139,7 +141,54 @@ struct pk_forest {
     int32_t *grp;          // device, n_grp+1 first-tree indices, then n_grp staged flags
     int n_grp;
     int grp_words, grp_slots;
+    // sklearn's arrays as handed to pk_forest_create (the LDS image is built from them)
+    std::vector<int32_t> h_tree_off, h_left, h_right, h_feat;
+    std::vector<double> h_thr, h_p1;
+    std::vector<uint8_t> h_miss;
+    // LDS image (forest_img_kernel): 0 = not tried, 1 = built, -1 = does not apply
+    int img_state = 0;
+    int img_slots = 0, img_n_grp = 0;
+    int64_t img_opt_slots = -1;  // value of the forest_slots option the image was planned for
+    struct pk_img_layout *img_layout = nullptr;
+    uint4 *img = nullptr;          // device
+    int32_t *img_gtab = nullptr;   // device
+    uint2 *img_troot = nullptr;    // device
+    int32_t *img_tdepth = nullptr; // device
 };
+// ---- LDS-image forest (pk_image.hip builds it, pk_forest_img.hip walks it) ----
+struct pk_img_layout {
+    int F, slots;
+    int HB;        // bytes of half a feature tile: [F][64] float32
+    int lenA;      // bytes of image region A = [HB, 65536) (0 if too small to use)
+    int B0;        // LDS byte offset of image region B = [B0, 163840)
+    int val_off;   // [slots][128] float64 leaf values parked for the ordered sum
+    int dec_off;   // early-termination flags: 128 ints + 3 vote words
+    int cap;       // bytes a group image may occupy
+};
+struct pk_img_out {
+    std::vector<uint2> words;      // images of all groups, each a whole number of 16-byte units
+    std::vector<int32_t> gtab;     // per group: first tree, trees, offset and size in 16-byte units
+    std::vector<uint2> troot;      // per tree: the word a walk starts from
+    std::vector<int32_t> tdepth;   // per tree: levels to descend (depth of the tree)
+    int n_grp = 0;
+};
+// staging registers (uint4) per thread of forest_img_kernel<slots>, and what they move
+inline int pk_img_stage_regs(int slots)
+{
+    return slots >= 8 ? 6 : slots == 7 ? 7 : slots == 6 ? 8 : slots == 5 ? 10 : 12;
+}
+inline int pk_img_stage_bytes(int slots) { return pk_img_stage_regs(slots) * 128 * slots * 16; }
+bool pk_img_make_layout(int F, int slots, int max_image_bytes, pk_img_layout *L);
+int pk_img_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
+                 const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
+                 const pk_img_layout &L, pk_img_out *out);
+// decides how `f` is evaluated for tile-shaped input: builds (once) the LDS image when the
+// image kernel applies; returns the tile width the extractor must produce for it
+int pk_forest_plan_blk(pk_forest *f);
+void pk_forest_img_release(pk_forest *f);
+int pk_launch_forest_img(pk_device_ctx *, pk_forest *f, const float *tiles, const uint8_t *d_status,
+                         int64_t c0, int64_t cn, double *d_prob, double prune_sum);
+
 // (re)build f->grp for this launch shape; returns PK_OK or an error code
 int pk_forest_groups(pk_forest *f, int tree_words, int slots);
 // per-tree flag: words <= region_words and no side-table offsets

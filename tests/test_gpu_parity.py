@@ -60,20 +60,26 @@ def _extract_golden(name):
 
 
 @pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
-@pytest.mark.parametrize("ilp,lds,slots,pipe", [(4, 0, 8, 0), (1, 0, 8, 0), (8, 0, 8, 0),
-                                                (4, 160, 8, 0), (4, 160, 4, 0), (4, 160, 2, 0),
-                                                (4, 160, 6, 0), (4, 2, 8, 0), (4, 1, 4, 0),
-                                                (4, 160, 8, 1), (4, 160, 4, 4), (4, 160, 8, 6)])
-def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe):
+@pytest.mark.parametrize("ilp,lds,slots,pipe,img", [(4, 0, 8, 0, 0), (1, 0, 8, 0, 0), (8, 0, 8, 0, 0),
+                                                    (4, 160, 8, 0, 0), (4, 160, 4, 0, 0), (4, 160, 2, 0, 0),
+                                                    (4, 160, 6, 0, 0), (4, 2, 8, 0, 0), (4, 1, 4, 0, 0),
+                                                    (4, 160, 8, 1, 0), (4, 160, 4, 4, 0), (4, 160, 8, 6, 0),
+                                                    (4, 160, 0, 0, 1), (4, 160, 2, 0, 1), (4, 160, 4, 0, 1),
+                                                    (4, 160, 5, 0, 1), (4, 160, 6, 0, 1), (4, 160, 7, 0, 1),
+                                                    (4, 160, 8, 0, 1)])
+def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img):
     """Every forest kernel variant: nodes via L2 (lds=0) with 1/4/8 chains per
     lane; trees streamed through LDS in barrier-separated groups with 2..8
     tree slots; a tree buffer so small (1-2 KiB) that some trees are walked
     from global memory; the barrier-free per-wave pipeline (pipe>0: number of
-    waves, 1 = as many as fit)."""
+    waves, 1 = as many as fit); the LDS-image kernel (img=1: fixed-depth walks
+    over absolute LDS addresses) with automatic and forced slot counts."""
     z = gio.load("g2_forest_%s.npz" % tag)
     X = gio.load("g2_forest_plain.npz")["X"]
     old = {k: _lib.load().pk_get_option(k.encode())
-           for k in ("forest_ilp", "forest_lds", "forest_slots", "forest_pipe", "forest_pipe_slots")}
+           for k in ("forest_ilp", "forest_lds", "forest_slots", "forest_pipe", "forest_pipe_slots",
+                     "forest_img")}
+    _lib.set_option("forest_img", img)
     _lib.set_option("forest_ilp", ilp)
     _lib.set_option("forest_lds", lds)
     _lib.set_option("forest_slots", slots)
@@ -334,8 +340,8 @@ def big_tree_forest(F, seed, n_small=5, big_nodes=60001):
                 p1=np.array(cols["p1"], np.float64), F=np.int32(F))
 
 
-@pytest.mark.parametrize("lds,pipe", [(160, 0), (160, 2), (0, 0)])
-def test_giant_tree_side_table(hip_lib, lds, pipe):
+@pytest.mark.parametrize("lds,pipe,img", [(160, 0, 0), (160, 2, 0), (0, 0, 0), (160, 0, 1)])
+def test_giant_tree_side_table(hip_lib, lds, pipe, img):
     F = 121
     fo = big_tree_forest(F, seed=9)
     rng = np.random.default_rng(3)
@@ -343,9 +349,10 @@ def test_giant_tree_side_table(hip_lib, lds, pipe):
     X[5, :] = np.nan
     X[11, rng.integers(0, F, 40)] = np.nan
     ref = onp.predict(fo, X)
-    old = {k: _lib.load().pk_get_option(k.encode()) for k in ("forest_lds", "forest_pipe")}
+    old = {k: _lib.load().pk_get_option(k.encode()) for k in ("forest_lds", "forest_pipe", "forest_img")}
     _lib.set_option("forest_lds", lds)
     _lib.set_option("forest_pipe", pipe)
+    _lib.set_option("forest_img", img)  # img=1: the tree does not fit the LDS -> falls back
     try:
         hf = _lib.HipForest(flat(fo))
         info = hf.info()

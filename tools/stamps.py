@@ -24,13 +24,14 @@ buf = np.zeros(16 * 32 * 5, np.int64)
 _lib.check(L.pk_debug_read(0, buf, buf.size), "dbg")
 st = buf.reshape(16, 32, 5)
 ng = int((st[0, :, 0] != 0).sum())
-st = st[:, :ng, :].astype(np.float64)
+nw = int((st[:, 0, 0] != 0).sum())  # waves of the workgroup (2 per tree slot)
+st = st[:nw, :ng, :].astype(np.float64)
 walk = st[:, :, 1] - st[:, :, 0]
 bar1 = st[:, :, 2] - st[:, :, 1]
 commit = st[:, :, 3] - st[:, :, 2]
 bar2 = st[:, :, 4] - st[:, :, 3]
 tot = st[:, -1, 4] - st[:, 0, 0]
-print("groups", ng, "cycles per group (mean over 16 waves):")
+print("groups", ng, "(first 32 at most) cycles per group (mean over %d waves):" % nw)
 print("  prefetch-issue+walk %8.0f  (min wave %.0f max wave %.0f)" % (walk.mean(), walk.mean(1).min(), walk.mean(1).max()))
 print("  wait at barrier 1   %8.0f" % bar1.mean())
 print("  commit+accumulate   %8.0f" % commit.mean())
