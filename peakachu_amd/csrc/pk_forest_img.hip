@@ -38,7 +38,7 @@ constexpr int IMG_C = 128;          // candidates per workgroup
 constexpr unsigned HALF1 = 65536u;  // LDS offset of the second half tile
 
 // one tree, `depth` levels; cur = the root word; lanek = lane*4 | half << 16
-template <bool WITH_NAN>
+template <bool WITH_NAN, bool ALL_LEFT = false>
 __device__ __forceinline__ double walk_img(uint2 cur, int depth, unsigned lanek)
 {
     for (int d = 0; d < depth; d++) {
@@ -49,6 +49,7 @@ __device__ __forceinline__ double walk_img(uint2 cur, int depth, unsigned lanek)
         const u64 rw = *LDS_AT(const volatile lds_u64, ca + 8);
         bool gl = x <= __uint_as_float(cur.x);
         if (WITH_NAN) gl = gl | ((x != x) & ((cur.y & 1u) != 0));
+        if (ALL_LEFT) gl = gl | (x == x);  // timing ablation: every lane takes the same path
         cur.x = gl ? (unsigned)lw : (unsigned)rw;
         cur.y = gl ? (unsigned)(lw >> 32) : (unsigned)(rw >> 32);
     }
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(IMG_C *SLOTS) void forest_img_kernel(
             const int t = t0 + slot;
             const uint2 r = troot[t];
             const int depth = tdepth[t];
-            const double v = wave_nan ? walk_img<true>(r, depth, lanek) : walk_img<false>(r, depth, lanek);
+            const double v = (dbg & 8)   ? walk_img<false, true>(r, depth, lanek)  // wrong results
+                             : wave_nan ? walk_img<true>(r, depth, lanek)
+                                        : walk_img<false>(r, depth, lanek);
             *LDS_AT(lds_f64, val_off + (slot * IMG_C + cl) * 8) = v;
         }
         IMG_STAMP(1);

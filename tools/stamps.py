@@ -13,11 +13,18 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 Mf, e, x, y, upper = bench.build_workload(0, n, 200, 5, 6, 200)
 fo = FlatForest.load("peakachu_amd/data/forest_w5_t100.npz")
 L = _lib.require_device()
+dbg_extra = 0
+for kv in filter(None, os.environ.get("PK_OPTS", "").split(",")):
+    k, v = kv.split("=")
+    if k == "forest_dbg":
+        dbg_extra = int(v)
+    else:
+        _lib.set_option(k, int(v))
 hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -9, upper + 9)
 hf = _lib.HipForest(fo)
 cd = _lib.HipCands(x, y)
 cd.run(hm, hf, 5, 0.5)
-_lib.set_option("forest_dbg", 16)
+_lib.set_option("forest_dbg", 16 | dbg_extra)
 cd.run(hm, hf, 5, 0.5)
 _lib.set_option("forest_dbg", 0)
 buf = np.zeros(16 * 32 * 5, np.int64)
