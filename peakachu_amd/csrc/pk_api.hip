@@ -213,7 +213,7 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "extract_pair")) {
         g_opt.extract_pair = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
-        if (value != 0 && value != 2 && (value < 4 || value > 8)) return PK_E_INVALID;
+        if (value < 0 || value == 1 || value > 16) return PK_E_INVALID;
         g_opt.forest_slots = value;
     } else if (!strcmp(name, "forest_pipe")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
@@ -228,7 +228,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_dbg")) {
         g_opt.forest_dbg = value;
     } else if (!strcmp(name, "forest_img")) {
-        g_opt.forest_img = value != 0;
+        if (value < 0 || value > 2) return PK_E_INVALID;
+        g_opt.forest_img = value;
     } else {
         pk_set_error("unknown option '%s'", name);
         return PK_E_INVALID;

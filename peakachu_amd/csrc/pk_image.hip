@@ -254,7 +254,7 @@ bool emit_tree(emitter &e, const tree_view &t, int F, uint2 *root, int *depth, s
 // max_image_bytes: what the kernel's register staging can move per group.
 bool pk_img_make_layout(int F, int slots, int max_image_bytes, pk_img_layout *L)
 {
-    if (F < 1 || F > 255 || slots < 1 || slots > 8) return false;
+    if (F < 1 || F > 255 || slots < 1 || slots > 16) return false;
     L->F = F;
     L->slots = slots;
     L->HB = F * 256;

@@ -66,14 +66,17 @@ def _extract_golden(name):
                                                     (4, 160, 8, 1, 0), (4, 160, 4, 4, 0), (4, 160, 8, 6, 0),
                                                     (4, 160, 0, 0, 1), (4, 160, 2, 0, 1), (4, 160, 4, 0, 1),
                                                     (4, 160, 5, 0, 1), (4, 160, 6, 0, 1), (4, 160, 7, 0, 1),
-                                                    (4, 160, 8, 0, 1)])
+                                                    (4, 160, 8, 0, 1),
+                                                    (4, 160, 0, 0, 2), (4, 160, 2, 0, 2), (4, 160, 3, 0, 2),
+                                                    (4, 160, 7, 0, 2), (4, 160, 12, 0, 2), (4, 160, 16, 0, 2)])
 def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img):
     """Every forest kernel variant: nodes via L2 (lds=0) with 1/4/8 chains per
     lane; trees streamed through LDS in barrier-separated groups with 2..8
     tree slots; a tree buffer so small (1-2 KiB) that some trees are walked
     from global memory; the barrier-free per-wave pipeline (pipe>0: number of
     waves, 1 = as many as fit); the LDS-image kernel (img=1: fixed-depth walks
-    over absolute LDS addresses) with automatic and forced slot counts."""
+    over absolute LDS addresses; img=2: one wave per tree, two walks per lane)
+    with automatic and forced slot counts."""
     z = gio.load("g2_forest_%s.npz" % tag)
     X = gio.load("g2_forest_plain.npz")["X"]
     old = {k: _lib.load().pk_get_option(k.encode())
