@@ -38,21 +38,35 @@ constexpr int IMG_C = 128;          // candidates per workgroup
 constexpr unsigned HALF1 = 65536u;  // LDS offset of the second half tile
 
 // one tree, `depth` levels; cur = the root word; lanek = lane*4 | half << 16
+// one level of one walk
+template <bool WITH_NAN, bool ALL_LEFT>
+__device__ __forceinline__ void img_step(uint2 &cur, unsigned lanek)
+{
+    const unsigned xa = __builtin_amdgcn_perm(cur.y, lanek, 0x0c020700u);
+    const float x = *LDS_AT(const lds_f32, xa);
+    const unsigned ca = cur.y & 0x3fff8u;
+    const u64 lw = *LDS_AT(const volatile lds_u64, ca);
+    const u64 rw = *LDS_AT(const volatile lds_u64, ca + 8);
+    bool gl = x <= __uint_as_float(cur.x);
+    if (WITH_NAN) gl = gl | ((x != x) & ((cur.y & 1u) != 0));
+    if (ALL_LEFT) gl = gl | (x == x);  // timing ablation: every lane takes the same path
+    cur.x = gl ? (unsigned)lw : (unsigned)rw;
+    cur.y = gl ? (unsigned)(lw >> 32) : (unsigned)(rw >> 32);
+}
+
+// one tree, `depth` levels; cur = the root word; lanek = lane*4 | half << 16.
+// Four levels per loop trip: a taken branch costs the wave an instruction refetch.
 template <bool WITH_NAN, bool ALL_LEFT = false>
 __device__ __forceinline__ double walk_img(uint2 cur, int depth, unsigned lanek)
 {
-    for (int d = 0; d < depth; d++) {
-        const unsigned xa = __builtin_amdgcn_perm(cur.y, lanek, 0x0c020700u);
-        const float x = *LDS_AT(const lds_f32, xa);
-        const unsigned ca = cur.y & 0x3fff8u;
-        const u64 lw = *LDS_AT(const volatile lds_u64, ca);
-        const u64 rw = *LDS_AT(const volatile lds_u64, ca + 8);
-        bool gl = x <= __uint_as_float(cur.x);
-        if (WITH_NAN) gl = gl | ((x != x) & ((cur.y & 1u) != 0));
-        if (ALL_LEFT) gl = gl | (x == x);  // timing ablation: every lane takes the same path
-        cur.x = gl ? (unsigned)lw : (unsigned)rw;
-        cur.y = gl ? (unsigned)(lw >> 32) : (unsigned)(rw >> 32);
+    int d = depth;
+    for (; d >= 4; d -= 4) {
+        img_step<WITH_NAN, ALL_LEFT>(cur, lanek);
+        img_step<WITH_NAN, ALL_LEFT>(cur, lanek);
+        img_step<WITH_NAN, ALL_LEFT>(cur, lanek);
+        img_step<WITH_NAN, ALL_LEFT>(cur, lanek);
     }
+    for (; d > 0; d--) img_step<WITH_NAN, ALL_LEFT>(cur, lanek);
     return *LDS_AT(const lds_f64, cur.x & 0x3ffffu);
 }
 
