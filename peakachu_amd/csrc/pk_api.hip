@@ -41,8 +41,8 @@ struct prof_rec {
 };
 static bool g_prof_on = false;
 static std::vector<prof_rec> g_prof_pending;
-static double g_prof_ms[PK_K_NCLASS] = {0, 0, 0, 0};
-static int64_t g_prof_n[PK_K_NCLASS] = {0, 0, 0, 0};
+static double g_prof_ms[PK_K_NCLASS] = {0, 0, 0, 0, 0};
+static int64_t g_prof_n[PK_K_NCLASS] = {0, 0, 0, 0, 0};
 
 pk_prof_scope::pk_prof_scope(pk_device_ctx *c, pk_kclass kk, hipStream_t s)
     : ctx(c), k(kk), st(s ? s : c->stream)
@@ -227,6 +227,11 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_l2_tile = value != 0;
     } else if (!strcmp(name, "forest_dbg")) {
         g_opt.forest_dbg = value;
+    } else if (!strcmp(name, "forest_q")) {
+        g_opt.forest_q = value != 0;
+    } else if (!strcmp(name, "forest_q_ch")) {
+        if (value != 0 && value != 2 && value != 4) return PK_E_INVALID;
+        g_opt.forest_q_ch = value;
     } else if (!strcmp(name, "forest_img")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
         g_opt.forest_img = value;
@@ -255,6 +260,8 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "early_exit")) return g_opt.early_exit;
     if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
     if (!strcmp(name, "forest_img")) return g_opt.forest_img;
+    if (!strcmp(name, "forest_q")) return g_opt.forest_q;
+    if (!strcmp(name, "forest_q_ch")) return g_opt.forest_q_ch;
     return -1;
 }
 
@@ -288,7 +295,7 @@ extern "C" int pk_prof_reset(void)
 extern "C" int pk_prof_get(const char *name, double *ms_total, int64_t *launches)
 {
     PK_API_LOCK;
-    static const char *names[PK_K_NCLASS] = {"extract", "forest", "compact", "band"};
+    static const char *names[PK_K_NCLASS] = {"extract", "forest", "compact", "band", "quant"};
     prof_drain();
     for (int i = 0; i < PK_K_NCLASS; i++)
         if (name && !strcmp(name, names[i])) {
@@ -557,6 +564,7 @@ extern "C" void pk_forest_destroy(pk_forest *f)
     if (f->tree_staged) hipFree(f->tree_staged);
     if (f->grp) hipFree(f->grp);
     pk_forest_img_release(f);
+    pk_forest_q_release(f);
     delete f;
 }
 

@@ -43,6 +43,8 @@ struct pk_device_ctx {
     hipEvent_t ev_for[2] = {nullptr, nullptr};  // forest(k) done with its tile buffer
     float *fea_tiles = nullptr;   // [tile][F][BLK] float32 feature tiles (two chunk buffers)
     size_t fea_tiles_bytes = 0;
+    uint16_t *q_tiles = nullptr;  // [tile][F][128] rank codes of the current chunk (forest_q_kernel)
+    size_t q_tiles_bytes = 0;
     int64_t *scan_scratch = nullptr;  // block counts for the compaction scan
     size_t scan_scratch_bytes = 0;
     int cu_count = 0;
@@ -72,6 +74,8 @@ struct pk_options {
     int64_t early_exit = 0;     // pk_score_run: stop walking candidates that provably end at p <= thre
                                 // (identical output pixels; per-candidate probabilities of pruned pixels read 0)
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
+    int64_t forest_q = 1;       // rank-quantised tiles + 4-byte nodes (forest_q_kernel) when the forest fits
+    int64_t forest_q_ch = 0;    // walks per lane of forest_q_kernel: 0 = auto (4 when F <= 128), 2, 4
     int64_t forest_img = 1;     // LDS-image forest kernel (fixed-depth walks, absolute LDS addresses)
                                 // when every tree fits; 0 = the grouped preorder kernel
 };
@@ -83,7 +87,7 @@ extern int64_t g_stat_extract_clean, g_stat_extract_general;
 // ---------------------------------------------------------------- profiling
 // Brackets a kernel launch with HIP events on the library's stream when
 // profiling is enabled (pk_prof_enable); otherwise a no-op.
-enum pk_kclass { PK_K_EXTRACT = 0, PK_K_FOREST, PK_K_COMPACT, PK_K_BAND, PK_K_NCLASS };
+enum pk_kclass { PK_K_EXTRACT = 0, PK_K_FOREST, PK_K_COMPACT, PK_K_BAND, PK_K_QUANT, PK_K_NCLASS };
 struct pk_prof_scope {
     pk_prof_scope(pk_device_ctx *ctx, pk_kclass k, hipStream_t st = nullptr);
     ~pk_prof_scope();
@@ -155,6 +159,17 @@ struct pk_forest {
     int32_t *img_gtab = nullptr;   // device
     uint2 *img_troot = nullptr;    // device
     int32_t *img_tdepth = nullptr; // device
+    // how pk_forest_plan_blk decided to evaluate this forest: 0 preorder kernels, 1 LDS image, 2 rank image
+    int plan_kind = 0;
+    // rank image (forest_q_kernel): 0 = not tried, 1 = built, -1 = does not apply
+    int q_state = 0;
+    int q_slots = 0, q_ch = 0, q_n_grp = 0;
+    int64_t q_opt_slots = -1, q_opt_ch = -1;
+    struct pk_q_layout *q_layout = nullptr;
+    uint4 *q_img = nullptr;        // device: tree images
+    int32_t *q_gtab = nullptr, *q_ttab = nullptr, *q_off = nullptr;  // device
+    float *q_thr = nullptr, *q_par = nullptr;                        // device
+    uint16_t *q_lut = nullptr;                                       // device
 };
 // ---- LDS-image forest (pk_image.hip builds it, pk_forest_img.hip walks it) ----
 struct pk_img_layout {
@@ -189,6 +204,37 @@ int pk_forest_plan_blk(pk_forest *f);
 void pk_forest_img_release(pk_forest *f);
 int pk_launch_forest_img(pk_device_ctx *, pk_forest *f, const float *tiles, const uint8_t *d_status,
                          int64_t c0, int64_t cn, double *d_prob, double prune_sum);
+
+// ---- rank image (pk_qimage.hip builds it, pk_forest_q.hip quantizes tiles and walks it) ----
+#define PK_Q_CELLS 1024
+struct pk_q_layout {
+    int F, slots, ch;   // ch = walks per lane: 2 (128 candidates per workgroup) or 4 (256)
+    int HB;             // bytes of a half tile: [F][128] u16
+    int dec_off;        // early-termination flags
+    int val_off;        // [slots][64*ch] float64 leaf values parked for the ordered sum
+    int img_off, cap;   // the group's trees: [img_off, img_off + cap)
+};
+struct pk_q_out {
+    std::vector<float> qthr;      // per feature: sorted distinct float32 thresholds, laid end to end
+    std::vector<int32_t> qoff;    // F+1 offsets into qthr
+    std::vector<uint16_t> qlut;   // [F][PK_Q_CELLS] first guess of the rank for a lookup cell
+    std::vector<float> qpar;      // [F][2]: lower end of the cells, cells per unit
+    std::vector<uint2> pairs;     // tree images (8-byte child pairs), tree after tree
+    std::vector<uint32_t> troot;  // per tree: the word a walk starts from
+    std::vector<int32_t> tdepth;  // per tree: levels to descend
+    std::vector<int32_t> gtab;    // per group: first tree, trees, offset and size in 16-byte units
+    std::vector<int32_t> ttab;    // per tree: byte offset inside its group, depth, root word, 0
+    int n_grp = 0;
+};
+inline int pk_q_stage_regs() { return 16; }  // uint4 staging registers per thread of forest_q_kernel
+bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L);
+int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
+               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
+               const pk_q_layout &L, pk_q_out *out);
+int pk_forest_q_plan(pk_forest *f);   // PK_OK when the rank image applies (built and uploaded)
+void pk_forest_q_release(pk_forest *f);
+int pk_launch_forest_q(pk_device_ctx *, pk_forest *f, const float *tiles, const uint8_t *d_status,
+                       int64_t c0, int64_t cn, double *d_prob, double prune_sum);
 
 // (re)build f->grp for this launch shape; returns PK_OK or an error code
 int pk_forest_groups(pk_forest *f, int tree_words, int slots);

@@ -720,8 +720,10 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
                      double prune_sum)
 {
     if (cn <= 0) return PK_OK;
-    // 64-candidate tiles are what pk_forest_plan_blk asks for when the LDS image applies
-    if (blk == 64 && f->img_state == 1 && g_opt.forest_img)
+    // pk_forest_plan_blk decided how this forest is evaluated (and which tile width that needs)
+    if (f->plan_kind == 2 && blk == 128 && f->q_state == 1)
+        return pk_launch_forest_q(ctx, f, tiles, d_status, c0, cn, d_prob, prune_sum);
+    if (f->plan_kind == 1 && blk == 64 && f->img_state == 1)
         return pk_launch_forest_img(ctx, f, tiles, d_status, c0, cn, d_prob, prune_sum);
     pk_prof_scope prof(ctx, PK_K_FOREST);
     const unsigned grid = (unsigned)((cn + blk - 1) / blk);

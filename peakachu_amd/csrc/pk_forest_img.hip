@@ -471,6 +471,15 @@ static int img_plan(pk_forest *f)
 
 int pk_forest_plan_blk(pk_forest *f)
 {
+    f->plan_kind = 0;
+    if (g_opt.forest_q && g_opt.forest_lds > 0) {
+        const int rc = pk_forest_q_plan(f);
+        if (rc == PK_OK) {
+            f->plan_kind = 2;
+            return 128;
+        }
+        if (rc != PK_E_UNSUPPORTED) return 0;  // error already set
+    }
     if (!g_opt.forest_img || g_opt.forest_lds <= 0) return pk_forest_tile_width(f->F);
     if (f->img_state != 0 &&
         (f->img_opt_slots != g_opt.forest_slots || f->img_ilp2 != (g_opt.forest_img == 2))) {
@@ -483,7 +492,11 @@ int pk_forest_plan_blk(pk_forest *f)
         f->img_state = rc == PK_OK ? 1 : -1;
         if (rc != PK_OK) img_free(f);
     }
-    return f->img_state == 1 ? 64 : pk_forest_tile_width(f->F);
+    if (f->img_state == 1) {
+        f->plan_kind = 1;
+        return 64;
+    }
+    return pk_forest_tile_width(f->F);
 }
 
 #define IMG_LAUNCH_P(SLOTS, PRUNE)                                                             \

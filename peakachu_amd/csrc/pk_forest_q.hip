@@ -1,0 +1,475 @@
+// pk_forest_q.hip -- Random-Forest predict_proba[:,1] on rank codes (gfx950 only).
+//
+// Replaces model.predict_proba(fea)[:, 1] at peakachu/scoreUtils.py:109 (sklearn
+// ForestClassifier.predict_proba -> Tree._apply_dense) exactly; pk_qimage.hip
+// explains why ranks decide every split the same way as the float32 features.
+//
+// Why this shape (measured on MI355X, tools/micro/lds_chain.hip):
+// a level of a tree walk is one dependent LDS round trip, and with >= 12 waves
+// walking the LDS pipe is what binds: a wave-level costs the CU about 15 cycles
+// when it reads a float32 feature and two 8-byte child words, and about 9 when
+// it reads a 16-bit code and ONE 8-byte word that holds both children.  Hence
+//   * quantize_tiles_kernel turns the extractor's float32 tiles into 16-bit
+//     rank codes once per candidate (a streaming pass, table lookups in LDS);
+//   * nodes are 4 bytes, sibling words adjacent; leaves lead back to themselves,
+//     so a tree is walked for a fixed number of levels with no termination test;
+//   * half the bytes per tree and per candidate tile put 9-13 whole trees and 256
+//     (or 128) candidates into the 160 KiB of LDS at once: one wave per tree,
+//     2 or 4 independent walks per lane, half as many tree groups (barriers, LDS
+//     commits, L2 -> LDS traffic) per candidate as the float kernels need.
+// Per level and walk: v_perm_b32 (feature address), v_bfe_u32 + v_lshl_add_u32
+// (pair address), v_cmp_le_u32_sdwa (code against the word's upper half),
+// v_cndmask_b32; ds_read_u16 + ds_read_b64.  Leaf values are added in tree order
+// in float64, the sequential sum sklearn computes.
+#include "pk_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef unsigned v4u __attribute__((ext_vector_type(4)));  // a plain 16-byte vector (uint4 is a class)
+typedef __attribute__((address_space(3))) v4u lds_u4;
+typedef unsigned long long u64;
+typedef __attribute__((address_space(3))) u64 lds_u64;
+
+#define LDS_AT(type, byte_addr) (reinterpret_cast<type *>((__UINTPTR_TYPE__)(unsigned)(byte_addr)))
+
+constexpr int Q_HALF1 = 32768;  // LDS offset of the rank tile of candidates 128..255
+
+// ------------------------------------------------------------------------
+// float32 feature tiles [tile][F][128] -> rank codes [tile][F][128] u16.
+// Block (f, s): the tables of feature f in LDS, every s-th group of tiles.
+// code = r(x) << 5 with r(x) = number of the feature's distinct thresholds
+// below x (exact: the lookup cell only gives the first guess), NaN -> 0xFFFF.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ unsigned q_code(float x, const float *thr, const unsigned short *lut, int n,
+                                           float lo, float inv)
+{
+    if (x != x) return 0xFFFFu;
+    float cf = (x - lo) * inv;  // +-inf, or NaN from inf * 0: fmaxf / fminf return the other operand
+    cf = fminf(fmaxf(cf, 0.f), (float)(PK_Q_CELLS - 1));
+    int r = lut[(int)cf];
+    while (r > 0 && thr[r - 1] >= x) r--;
+    while (r < n && thr[r] < x) r++;
+    return (unsigned)r << 5;
+}
+
+__global__ __launch_bounds__(256) void quantize_tiles_kernel(
+    const float *__restrict__ tiles, int64_t n_tiles, int F, const float *__restrict__ qthr,
+    const int32_t *__restrict__ qoff, const unsigned short *__restrict__ qlut,
+    const float *__restrict__ qpar, unsigned short *__restrict__ qtiles)
+{
+    __shared__ float thr[2048];
+    __shared__ unsigned short lut[PK_Q_CELLS];
+    const int f = blockIdx.x;
+    const int o = qoff[f], n = qoff[f + 1] - o;
+    for (int i = threadIdx.x; i < n; i += 256) thr[i] = qthr[o + i];
+    for (int i = threadIdx.x; i < PK_Q_CELLS; i += 256) lut[i] = qlut[(size_t)f * PK_Q_CELLS + i];
+    const float lo = qpar[2 * f], inv = qpar[2 * f + 1];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int64_t t = (int64_t)blockIdx.y * 4 + wave; t < n_tiles; t += (int64_t)gridDim.y * 4) {
+        const size_t row = ((size_t)t * F + f) * 128;
+        const float2 x = reinterpret_cast<const float2 *>(tiles + row)[lane];
+        const unsigned c0 = q_code(x.x, thr, lut, n, lo, inv), c1 = q_code(x.y, thr, lut, n, lo, inv);
+        reinterpret_cast<unsigned *>(qtiles + row)[lane] = c0 | (c1 << 16);
+    }
+}
+
+// ------------------------------------------------------------------------
+// the walk
+// ------------------------------------------------------------------------
+__device__ __forceinline__ unsigned q_pair_index(unsigned w)
+{
+    unsigned t;  // (the compiler turns a C bit-field extract into shift + and + add: 3 VALU, not 2)
+    asm("v_bfe_u32 %0, %1, 8, 12" : "=v"(t) : "v"(w));
+    return t;
+}
+
+// one level of CH walks of one tree.  Walk c belongs to candidate lane + 64 c of the
+// workgroup: code address = (c >> 1) * 32 KiB + feature * 256 + ((lane + 64 (c & 1)) * 2)
+template <int CH, bool WITH_NAN, bool ALL_LEFT>
+__device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsigned lk0, unsigned lk1)
+{
+    unsigned xv[CH];
+    u64 pr[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        // byte 0 <- lane constant, byte 1 <- the word's feature byte
+        const unsigned xa = __builtin_amdgcn_perm(w[c], (c & 1) ? lk1 : lk0, 0x0c0c0400u);
+        xv[c] = *LDS_AT(const lds_u16, xa + (c >> 1) * Q_HALF1);
+        pr[c] = *LDS_AT(const lds_u64, tbase + (q_pair_index(w[c]) << 3));
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        bool gl = xv[c] <= (w[c] >> 16);  // rank(x) <= rank(threshold); bits 20..16 cannot flip it
+        if (WITH_NAN) gl = gl | ((xv[c] == 0xFFFFu) & ((w[c] & (1u << 20)) != 0));
+        if (ALL_LEFT) gl = gl | (xv[c] < 0x10000u);  // timing ablation: every lane takes the same path
+        w[c] = gl ? (unsigned)pr[c] : (unsigned)(pr[c] >> 32);
+    }
+}
+
+template <int CH, bool WITH_NAN, bool ALL_LEFT = false>
+__device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase, unsigned lk0,
+                                       unsigned lk1, double (&v)[CH])
+{
+    unsigned w[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) w[c] = root;
+    int d = depth;
+    for (; d >= 2; d -= 2) {  // two levels per trip: a taken branch costs an instruction refetch
+        q_level<CH, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+        q_level<CH, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+    }
+    if (d) q_level<CH, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+#pragma unroll
+    for (int c = 0; c < CH; c++)  // the leaf's float64 value follows its pair
+        v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index(w[c]) + 1) << 3));
+}
+
+#define Q_PF16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define Q_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u};
+#define Q_PF_LOAD(q) \
+    if constexpr ((q) < PFN) pf##q = pf_src[min(tid + (q) * THREADS, pf_nu - 1)];
+#define Q_PF_STORE(q)                                                          \
+    if constexpr ((q) < PFN) {                                                 \
+        const int u = tid + (q) * THREADS;                                     \
+        if (u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q;            \
+    }
+
+// One workgroup = 64 * CH candidates and SLOTS waves; wave s walks tree s of the group
+// for all of them (CH walks per lane).  Trees arrive group by group: the next group
+// travels global -> VGPR during the walk and VGPR -> LDS behind the barrier.
+template <int SLOTS, int CH, bool PRUNE>
+__global__ __launch_bounds__(64 * SLOTS) void forest_q_kernel(
+    const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp,
+    const int4 *__restrict__ ttab, int T, int F, int dec_off, int val_off, int img_off,
+    const unsigned short *__restrict__ qtiles, const uint8_t *__restrict__ status, int64_t c0,
+    int64_t cn, double *__restrict__ prob, double prune_sum, int warm_ahead, int dbg,
+    long long *__restrict__ stamps)
+{
+    constexpr int THREADS = 64 * SLOTS;
+    constexpr int C = 64 * CH;
+    // staging registers: enough for a group that fills the LDS (the host never plans more
+    // than 16 per thread: pk_q_stage_regs)
+    constexpr int PFN = (160 + SLOTS - 1) / SLOTS < 16 ? (160 + SLOTS - 1) / SLOTS : 16;
+    static_assert(THREADS >= C, "one thread per candidate owns the ordered sum");
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HB = F * 256;
+    const unsigned lk0 = (unsigned)lane << 1, lk1 = lk0 + 128u;
+    const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
+    if (!lds_at_zero && tid == 0 && stamps) stamps[65535] = 2;
+
+    if (PRUNE)
+        for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
+    const int64_t wg = blockIdx.x;
+    const int64_t cbase = wg * C;  // first candidate of this workgroup (relative to c0)
+    {
+        // rank tiles of 128 candidates each, consecutive in memory; the second one exists
+        // only if it holds a candidate (the buffer ends with the last tile in use)
+        const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
+        const int halves = (CH == 4 && cbase + 128 < cn) ? 2 : 1;
+        const int nu = halves * (HB >> 4);
+        for (int i = tid; i < nu; i += THREADS) {
+            const int o = i << 4;
+            *LDS_AT(lds_u4, o < HB ? o : o - HB + Q_HALF1) = src[i];
+        }
+    }
+    // every wave walks for all C candidates: walk c of a lane = candidate lane + 64 c
+    unsigned stc[CH];
+    bool act[CH];
+    bool any_nan = false;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int64_t loc = cbase + lane + 64 * c;
+        stc[c] = loc < cn ? status[c0 + loc] : 0;
+        act[c] = stc[c] != 0 && lds_at_zero;
+        any_nan = any_nan || stc[c] == 2;
+    }
+    const bool wave_nan = __any(any_nan);  // a wave holding NaN features takes the slow walk
+    // threads 0 .. C-1 also own one candidate each for the ordered sum
+    const bool owner = tid < C;
+    const int64_t local = cbase + tid;
+    const bool valid = owner && local < cn;
+    const unsigned st = valid ? status[c0 + local] : 0;
+    const bool active = st != 0 && lds_at_zero;
+
+    Q_PF16(Q_PF_DECL)
+    const v4u *pf_src;
+    int pf_nu;
+    int4 g_cur = gtab[0];
+    int4 tt = ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree of the group: offset, depth, root
+    {
+        pf_src = img + g_cur.z;
+        pf_nu = g_cur.w;
+        Q_PF16(Q_PF_LOAD)
+        Q_PF16(Q_PF_STORE)
+    }
+    __syncthreads();  // rank tiles and first group are in LDS
+
+#define Q_STAMP(slot_)                                                                   \
+    do {                                                                                 \
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && g < 32)              \
+            stamps[((tid >> 6) * 32 + g) * 5 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+    double acc = 0.0;
+    unsigned warm_sink = 0;
+    for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
+        const int t0 = g_cur.x, gt = g_cur.y;
+        const int4 g_nxt = gtab[g + 1];
+        const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];  // (scalar loads: in flight during the walk)
+        Q_STAMP(0);
+        if (g + 1 < n_grp) {  // loads fly while this group is walked
+            pf_src = img + g_nxt.z;
+            pf_nu = g_nxt.w;
+            Q_PF16(Q_PF_LOAD)
+        } else if (warm_ahead > 0) {
+            // last group: pull the tiles of the workgroup that follows this one on this XCD
+            // into its L2, one dword per 128-byte line; the value is never used
+            const int64_t ahead = wg + warm_ahead;
+            if ((ahead + 1) * C <= cn)
+                for (int line = tid; line < F * CH; line += THREADS)
+                    warm_sink += reinterpret_cast<const unsigned *>(qtiles + (size_t)ahead * C * F)[line * 32];
+        }
+        bool walk[CH];
+        bool any_walk = false;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            walk[c] = act[c] && (!PRUNE || *LDS_AT(lds_i32, dec_off + 4 * (lane + 64 * c)) == 0);
+            any_walk = any_walk || walk[c];
+        }
+        if (slot < gt && !(dbg & 2) && __any(any_walk)) {
+            double v[CH];
+            const unsigned tbase = (unsigned)(img_off + tt.x);
+            // lanes without a live candidate walk along (their values are not stored)
+            if (dbg & 8) q_walk<CH, false, true>((unsigned)tt.z, tt.y, tbase, lk0, lk1, v);  // wrong results
+            else if (wave_nan) q_walk<CH, true>((unsigned)tt.z, tt.y, tbase, lk0, lk1, v);
+            else q_walk<CH, false>((unsigned)tt.z, tt.y, tbase, lk0, lk1, v);
+#pragma unroll
+            for (int c = 0; c < CH; c++)
+                if (walk[c]) *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * c) * 8) = v[c];
+        }
+        Q_STAMP(1);
+        __syncthreads();  // every walk of the group is done: the trees may be overwritten
+        Q_STAMP(2);
+        if (g + 1 < n_grp) { Q_PF16(Q_PF_STORE) }
+        const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
+        if (owner && active && undecided) {
+            for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
+            if (PRUNE) {
+                // every remaining tree adds at most 1.0: if even that cannot lift the sum to
+                // thre*T (1e-12 covers the rounding of at most T additions) the final p is
+                // <= thre and the pixel is not reported -- stop walking it
+                const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < prune_sum;
+                if (out) {
+                    *LDS_AT(lds_i32, dec_off + 4 * tid) = 1;
+                    acc = 0.0;  // reported probability of a pruned candidate: 0
+                } else {
+                    *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) = 1;  // still an open candidate
+                }
+            }
+        }
+        Q_STAMP(3);
+        __syncthreads();  // next group staged; values consumed; votes cast
+        bool all_done = false;
+        if (PRUNE) {
+            // a vote word is set before this barrier, read after it and cleared two groups
+            // ahead, so a clear and a set of the same word are always a barrier apart
+            all_done = *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) == 0;
+            if (tid == 0) *LDS_AT(lds_i32, dec_off + 4 * (C + ((g + 2) % 3))) = 0;
+        }
+        Q_STAMP(4);
+        g_cur = g_nxt;
+        tt = tt_nxt;
+        if (all_done) break;
+    }
+    if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
+    if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-ahead loads alive
+#undef Q_STAMP
+}
+
+template <typename KernelT>
+int q_set_max_lds(KernelT k, size_t bytes)
+{
+    PK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PK_OK;
+}
+
+void q_free(pk_forest *f)
+{
+    void *ptrs[] = {f->q_img, f->q_gtab, f->q_ttab, f->q_off, f->q_thr, f->q_par, f->q_lut};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    f->q_img = nullptr;
+    f->q_gtab = f->q_ttab = f->q_off = nullptr;
+    f->q_thr = f->q_par = nullptr;
+    f->q_lut = nullptr;
+    delete f->q_layout;
+    f->q_layout = nullptr;
+}
+
+template <typename V>
+int q_upload(void **dst, const V &v)
+{
+    PK_HIP(hipMalloc(dst, v.size() * sizeof(v[0])));
+    PK_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    return PK_OK;
+}
+
+}  // namespace
+
+void pk_forest_q_release(pk_forest *f)
+{
+    q_free(f);
+    f->q_state = 0;
+}
+
+// Picks walks per lane and the slot count, builds and uploads the rank image.
+static int q_plan_build(pk_forest *f)
+{
+    const int F = f->F, T = f->T;
+    if (F > 255 || f->h_tree_off.empty()) return PK_E_UNSUPPORTED;
+    int ch = (int)g_opt.forest_q_ch;
+    if (ch == 0) ch = F <= 128 ? 4 : 2;
+    if (ch == 4 && F > 128) return PK_E_UNSUPPORTED;
+    pk_q_out best;
+    pk_q_layout bestL;
+    int best_slots = 0;
+    double best_score = 0.0;
+    const int forced = (int)g_opt.forest_slots;
+    for (int slots = ch; slots <= 16; slots++) {  // (one thread per candidate: slots >= ch)
+        if (forced && slots != forced) continue;
+        pk_q_layout L;
+        if (!pk_q_make_layout(F, slots, ch, &L)) continue;
+        pk_q_out out;
+        const int rc = pk_q_build(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(),
+                                  f->h_feat.data(), f->h_thr.data(),
+                                  f->h_miss.empty() ? nullptr : f->h_miss.data(), f->h_p1.data(), L,
+                                  &out);
+        if (rc == PK_E_UNSUPPORTED) continue;
+        if (rc) return rc;
+        // a group costs about the same whatever it holds: trees per group is the figure of
+        // merit; a slot that adds less than a quarter tree per group only adds an idle wave
+        const double score = (double)T / (double)out.n_grp;
+        if (score > best_score + 0.24) {
+            best_score = score;
+            best = std::move(out);
+            bestL = L;
+            best_slots = slots;
+        }
+    }
+    if (!best_slots) return PK_E_UNSUPPORTED;
+    q_free(f);
+    f->q_layout = new pk_q_layout(bestL);
+    f->q_slots = best_slots;
+    f->q_ch = ch;
+    f->q_n_grp = best.n_grp;
+    int rc = q_upload((void **)&f->q_img, best.pairs);
+    if (!rc) rc = q_upload((void **)&f->q_gtab, best.gtab);
+    if (!rc) rc = q_upload((void **)&f->q_ttab, best.ttab);
+    if (!rc) rc = q_upload((void **)&f->q_off, best.qoff);
+    if (!rc) rc = q_upload((void **)&f->q_thr, best.qthr);
+    if (!rc) rc = q_upload((void **)&f->q_par, best.qpar);
+    if (!rc) rc = q_upload((void **)&f->q_lut, best.qlut);
+    return rc;
+}
+
+int pk_forest_q_plan(pk_forest *f)
+{
+    if (f->q_state != 0 && (f->q_opt_slots != g_opt.forest_slots || f->q_opt_ch != g_opt.forest_q_ch)) {
+        q_free(f);
+        f->q_state = 0;
+    }
+    if (f->q_state == 0) {
+        f->q_opt_slots = g_opt.forest_slots;
+        f->q_opt_ch = g_opt.forest_q_ch;
+        const int rc = q_plan_build(f);
+        f->q_state = rc == PK_OK ? 1 : -1;
+        if (rc != PK_OK) q_free(f);
+        if (rc != PK_OK && rc != PK_E_UNSUPPORTED) return rc;
+    }
+    return f->q_state == 1 ? PK_OK : PK_E_UNSUPPORTED;
+}
+
+#define Q_LAUNCH_P(SLOTS, CH, PRUNE)                                                           \
+    do {                                                                                       \
+        int rc__ = q_set_max_lds(forest_q_kernel<SLOTS, CH, PRUNE>, 163840);                   \
+        if (rc__) return rc__;                                                                 \
+        hipLaunchKernelGGL((forest_q_kernel<SLOTS, CH, PRUNE>), dim3(grid), dim3(64 * (SLOTS)), \
+                           163840, ctx->stream, reinterpret_cast<const v4u *>(f->q_img),       \
+                           reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp,              \
+                           reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
+                           L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob,       \
+                           prune_sum,                                                          \
+                           g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
+                           (int)g_opt.forest_dbg, ctx->dbg_buf);                               \
+    } while (0)
+#define Q_CASE(SLOTS, CH)                                                                      \
+    case SLOTS:                                                                                \
+        if (prune_sum > -1e300) Q_LAUNCH_P(SLOTS, CH, true);                                   \
+        else Q_LAUNCH_P(SLOTS, CH, false);                                                     \
+        break;
+
+int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, const uint8_t *d_status,
+                       int64_t c0, int64_t cn, double *d_prob, double prune_sum)
+{
+    if (cn <= 0) return PK_OK;
+    if (f->q_state != 1 || !f->q_layout) {
+        pk_set_error("forest rank kernel launched without a rank image (internal error)");
+        return PK_E_INVALID;
+    }
+    const pk_q_layout &L = *f->q_layout;
+    const int F = f->F;
+    const int64_t n_tiles = (cn + 127) / 128;
+    const size_t qbytes = (size_t)n_tiles * F * 128 * sizeof(unsigned short);
+    if (qbytes > ctx->q_tiles_bytes) {
+        if (ctx->q_tiles) {
+            PK_HIP(hipStreamSynchronize(ctx->stream));
+            PK_HIP(hipFree(ctx->q_tiles));
+            ctx->q_tiles = nullptr;
+            ctx->q_tiles_bytes = 0;
+        }
+        PK_HIP(hipMalloc((void **)&ctx->q_tiles, qbytes));
+        ctx->q_tiles_bytes = qbytes;
+    }
+    {
+        pk_prof_scope prof(ctx, PK_K_QUANT);
+        // enough blocks per feature to fill the chip, few enough that the tables are
+        // loaded for many tiles each
+        int64_t split = (n_tiles + 63) / 64;
+        if (split > 64) split = 64;
+        if (split < 1) split = 1;
+        hipLaunchKernelGGL(quantize_tiles_kernel, dim3((unsigned)F, (unsigned)split), dim3(256), 0,
+                           ctx->stream, tiles, n_tiles, F, f->q_thr, f->q_off, f->q_lut, f->q_par,
+                           ctx->q_tiles);
+        PK_HIP(hipGetLastError());
+    }
+    pk_prof_scope prof(ctx, PK_K_FOREST);
+    const int C = 64 * L.ch;
+    const unsigned grid = (unsigned)((cn + C - 1) / C);
+    if (L.ch == 4) {
+        switch (f->q_slots) {
+            Q_CASE(4, 4) Q_CASE(5, 4) Q_CASE(6, 4) Q_CASE(7, 4) Q_CASE(8, 4) Q_CASE(9, 4) Q_CASE(10, 4)
+            Q_CASE(11, 4) Q_CASE(12, 4) Q_CASE(13, 4) Q_CASE(14, 4) Q_CASE(15, 4) Q_CASE(16, 4)
+        default:
+            pk_set_error("forest rank kernel: %d slots x 4 walks not instantiated", f->q_slots);
+            return PK_E_INVALID;
+        }
+    } else {
+        switch (f->q_slots) {
+            Q_CASE(2, 2) Q_CASE(3, 2) Q_CASE(4, 2) Q_CASE(5, 2) Q_CASE(6, 2) Q_CASE(7, 2) Q_CASE(8, 2)
+            Q_CASE(9, 2) Q_CASE(10, 2) Q_CASE(11, 2) Q_CASE(12, 2) Q_CASE(13, 2) Q_CASE(14, 2)
+            Q_CASE(15, 2) Q_CASE(16, 2)
+        default:
+            pk_set_error("forest rank kernel: %d slots x 2 walks not instantiated", f->q_slots);
+            return PK_E_INVALID;
+        }
+    }
+    PK_HIP(hipGetLastError());
+    return PK_OK;
+}

@@ -1,0 +1,359 @@
+// pk_qimage.hip -- host-side builder of the forest's RANK image (gfx950 only).
+//
+// Serves model.predict_proba(fea)[:, 1] at peakachu/scoreUtils.py:109 (sklearn
+// Tree._apply_dense: `x[feature] <= threshold` goes left, NaN goes where
+// missing_go_to_left says).  The decision `(double)x <= thr` of a float32
+// feature x depends only on how many of the forest's distinct thresholds of
+// that feature lie below x:
+//     t32  = largest float32 <= thr                  ((double)x <= thr  <=>  x <= t32)
+//     k    = index of t32 among the feature's sorted distinct t32 values
+//     r(x) = number of those values that are < x      (0 .. n_f)
+//     x <= t32  <=>  r(x) <= k
+// so the forest kernel can work on 16-bit rank codes instead of float32
+// features (half the LDS tile) and on 4-BYTE nodes (half the LDS image, and both
+// children of a node arrive in one 8-byte LDS read): forest_q_kernel in
+// pk_forest_q.hip.  The codes are made by quantize_tiles_kernel from the float32
+// tiles with the tables built here; exact, not an approximation.
+//
+// Node word (32 bits):  [31:21] rank k   [20] NaN goes left   [19:8] pair   [7:0] feature
+//   pair = index (8-byte units, relative to the tree's first byte) of the node's
+//   child pair: the left child's word, then the right child's word.
+//   A feature code is r(x) << 5 (NaN: 0xFFFF), so `code <= (word >> 16)` is
+//   `r(x) <= k` whatever bits 20..16 hold.
+// Leaf word: rank field 0x7FF (every code compares <=: a leaf always goes left),
+//   bit 20 set (NaN goes left too), pair = the leaf's own block [leaf word][0][float64
+//   value]: a walk that has reached a leaf stays on it however many more levels it is
+//   asked to descend; the kernel walks every tree for a fixed number of levels (its depth)
+//   and reads the value at pair + 1 at the end.
+// Per tree: blocks of the two pure leaves (0.0 / 1.0), the four pairs of two pure
+// leaves, the child pairs of the interior nodes, the blocks of the other leaf values.
+// Trees are position independent (a multiple of 16 bytes each); a group of
+// consecutive trees is a contiguous slice of the image.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+
+#include "pk_common.h"
+
+namespace {
+
+constexpr uint32_t Q_LEAF = (0x7FFu << 21) | (1u << 20);
+constexpr int Q_CONST_PAIRS = 8;  // block(0.0), block(1.0), pairs (0,1) (1,0) (0,0) (1,1)
+
+float q_floor32(double t)
+{
+    float f = (float)t;
+    if ((double)f > t) f = nextafterf(f, -INFINITY);
+    return f;
+}
+
+struct q_tree {
+    int nn;
+    const int32_t *left, *right, *feat;
+    const double *thr, *p1;
+    const uint8_t *miss;
+    int kind(int v) const  // 0 interior, 1 stored leaf, 2 pure 0.0, 3 pure 1.0
+    {
+        if (left[v] != -1) return 0;
+        uint64_t b;
+        memcpy(&b, &p1[v], 8);
+        if (b == 0) return 2;
+        if (p1[v] == 1.0) return 3;
+        return 1;
+    }
+};
+
+// lays one tree out; pairs are appended to `out` (nullptr: only count).  Returns the
+// number of pairs, or -1 (malformed) / -2 (does not fit the 12-bit pair field).
+int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> *out, uint32_t *root,
+                int *depth, std::string *err)
+{
+    const int nn = t.nn;
+    std::vector<int> order, dep((size_t)nn, 0), stack;
+    std::vector<uint8_t> seen((size_t)nn, 0);
+    int maxd = 0;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const int v = stack.back();
+        stack.pop_back();
+        if (v < 0 || v >= nn || seen[(size_t)v]) {
+            if (err) *err = "malformed tree (cycle or child out of range)";
+            return -1;
+        }
+        seen[(size_t)v] = 1;
+        if (dep[(size_t)v] > maxd) maxd = dep[(size_t)v];
+        if (t.left[v] == -1) continue;
+        const int l = t.left[v], r = t.right[v];
+        if (l < 0 || l >= nn || r < 0 || r >= nn || t.feat[v] < 0 || t.feat[v] >= F) {
+            if (err) *err = "malformed tree (bad child or feature index)";
+            return -1;
+        }
+        order.push_back(v);
+        dep[(size_t)l] = dep[(size_t)r] = dep[(size_t)v] + 1;
+        stack.push_back(r);
+        stack.push_back(l);
+    }
+    *depth = maxd;
+    // pair indices: 0,1 block(0.0); 2,3 block(1.0); 4..7 pure/pure pairs; then node pairs;
+    // then the blocks of the stored leaves (one per distinct value)
+    int next = Q_CONST_PAIRS;
+    std::vector<int> pairi((size_t)nn, -1);
+    for (int n : order) {
+        const bool pl = t.kind(t.left[n]) >= 2, pr = t.kind(t.right[n]) >= 2;
+        if (pl && pr) {
+            const int vl = t.kind(t.left[n]) - 2, vr = t.kind(t.right[n]) - 2;
+            pairi[(size_t)n] = 4 + (vl == 0 && vr == 1 ? 0 : vl == 1 && vr == 0 ? 1 : vl == 0 ? 2 : 3);
+        } else {
+            pairi[(size_t)n] = next++;
+        }
+    }
+    std::map<uint64_t, int> vblock;  // stored leaf value bits -> pair index of its block
+    std::vector<std::pair<int, double>> blocks;
+    auto leaf_block = [&](int leaf) {
+        const int k = t.kind(leaf);
+        if (k == 2) return 0;
+        if (k == 3) return 2;
+        uint64_t b;
+        memcpy(&b, &t.p1[leaf], 8);
+        auto it = vblock.find(b);
+        if (it != vblock.end()) return it->second;
+        const int p = next;
+        next += 2;
+        vblock[b] = p;
+        blocks.push_back({p, t.p1[leaf]});
+        return p;
+    };
+    std::vector<int> lblock((size_t)nn, -1);
+    for (int v = 0; v < nn; v++)
+        if (seen[(size_t)v] && t.left[v] == -1) lblock[(size_t)v] = leaf_block(v);
+    if (next & 1) next++;  // whole 16-byte units
+    if (next > 4096) return -2;
+    auto leaf_word = [](int block) { return Q_LEAF | ((uint32_t)block << 8); };
+    auto word_of = [&](int v) -> uint32_t {
+        if (t.left[v] == -1) return leaf_word(lblock[(size_t)v]);
+        const int f = t.feat[v];
+        const float t32 = q_floor32(t.thr[v]);
+        const float *b = tab.qthr.data() + tab.qoff[(size_t)f], *e = tab.qthr.data() + tab.qoff[(size_t)f + 1];
+        const int k = (int)(std::lower_bound(b, e, t32) - b);  // t32 is in the table by construction
+        uint32_t w = ((uint32_t)k << 21) | ((uint32_t)pairi[(size_t)v] << 8) | (uint32_t)f;
+        if (t.miss && t.miss[v]) w |= 1u << 20;
+        return w;
+    };
+    *root = word_of(0);
+    if (!out) return next;
+    const size_t base = out->size();
+    out->resize(base + (size_t)next, make_uint2(0, 0));
+    uint2 *P = out->data() + base;
+    auto put_block = [&](int p, double v) {
+        uint64_t b;
+        memcpy(&b, &v, 8);
+        P[p] = make_uint2(leaf_word(p), 0);
+        P[p + 1] = make_uint2((uint32_t)(b & 0xffffffffu), (uint32_t)(b >> 32));
+    };
+    put_block(0, 0.0);
+    put_block(2, 1.0);
+    P[4] = make_uint2(leaf_word(0), leaf_word(2));
+    P[5] = make_uint2(leaf_word(2), leaf_word(0));
+    P[6] = make_uint2(leaf_word(0), leaf_word(0));
+    P[7] = make_uint2(leaf_word(2), leaf_word(2));
+    for (auto &bk : blocks) put_block(bk.first, bk.second);
+    for (int n : order)
+        if (pairi[(size_t)n] >= Q_CONST_PAIRS)
+            P[pairi[(size_t)n]] = make_uint2(word_of(t.left[n]), word_of(t.right[n]));
+    return next;
+}
+
+}  // namespace
+
+// LDS map of forest_q_kernel<slots, ch>:
+//   [0, HB)                  rank tile of candidates 0..127   ([F][128] u16)
+//   [32768, 32768 + HB)      rank tile of candidates 128..255 (ch == 4 only; needs F <= 128)
+//   dec_off                  early-termination flags: one int per candidate + 3 vote words
+//   val_off                  [slots][64*ch] float64 leaf values parked for the ordered sum
+//   [img_off, 163840)        the group's trees
+bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L)
+{
+    if (F < 1 || F > 255 || slots < 2 || slots > 16 || (ch != 2 && ch != 4)) return false;
+    L->F = F;
+    L->slots = slots;
+    L->ch = ch;
+    L->HB = F * 256;
+    const int C = 64 * ch;
+    int top;
+    if (ch == 4) {
+        if (L->HB > 32768) return false;
+        top = 32768 + L->HB;
+    } else {
+        top = L->HB;
+    }
+    const int dec_bytes = (C * 4 + 16 + 15) & ~15;
+    // the flags go into the gap below the second half tile when they fit there
+    if (ch == 4 && L->HB + dec_bytes <= 32768) {
+        L->dec_off = L->HB;
+    } else {
+        L->dec_off = top;
+        top += dec_bytes;
+    }
+    L->val_off = top;
+    top += slots * C * 8;
+    L->img_off = (top + 15) & ~15;
+    L->cap = 163840 - L->img_off;
+    const int stage = pk_q_stage_regs() * 64 * slots * 16;  // what the register staging moves
+    if (L->cap > stage) L->cap = stage;
+    return L->cap >= 4096;
+}
+
+// Rank tables + tree images + groups for one layout.  PK_E_UNSUPPORTED when the forest
+// does not fit the format (more than 2047 distinct thresholds on a feature, a tree of
+// more than 4096 pairs or larger than the LDS budget).
+int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
+               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
+               const pk_q_layout &L, pk_q_out *out)
+{
+    *out = pk_q_out();
+    if (T <= 0 || F < 1 || F > 255) return PK_E_UNSUPPORTED;
+    // rank tables
+    std::vector<std::vector<float>> per((size_t)F);
+    for (int t = 0; t < T; t++)
+        for (int32_t v = tree_off[t]; v < tree_off[t + 1]; v++)
+            if (left[v] != -1) {
+                if (feat[v] < 0 || feat[v] >= F) {
+                    pk_set_error("forest rank image: tree %d: feature index out of range", t);
+                    return PK_E_INVALID;
+                }
+                if (!(thr[v] == thr[v])) return PK_E_UNSUPPORTED;  // NaN threshold
+                per[(size_t)feat[v]].push_back(q_floor32(thr[v]));
+            }
+    out->qoff.assign((size_t)F + 1, 0);
+    for (int f = 0; f < F; f++) {
+        auto &p = per[(size_t)f];
+        std::sort(p.begin(), p.end());
+        p.erase(std::unique(p.begin(), p.end()), p.end());  // -0.0 == 0.0: one entry
+        if (p.size() > 2047) return PK_E_UNSUPPORTED;
+        out->qoff[(size_t)f + 1] = out->qoff[(size_t)f] + (int32_t)p.size();
+        out->qthr.insert(out->qthr.end(), p.begin(), p.end());
+    }
+    out->qthr.push_back(0.f);
+    // lookup cells for the quantizer: the first guess of r(x) for x in cell c of [lo, hi]
+    out->qlut.assign((size_t)F * PK_Q_CELLS, 0);
+    out->qpar.assign((size_t)F * 2, 0.f);
+    for (int f = 0; f < F; f++) {
+        const float *b = out->qthr.data() + out->qoff[(size_t)f];
+        const int n = out->qoff[(size_t)f + 1] - out->qoff[(size_t)f];
+        float lo = 0.f, inv = 0.f;
+        if (n >= 2 && b[n - 1] > b[0]) {
+            lo = b[0];
+            const double w = ((double)b[n - 1] - (double)b[0]) / (double)PK_Q_CELLS;
+            inv = (float)(1.0 / w);
+            if (!(inv > 0.f) || !std::isfinite(inv)) inv = 0.f;
+        }
+        out->qpar[(size_t)f * 2] = lo;
+        out->qpar[(size_t)f * 2 + 1] = inv;
+        for (int c = 0; c < PK_Q_CELLS; c++) {
+            int r = 0;
+            if (inv > 0.f) {
+                const double edge = (double)lo + (double)c / (double)inv;
+                r = (int)(std::lower_bound(b, b + n, (float)edge) - b);
+            }
+            out->qlut[(size_t)f * PK_Q_CELLS + c] = (uint16_t)r;
+        }
+    }
+    // tree images
+    out->troot.assign((size_t)T, 0);
+    out->tdepth.assign((size_t)T, 0);
+    std::vector<int32_t> toff((size_t)T + 1, 0);  // pairs
+    for (int t = 0; t < T; t++) {
+        const int32_t b = tree_off[t];
+        const q_tree tv{tree_off[t + 1] - b, left + b, right + b, feat + b, thr + b, p1 + b,
+                        miss ? miss + b : nullptr};
+        if (tv.nn <= 0) {
+            pk_set_error("forest rank image: tree %d is empty", t);
+            return PK_E_INVALID;
+        }
+        std::string err;
+        const int np = q_emit_tree(tv, F, *out, &out->pairs, &out->troot[(size_t)t],
+                                   &out->tdepth[(size_t)t], &err);
+        if (np == -1) {
+            pk_set_error("forest rank image: tree %d: %s", t, err.c_str());
+            return PK_E_INVALID;
+        }
+        if (np < 0 || np * 8 > L.cap) return PK_E_UNSUPPORTED;
+        toff[(size_t)t + 1] = toff[(size_t)t] + np;
+    }
+    // groups of consecutive trees: at most `slots`, at most `cap` bytes
+    out->ttab.assign((size_t)T * 4, 0);
+    int t = 0;
+    while (t < T) {
+        int t1 = t + 1;
+        while (t1 < T && t1 - t < L.slots && (toff[(size_t)t1 + 1] - toff[(size_t)t]) * 8 <= L.cap) t1++;
+        out->gtab.push_back(t);
+        out->gtab.push_back(t1 - t);
+        out->gtab.push_back(toff[(size_t)t] / 2);                        // 16-byte units
+        out->gtab.push_back((toff[(size_t)t1] - toff[(size_t)t]) / 2);
+        for (int k = t; k < t1; k++) {
+            out->ttab[(size_t)k * 4] = (toff[(size_t)k] - toff[(size_t)t]) * 8;  // bytes inside the group
+            out->ttab[(size_t)k * 4 + 1] = out->tdepth[(size_t)k];
+            out->ttab[(size_t)k * 4 + 2] = (int32_t)out->troot[(size_t)k];
+        }
+        t = t1;
+    }
+    out->n_grp = (int)(out->gtab.size() / 4);
+    for (int k = 0; k < 2; k++) {  // the kernel reads one entry past the last group
+        out->gtab.push_back(T);
+        out->gtab.push_back(0);
+        out->gtab.push_back(toff[(size_t)T] / 2);
+        out->gtab.push_back(0);
+    }
+    out->pairs.push_back(make_uint2(0, 0));  // the clamped staging loads stay inside
+    out->pairs.push_back(make_uint2(0, 0));
+    return PK_OK;
+}
+
+// Diagnostic / test entry (no device needed): the rank tables and the rank image of a
+// forest, so that tests can quantize and walk on the CPU.
+extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, const int32_t *left,
+                                      const int32_t *right, const int32_t *feat, const double *thr,
+                                      const uint8_t *miss_left, const double *p1, int slots, int ch,
+                                      int32_t *layout8, int32_t *qoff, int64_t cap_thr, float *qthr,
+                                      uint16_t *qlut, float *qpar, int64_t cap_pairs, uint64_t *pairs,
+                                      int64_t *n_pairs, int64_t cap_groups, int32_t *gtab,
+                                      int32_t *n_groups, int32_t *ttab)
+{
+    if (T <= 0 || !tree_off || !left || !right || !feat || !thr || !p1 || !layout8 || !qoff || !qthr ||
+        !qlut || !qpar || !pairs || !n_pairs || !gtab || !n_groups || !ttab) {
+        pk_set_error("pk_debug_forest_qimage: bad arguments");
+        return PK_E_INVALID;
+    }
+    pk_q_layout L;
+    if (!pk_q_make_layout(F, slots, ch, &L)) {
+        pk_set_error("pk_debug_forest_qimage: no LDS layout for F=%d, %d slots, %d walks per lane", F,
+                     slots, ch);
+        return PK_E_UNSUPPORTED;
+    }
+    pk_q_out out;
+    const int rc = pk_q_build(T, F, tree_off, left, right, feat, thr, miss_left, p1, L, &out);
+    if (rc) {
+        if (rc == PK_E_UNSUPPORTED) pk_set_error("pk_debug_forest_qimage: the forest does not fit the rank format");
+        return rc;
+    }
+    if ((int64_t)out.qthr.size() > cap_thr || (int64_t)out.pairs.size() > cap_pairs ||
+        out.n_grp + 2 > cap_groups) {
+        pk_set_error("pk_debug_forest_qimage: output buffers too small");
+        return PK_E_NOMEM;
+    }
+    const int32_t lay[8] = {L.HB, L.ch, L.dec_off, L.val_off, L.img_off, L.cap, L.slots, L.F};
+    memcpy(layout8, lay, sizeof(lay));
+    memcpy(qoff, out.qoff.data(), out.qoff.size() * sizeof(int32_t));
+    memcpy(qthr, out.qthr.data(), out.qthr.size() * sizeof(float));
+    memcpy(qlut, out.qlut.data(), out.qlut.size() * sizeof(uint16_t));
+    memcpy(qpar, out.qpar.data(), out.qpar.size() * sizeof(float));
+    for (size_t i = 0; i < out.pairs.size(); i++)
+        pairs[i] = ((uint64_t)out.pairs[i].y << 32) | out.pairs[i].x;
+    *n_pairs = (int64_t)out.pairs.size();
+    memcpy(gtab, out.gtab.data(), out.gtab.size() * sizeof(int32_t));
+    *n_groups = out.n_grp;
+    memcpy(ttab, out.ttab.data(), out.ttab.size() * sizeof(int32_t));
+    return PK_OK;
+}

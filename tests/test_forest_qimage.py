@@ -1,0 +1,227 @@
+"""The forest's RANK image (peakachu_amd/csrc/pk_qimage.hip), checked on the CPU.
+
+forest_q_kernel (the default forest kernel; model.predict_proba at
+peakachu/scoreUtils.py:109) walks 4-byte nodes over 16-bit rank codes.  Here the
+float32 features are quantized with the library's own tables exactly as
+quantize_tiles_kernel does it (lookup cell -> first guess -> exact scan), a numpy
+model of the LDS receives each group of trees as the kernel stages it, and the
+walk follows the kernel's rules: pair address = tree base + ((word >> 8) & 0xfff)
+* 8, `code <= (word >> 16)` picks the left word (a NaN code goes left only
+where bit 20 says so), a fixed number of levels per tree, the float64 value
+behind the final pair.  The result must equal the oracle's predict_proba bit
+for bit, i.e. the golden sklearn outputs.  No GPU needed.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import golden_io as gio
+from oracle import oracle_np as onp
+from peakachu_amd import _lib
+from peakachu_amd.forest import FlatForest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LDS_BYTES = 163840
+CELLS = 1024
+
+
+def build_qimage(fo, F, slots, ch):
+    L = _lib.load()
+    T = int(len(fo["tree_off"]) - 1)
+    nn = int(fo["tree_off"][-1])
+    lay = np.zeros(8, np.int32)
+    qoff = np.zeros(F + 1, np.int32)
+    qthr = np.zeros(nn + 8, np.float32)
+    qlut = np.zeros(F * CELLS, np.uint16)
+    qpar = np.zeros(F * 2, np.float32)
+    cap_pairs = 2 * nn + 64 * T + 64
+    pairs = np.zeros(cap_pairs, np.uint64)
+    npairs = C.c_int64()
+    gtab = np.zeros(4 * (T + 4), np.int32)
+    ng = C.c_int32()
+    ttab = np.zeros(4 * T, np.int32)
+    rc = L.pk_debug_forest_qimage(
+        T, F, np.ascontiguousarray(fo["tree_off"], np.int32),
+        np.ascontiguousarray(fo["left"], np.int32), np.ascontiguousarray(fo["right"], np.int32),
+        np.ascontiguousarray(fo["feat"], np.int32), np.ascontiguousarray(fo["thr"], np.float64),
+        np.ascontiguousarray(fo["miss_left"], np.uint8), np.ascontiguousarray(fo["p1"], np.float64),
+        slots, ch, lay, qoff, qthr.size, qthr, qlut, qpar, cap_pairs, pairs, C.byref(npairs),
+        T + 4, gtab, C.byref(ng), ttab)
+    if rc != 0:
+        return rc, _lib.last_error()
+    return 0, dict(lay=lay, qoff=qoff, qthr=qthr, qlut=qlut.reshape(F, CELLS), qpar=qpar.reshape(F, 2),
+                   pairs=pairs[:npairs.value], gtab=gtab[:4 * (ng.value + 2)].reshape(-1, 4),
+                   n_grp=ng.value, ttab=ttab.reshape(T, 4))
+
+
+def quantize(img, X):
+    """q_code of pk_forest_q.hip, per feature column: lookup cell, then the exact scan."""
+    N, F = X.shape
+    codes = np.zeros((N, F), np.uint16)
+    steps = 0
+    with np.errstate(invalid="ignore", over="ignore"):
+        for f in range(F):
+            thr = img["qthr"][img["qoff"][f]:img["qoff"][f + 1]]
+            n = thr.size
+            lo, inv = img["qpar"][f]
+            x = X[:, f]
+            cf = (x - lo) * inv                              # float32 arithmetic, like the kernel
+            cf = np.where(np.isnan(cf), np.float32(0), cf)   # fmaxf(NaN, 0) = 0
+            cf = np.minimum(np.maximum(cf, np.float32(0)), np.float32(CELLS - 1))
+            r = img["qlut"][f][cf.astype(np.int64)].astype(np.int64)
+            for _ in range(n + 1):
+                down = (r > 0) & (thr[np.maximum(r - 1, 0)] >= x) if n else np.zeros(N, bool)
+                if not down.any():
+                    break
+                r -= down
+                steps += int(down.sum())
+            for _ in range(n + 1):
+                up = (r < n) & (thr[np.minimum(r, max(n - 1, 0))] < x) if n else np.zeros(N, bool)
+                if not up.any():
+                    break
+                r += up
+                steps += int(up.sum())
+            # the definition: number of distinct thresholds below x
+            assert np.array_equal(r[~np.isnan(x)], np.searchsorted(thr, x[~np.isnan(x)], side="left"))
+            codes[:, f] = np.where(np.isnan(x), 0xFFFF, r << 5)
+    return codes, steps
+
+
+def walk_qimage(img, codes, T):
+    HB, ch, dec_off, val_off, img_off, cap, slots, F = [int(v) for v in img["lay"]]
+    N = codes.shape[0]
+    acc = np.zeros(N, np.float64)
+    assert img_off % 16 == 0 and img_off + cap <= LDS_BYTES
+    assert dec_off >= HB and val_off >= HB and img_off >= val_off + slots * 64 * ch * 8
+    if ch == 4:
+        assert HB <= 32768 and val_off >= 32768 + HB
+    for g in range(img["n_grp"]):
+        t0, nt, off, nu = [int(v) for v in img["gtab"][g]]
+        assert 0 < nt <= slots and nu * 16 <= cap
+        lds = np.full(LDS_BYTES // 8, 0xDEADBEEFDEADBEEF, np.uint64)
+        lds[img_off // 8: img_off // 8 + 2 * nu] = img["pairs"][2 * off: 2 * (off + nu)]
+        for t in range(t0, t0 + nt):
+            toff, depth, root, _ = [int(v) for v in img["ttab"][t]]
+            assert toff % 16 == 0 and toff < nu * 16
+            tbase = img_off + toff
+            w = np.full(N, np.uint32(root & 0xFFFFFFFF), np.uint32)
+            for _ in range(depth):
+                f = (w & 0xFF).astype(np.int64)
+                assert f.max() < F
+                xv = codes[np.arange(N), f].astype(np.uint32)
+                ca = tbase + ((w >> 8) & 0xFFF).astype(np.int64) * 8
+                assert (ca + 8 <= img_off + nu * 16).all()
+                pr = lds[ca // 8]
+                gl = (xv <= (w >> 16)) | ((xv == 0xFFFF) & ((w >> 20) & 1 != 0))
+                w = np.where(gl, pr & np.uint64(0xFFFFFFFF), pr >> np.uint64(32)).astype(np.uint32)
+            va = tbase + (((w >> 8) & 0xFFF).astype(np.int64) + 1) * 8
+            acc += lds[va // 8].view(np.float64)  # tree order: sklearn's sequential sum
+    return acc / float(T)
+
+
+@pytest.mark.parametrize("slots,ch", [(2, 2), (5, 2), (13, 2), (16, 2), (4, 4), (9, 4), (16, 4)])
+@pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
+def test_rank_walk_equals_sklearn_golden(tag, slots, ch):
+    z = gio.load("g2_forest_%s.npz" % tag)
+    X = np.ascontiguousarray(gio.load("g2_forest_plain.npz")["X"], np.float32)
+    assert np.isnan(X).any()
+    fo = gio.forest(z)
+    F = X.shape[1]
+    rc, img = build_qimage(fo, F, slots, ch)
+    assert rc == 0, img
+    codes, _ = quantize(img, X)
+    T = len(fo["tree_off"]) - 1
+    p = walk_qimage(img, codes, T)
+    assert np.array_equal(gio.bits(p), gio.bits(z["p"]))
+
+
+@pytest.mark.parametrize("name,slots,ch", [("forest_w5_t100.npz", 9, 4), ("forest_w5_t100.npz", 13, 2),
+                                           ("forest_w6_t100.npz", 8, 2)])
+def test_rank_image_of_benchmark_forests(name, slots, ch):
+    ff = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", name))
+    fo = {k: getattr(ff, k) for k in FlatForest.FIELDS}
+    rc, img = build_qimage(fo, ff.F, slots, ch)
+    assert rc == 0, img
+    rng = np.random.default_rng(5)
+    X = rng.random((400, ff.F)).astype(np.float32)
+    X[::7] = (X[::7] > 0.5).astype(np.float32)          # exact 0 / 1 features (min-max scaling makes them)
+    # values sitting exactly on thresholds, one ulp below and one above
+    thr_all = img["qthr"][: img["qoff"][-1]]
+    pick = rng.integers(0, thr_all.size, 300)
+    for k, i in enumerate(pick):
+        f = int(np.searchsorted(img["qoff"], i, side="right") - 1)
+        t = thr_all[i]
+        X[100 + k % 300, f] = [t, np.nextafter(t, np.float32(-np.inf)), np.nextafter(t, np.float32(np.inf))][k % 3]
+    X[5, 3] = np.nan
+    X[11, :] = np.nan
+    X[12, 0] = np.inf
+    X[13, 1] = -np.inf
+    X[14, 2] = -0.0
+    codes, steps = quantize(img, X)
+    # the lookup cells do their job: the exact scan moves less than two steps per value
+    assert steps < 2 * X.size
+    p = walk_qimage(img, codes, ff.T)
+    ref = onp.predict(fo, X)
+    assert np.array_equal(gio.bits(p), gio.bits(ref))
+    gt = img["gtab"][: img["n_grp"]]
+    assert gt[0, 0] == 0 and (gt[1:, 0] == gt[:-1, 0] + gt[:-1, 1]).all()
+    assert gt[-1, 0] + gt[-1, 1] == ff.T
+    assert (img["ttab"][:, 1] == 20).all()
+    assert (np.diff(img["qoff"]) <= 2047).all()
+
+
+def test_rank_image_degenerate_trees():
+    """One-leaf trees, stumps with two pure leaves, equal-valued pure siblings, stored leaves,
+    negative and repeated thresholds."""
+    tree_off = [0, 1, 4, 7, 12, 13]
+    left = np.array([-1, 1, -1, -1, 1, -1, -1, 1, 3, -1, -1, -1, -1], np.int32)
+    right = np.array([-1, 2, -1, -1, 2, -1, -1, 2, 4, -1, -1, -1, -1], np.int32)
+    feat = np.array([0, 2, 0, 0, 1, 0, 0, 0, 2, 0, 0, 0, 0], np.int32)
+    thr = np.array([0, 0.5, 0, 0, -0.25, 0, 0, 0.75, 0.5, 0, 0, 0, 0], np.float64)
+    p1 = np.array([0.25, 0, 0.0, 1.0, 0, 1.0, 1.0, 0, 0, 0.5, 0.0, 0.0, 1.0], np.float64)
+    fo = dict(tree_off=np.array(tree_off, np.int32), left=left, right=right, feat=feat, thr=thr,
+              miss_left=np.zeros(13, np.uint8), p1=p1)
+    fo["miss_left"][7] = 1
+    F = 3
+    rng = np.random.default_rng(2)
+    X = (rng.random((200, F)) * 2 - 0.5).astype(np.float32)
+    X[3, 0] = np.nan
+    X[4, 2] = np.nan
+    X[5, 2] = 0.5
+    X[6, 1] = -0.25
+    ref = onp.predict(fo, X)
+    for slots, ch in ((2, 2), (4, 4), (16, 2)):
+        rc, img = build_qimage(fo, F, slots, ch)
+        assert rc == 0, img
+        assert list(img["ttab"][:, 1]) == [0, 1, 1, 2, 0]
+        assert list(np.diff(img["qoff"])) == [1, 1, 1]      # 0.5 on feature 2 is used twice: one rank
+        codes, _ = quantize(img, X)
+        p = walk_qimage(img, codes, 5)
+        assert np.array_equal(gio.bits(p), gio.bits(ref))
+
+
+def test_rank_image_limits():
+    # more than 2047 distinct thresholds on one feature: the rank format does not apply
+    n = 2100
+    left = np.full(2 * n + 1, -1, np.int32)
+    right = np.full(2 * n + 1, -1, np.int32)
+    feat = np.zeros(2 * n + 1, np.int32)
+    thr = np.zeros(2 * n + 1)
+    p1 = np.zeros(2 * n + 1)
+    for i in range(n):          # a comb: node 2i has leaf 2i+1 on the left and node 2i+2 on the right
+        left[2 * i] = 2 * i + 1
+        right[2 * i] = 2 * i + 2
+        thr[2 * i] = i / n
+        p1[2 * i + 1] = i % 2
+    fo = dict(tree_off=np.array([0, 2 * n + 1], np.int32), left=left, right=right, feat=feat, thr=thr,
+              miss_left=np.zeros(2 * n + 1, np.uint8), p1=p1)
+    rc, msg = build_qimage(fo, 4, 4, 2)
+    assert rc != 0 and "rank format" in msg
+    # malformed forests are errors, not "unsupported"
+    bad = dict(tree_off=np.array([0, 3], np.int32), left=np.array([1, 0, -1], np.int32),
+               right=np.array([2, 2, -1], np.int32), feat=np.zeros(3, np.int32), thr=np.zeros(3),
+               miss_left=np.zeros(3, np.uint8), p1=np.zeros(3))
+    rc, msg = build_qimage(bad, 4, 4, 2)
+    assert rc != 0 and "malformed" in msg

@@ -73,12 +73,15 @@ def test_config2_properties(config2):
     # invariance to chunking and kernel variant
     old = {k: _lib.load().pk_get_option(k.encode())
            for k in ("chunk", "forest_slots", "forest_lds", "forest_pipe", "forest_pipe_slots",
-                     "extract_pair", "overlap", "forest_img")}
+                     "extract_pair", "overlap", "forest_img", "forest_q", "forest_q_ch")}
     try:
-        for opts in (dict(chunk=65536), dict(chunk=1000003), dict(forest_slots=8), dict(forest_slots=5),
-                     dict(forest_img=0, forest_pipe=0),
-                     dict(forest_img=0, forest_pipe=0, forest_slots=4), dict(forest_img=0, forest_pipe=2),
-                     dict(forest_img=0, forest_pipe=2, forest_pipe_slots=4),
+        for opts in (dict(chunk=65536), dict(chunk=1000003), dict(forest_slots=12), dict(forest_q_ch=2),
+                     dict(forest_q_ch=2, forest_slots=7),
+                     dict(forest_q=0), dict(forest_q=0, forest_slots=5), dict(forest_q=0, forest_img=2),
+                     dict(forest_q=0, forest_img=0, forest_pipe=0),
+                     dict(forest_q=0, forest_img=0, forest_pipe=0, forest_slots=4),
+                     dict(forest_q=0, forest_img=0, forest_pipe=2),
+                     dict(forest_q=0, forest_img=0, forest_pipe=2, forest_pipe_slots=4),
                      dict(forest_lds=0), dict(extract_pair=0), dict(overlap=1), dict(overlap=1, chunk=65536)):
             for k, v in opts.items():
                 _lib.set_option(k, v)

@@ -60,29 +60,37 @@ def _extract_golden(name):
 
 
 @pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
-@pytest.mark.parametrize("ilp,lds,slots,pipe,img", [(4, 0, 8, 0, 0), (1, 0, 8, 0, 0), (8, 0, 8, 0, 0),
-                                                    (4, 160, 8, 0, 0), (4, 160, 4, 0, 0), (4, 160, 2, 0, 0),
-                                                    (4, 160, 6, 0, 0), (4, 2, 8, 0, 0), (4, 1, 4, 0, 0),
-                                                    (4, 160, 8, 1, 0), (4, 160, 4, 4, 0), (4, 160, 8, 6, 0),
-                                                    (4, 160, 0, 0, 1), (4, 160, 2, 0, 1), (4, 160, 4, 0, 1),
-                                                    (4, 160, 5, 0, 1), (4, 160, 6, 0, 1), (4, 160, 7, 0, 1),
-                                                    (4, 160, 8, 0, 1),
-                                                    (4, 160, 0, 0, 2), (4, 160, 2, 0, 2), (4, 160, 3, 0, 2),
-                                                    (4, 160, 7, 0, 2), (4, 160, 12, 0, 2), (4, 160, 16, 0, 2)])
-def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img):
+@pytest.mark.parametrize("ilp,lds,slots,pipe,img,q", [
+    (4, 0, 8, 0, 0, 0), (1, 0, 8, 0, 0, 0), (8, 0, 8, 0, 0, 0),
+    (4, 160, 8, 0, 0, 0), (4, 160, 4, 0, 0, 0), (4, 160, 2, 0, 0, 0),
+    (4, 160, 6, 0, 0, 0), (4, 2, 8, 0, 0, 0), (4, 1, 4, 0, 0, 0),
+    (4, 160, 8, 1, 0, 0), (4, 160, 4, 4, 0, 0), (4, 160, 8, 6, 0, 0),
+    (4, 160, 0, 0, 1, 0), (4, 160, 2, 0, 1, 0), (4, 160, 4, 0, 1, 0),
+    (4, 160, 5, 0, 1, 0), (4, 160, 6, 0, 1, 0), (4, 160, 7, 0, 1, 0),
+    (4, 160, 8, 0, 1, 0),
+    (4, 160, 0, 0, 2, 0), (4, 160, 2, 0, 2, 0), (4, 160, 3, 0, 2, 0),
+    (4, 160, 7, 0, 2, 0), (4, 160, 12, 0, 2, 0), (4, 160, 16, 0, 2, 0),
+    # q = walks per lane of the rank kernel + 1 (1 = automatic)
+    (4, 160, 0, 0, 1, 1), (4, 160, 4, 0, 1, 5), (4, 160, 9, 0, 1, 5), (4, 160, 16, 0, 1, 5),
+    (4, 160, 0, 0, 1, 3), (4, 160, 2, 0, 1, 3), (4, 160, 3, 0, 1, 3), (4, 160, 13, 0, 1, 3),
+    (4, 160, 16, 0, 1, 3)])
+def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img, q):
     """Every forest kernel variant: nodes via L2 (lds=0) with 1/4/8 chains per
     lane; trees streamed through LDS in barrier-separated groups with 2..8
     tree slots; a tree buffer so small (1-2 KiB) that some trees are walked
     from global memory; the barrier-free per-wave pipeline (pipe>0: number of
     waves, 1 = as many as fit); the LDS-image kernel (img=1: fixed-depth walks
     over absolute LDS addresses; img=2: one wave per tree, two walks per lane)
-    with automatic and forced slot counts."""
+    with automatic and forced slot counts; the rank kernel (q>0: 16-bit rank
+    codes, 4-byte nodes, 2 or 4 walks per lane) with automatic and forced shapes."""
     z = gio.load("g2_forest_%s.npz" % tag)
     X = gio.load("g2_forest_plain.npz")["X"]
     old = {k: _lib.load().pk_get_option(k.encode())
            for k in ("forest_ilp", "forest_lds", "forest_slots", "forest_pipe", "forest_pipe_slots",
-                     "forest_img")}
+                     "forest_img", "forest_q", "forest_q_ch")}
     _lib.set_option("forest_img", img)
+    _lib.set_option("forest_q", 1 if q else 0)
+    _lib.set_option("forest_q_ch", q - 1 if q > 1 else 0)
     _lib.set_option("forest_ilp", ilp)
     _lib.set_option("forest_lds", lds)
     _lib.set_option("forest_slots", slots)
@@ -343,8 +351,9 @@ def big_tree_forest(F, seed, n_small=5, big_nodes=60001):
                 p1=np.array(cols["p1"], np.float64), F=np.int32(F))
 
 
-@pytest.mark.parametrize("lds,pipe,img", [(160, 0, 0), (160, 2, 0), (0, 0, 0), (160, 0, 1)])
-def test_giant_tree_side_table(hip_lib, lds, pipe, img):
+@pytest.mark.parametrize("lds,pipe,img,q", [(160, 0, 0, 0), (160, 2, 0, 0), (0, 0, 0, 0), (160, 0, 1, 0),
+                                            (160, 0, 1, 1)])
+def test_giant_tree_side_table(hip_lib, lds, pipe, img, q):
     F = 121
     fo = big_tree_forest(F, seed=9)
     rng = np.random.default_rng(3)
@@ -352,7 +361,9 @@ def test_giant_tree_side_table(hip_lib, lds, pipe, img):
     X[5, :] = np.nan
     X[11, rng.integers(0, F, 40)] = np.nan
     ref = onp.predict(fo, X)
-    old = {k: _lib.load().pk_get_option(k.encode()) for k in ("forest_lds", "forest_pipe", "forest_img")}
+    old = {k: _lib.load().pk_get_option(k.encode())
+           for k in ("forest_lds", "forest_pipe", "forest_img", "forest_q")}
+    _lib.set_option("forest_q", q)      # q=1: the tree exceeds the rank format -> falls back
     _lib.set_option("forest_lds", lds)
     _lib.set_option("forest_pipe", pipe)
     _lib.set_option("forest_img", img)  # img=1: the tree does not fit the LDS -> falls back
