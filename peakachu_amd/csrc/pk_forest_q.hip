@@ -38,7 +38,7 @@ typedef __attribute__((address_space(3))) u64 lds_u64;
 constexpr int Q_HALF1 = 32768;  // LDS offset of the rank tile of candidates 128..255
 
 // ------------------------------------------------------------------------
-// float32 feature tiles [tile][F][128] -> rank codes [tile][F][128] u16.
+// float32 feature tiles [tile][F][128] -> rank codes [tile][F][64][2] u16.
 // Block (f, s): the tables of feature f in LDS, every s-th group of tiles.
 // code = r(x) << 5 with r(x) = number of the feature's distinct thresholds
 // below x (exact: the lookup cell only gives the first guess), NaN -> 0xFFFF.
@@ -70,9 +70,11 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int64_t t = (int64_t)blockIdx.y * 4 + wave; t < n_tiles; t += (int64_t)gridDim.y * 4) {
+        // dword j of a row holds the codes of candidates j (low half) and j + 64 (high half):
+        // the two walks of a lane read the same LDS bank, different lanes different banks
         const size_t row = ((size_t)t * F + f) * 128;
-        const float2 x = reinterpret_cast<const float2 *>(tiles + row)[lane];
-        const unsigned c0 = q_code(x.x, thr, lut, n, lo, inv), c1 = q_code(x.y, thr, lut, n, lo, inv);
+        const float xa = tiles[row + lane], xb = tiles[row + 64 + lane];
+        const unsigned c0 = q_code(xa, thr, lut, n, lo, inv), c1 = q_code(xb, thr, lut, n, lo, inv);
         reinterpret_cast<unsigned *>(qtiles + row)[lane] = c0 | (c1 << 16);
     }
 }
@@ -88,7 +90,7 @@ __device__ __forceinline__ unsigned q_pair_index(unsigned w)
 }
 
 // one level of CH walks of one tree.  Walk c belongs to candidate lane + 64 c of the
-// workgroup: code address = (c >> 1) * 32 KiB + feature * 256 + ((lane + 64 (c & 1)) * 2)
+// workgroup: code address = (c >> 1) * 32 KiB + feature * 256 + lane * 4 + (c & 1) * 2
 template <int CH, bool WITH_NAN, bool ALL_LEFT>
 __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsigned lk0, unsigned lk1)
 {
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(64 * SLOTS) void forest_q_kernel(
     const int lane = tid & 63;
     const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HB = F * 256;
-    const unsigned lk0 = (unsigned)lane << 1, lk1 = lk0 + 128u;
+    const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
     const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
     if (!lds_at_zero && tid == 0 && stamps) stamps[65535] = 2;
 
