@@ -226,7 +226,7 @@ struct pk_q_out {
     std::vector<int32_t> ttab;    // per tree: byte offset inside its group, depth, root word, 0
     int n_grp = 0;
 };
-inline int pk_q_stage_regs() { return 16; }  // uint4 staging registers per thread of forest_q_kernel
+inline int pk_q_stage_regs() { return 8; }  // uint4 staging registers per thread (1024) of forest_q_kernel
 bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L);
 int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
                const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,

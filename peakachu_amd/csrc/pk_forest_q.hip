@@ -69,13 +69,28 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     const float lo = qpar[2 * f], inv = qpar[2 * f + 1];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int64_t t = (int64_t)blockIdx.y * 4 + wave; t < n_tiles; t += (int64_t)gridDim.y * 4) {
-        // dword j of a row holds the codes of candidates j (low half) and j + 64 (high half):
-        // the two walks of a lane read the same LDS bank, different lanes different banks
-        const size_t row = ((size_t)t * F + f) * 128;
-        const float xa = tiles[row + lane], xb = tiles[row + 64 + lane];
-        const unsigned c0 = q_code(xa, thr, lut, n, lo, inv), c1 = q_code(xb, thr, lut, n, lo, inv);
-        reinterpret_cast<unsigned *>(qtiles + row)[lane] = c0 | (c1 << 16);
+    // a wave converts four rows per trip: the loads of all four are in flight together
+    // (one row per trip left the kernel waiting for HBM: 1.55 ms per 5.6 M candidates)
+    const int64_t stride = (int64_t)gridDim.y * 4;
+    for (int64_t t = (int64_t)blockIdx.y * 4 + wave; t < n_tiles; t += 4 * stride) {
+        float xa[4], xb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t tk = t + k * stride;
+            const size_t row = ((size_t)(tk < n_tiles ? tk : t) * F + f) * 128;
+            xa[k] = tiles[row + lane];
+            xb[k] = tiles[row + 64 + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t tk = t + k * stride;
+            if (tk >= n_tiles) break;
+            // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
+            // half): the two walks of a lane read the same LDS bank, different lanes different banks
+            const size_t row = ((size_t)tk * F + f) * 128;
+            const unsigned c0 = q_code(xa[k], thr, lut, n, lo, inv), c1 = q_code(xb[k], thr, lut, n, lo, inv);
+            reinterpret_cast<unsigned *>(qtiles + row)[lane] = c0 | (c1 << 16);
+        }
     }
 }
 
@@ -140,22 +155,23 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
         if (u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q;            \
     }
 
-// One workgroup = 64 * CH candidates and SLOTS waves; wave s walks tree s of the group
-// for all of them (CH walks per lane).  Trees arrive group by group: the next group
-// travels global -> VGPR during the walk and VGPR -> LDS behind the barrier.
-template <int SLOTS, int CH, bool PRUNE>
-__global__ __launch_bounds__(64 * SLOTS) void forest_q_kernel(
+// One workgroup = 64 * CH candidates and 16 waves; wave s walks tree s of the group for
+// all of them (CH walks per lane); waves beyond the group's trees only help to move
+// data (tile load, staging of the next group: the LDS store path wants all SIMDs busy).
+// Trees arrive group by group: the next group travels global -> VGPR during the walk and
+// VGPR -> LDS behind the barrier.
+constexpr int Q_THREADS = 1024;
+template <int CH, bool PRUNE>
+__global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp,
     const int4 *__restrict__ ttab, int T, int F, int dec_off, int val_off, int img_off,
     const unsigned short *__restrict__ qtiles, const uint8_t *__restrict__ status, int64_t c0,
     int64_t cn, double *__restrict__ prob, double prune_sum, int warm_ahead, int dbg,
     long long *__restrict__ stamps)
 {
-    constexpr int THREADS = 64 * SLOTS;
+    constexpr int THREADS = Q_THREADS;
     constexpr int C = 64 * CH;
-    // staging registers: enough for a group that fills the LDS (the host never plans more
-    // than 16 per thread: pk_q_stage_regs)
-    constexpr int PFN = (160 + SLOTS - 1) / SLOTS < 16 ? (160 + SLOTS - 1) / SLOTS : 16;
+    constexpr int PFN = 8;  // staging registers: 8 x 1024 x 16 B = 128 KiB per group (pk_q_stage_regs)
     static_assert(THREADS >= C, "one thread per candidate owns the ordered sum");
     extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
     const int tid = threadIdx.x;
@@ -344,7 +360,7 @@ static int q_plan_build(pk_forest *f)
     int best_slots = 0;
     double best_score = 0.0;
     const int forced = (int)g_opt.forest_slots;
-    for (int slots = ch; slots <= 16; slots++) {  // (one thread per candidate: slots >= ch)
+    for (int slots = 2; slots <= 16; slots++) {  // slots = trees per group at most
         if (forced && slots != forced) continue;
         pk_q_layout L;
         if (!pk_q_make_layout(F, slots, ch, &L)) continue;
@@ -398,11 +414,11 @@ int pk_forest_q_plan(pk_forest *f)
     return f->q_state == 1 ? PK_OK : PK_E_UNSUPPORTED;
 }
 
-#define Q_LAUNCH_P(SLOTS, CH, PRUNE)                                                           \
+#define Q_LAUNCH_P(CH, PRUNE)                                                                  \
     do {                                                                                       \
-        int rc__ = q_set_max_lds(forest_q_kernel<SLOTS, CH, PRUNE>, 163840);                   \
+        int rc__ = q_set_max_lds(forest_q_kernel<CH, PRUNE>, 163840);                          \
         if (rc__) return rc__;                                                                 \
-        hipLaunchKernelGGL((forest_q_kernel<SLOTS, CH, PRUNE>), dim3(grid), dim3(64 * (SLOTS)), \
+        hipLaunchKernelGGL((forest_q_kernel<CH, PRUNE>), dim3(grid), dim3(Q_THREADS),          \
                            163840, ctx->stream, reinterpret_cast<const v4u *>(f->q_img),       \
                            reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp,              \
                            reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
@@ -411,11 +427,11 @@ int pk_forest_q_plan(pk_forest *f)
                            g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
                            (int)g_opt.forest_dbg, ctx->dbg_buf);                               \
     } while (0)
-#define Q_CASE(SLOTS, CH)                                                                      \
-    case SLOTS:                                                                                \
-        if (prune_sum > -1e300) Q_LAUNCH_P(SLOTS, CH, true);                                   \
-        else Q_LAUNCH_P(SLOTS, CH, false);                                                     \
-        break;
+#define Q_LAUNCH(CH)                                                                           \
+    do {                                                                                       \
+        if (prune_sum > -1e300) Q_LAUNCH_P(CH, true);                                          \
+        else Q_LAUNCH_P(CH, false);                                                            \
+    } while (0)
 
 int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, const uint8_t *d_status,
                        int64_t c0, int64_t cn, double *d_prob, double prune_sum)
@@ -454,24 +470,8 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
     pk_prof_scope prof(ctx, PK_K_FOREST);
     const int C = 64 * L.ch;
     const unsigned grid = (unsigned)((cn + C - 1) / C);
-    if (L.ch == 4) {
-        switch (f->q_slots) {
-            Q_CASE(4, 4) Q_CASE(5, 4) Q_CASE(6, 4) Q_CASE(7, 4) Q_CASE(8, 4) Q_CASE(9, 4) Q_CASE(10, 4)
-            Q_CASE(11, 4) Q_CASE(12, 4) Q_CASE(13, 4) Q_CASE(14, 4) Q_CASE(15, 4) Q_CASE(16, 4)
-        default:
-            pk_set_error("forest rank kernel: %d slots x 4 walks not instantiated", f->q_slots);
-            return PK_E_INVALID;
-        }
-    } else {
-        switch (f->q_slots) {
-            Q_CASE(2, 2) Q_CASE(3, 2) Q_CASE(4, 2) Q_CASE(5, 2) Q_CASE(6, 2) Q_CASE(7, 2) Q_CASE(8, 2)
-            Q_CASE(9, 2) Q_CASE(10, 2) Q_CASE(11, 2) Q_CASE(12, 2) Q_CASE(13, 2) Q_CASE(14, 2)
-            Q_CASE(15, 2) Q_CASE(16, 2)
-        default:
-            pk_set_error("forest rank kernel: %d slots x 2 walks not instantiated", f->q_slots);
-            return PK_E_INVALID;
-        }
-    }
+    if (L.ch == 4) Q_LAUNCH(4);
+    else Q_LAUNCH(2);
     PK_HIP(hipGetLastError());
     return PK_OK;
 }

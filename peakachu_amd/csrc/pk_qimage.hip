@@ -208,7 +208,7 @@ bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L)
     top += slots * C * 8;
     L->img_off = (top + 15) & ~15;
     L->cap = 163840 - L->img_off;
-    const int stage = pk_q_stage_regs() * 64 * slots * 16;  // what the register staging moves
+    const int stage = pk_q_stage_regs() * 1024 * 16;  // what the register staging moves per group
     if (L->cap > stage) L->cap = stage;
     return L->cap >= 4096;
 }
