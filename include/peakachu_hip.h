@@ -195,15 +195,15 @@ int pk_comm_gatherv_bytes(pk_comm *, const void *send, int64_t nbytes, int64_t *
  * walks per lane, so that tests can quantize and walk on the CPU.
  * layout8 = {half-tile bytes, walks per lane, flag area offset, value area offset,
  * image offset, image capacity, slots, F}; qoff = F+1 offsets into qthr (per feature the
- * sorted distinct float32 thresholds); qlut = [F][1024] lookup cells, qpar = [F][2]
- * (lower end, cells per unit); pairs = the trees' 8-byte child pairs; gtab = 4 ints per
+ * sorted distinct float32 thresholds); qlut = [F][4096] lookup cells (thresholds in
+ * lower cells | thresholds in the cell << 16), qpar = [F][2] (lower end, cells per unit); pairs = the trees' 8-byte child pairs; gtab = 4 ints per
  * group (first tree, trees, offset and size in 16-byte units); ttab = 4 ints per tree
  * (byte offset inside its group, levels to walk, root word, 0). */
 int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, const int32_t *left,
                            const int32_t *right, const int32_t *feat, const double *thr,
                            const uint8_t *miss_left, const double *p1, int slots, int ch,
                            int32_t *layout8, int32_t *qoff, int64_t cap_thr, float *qthr,
-                           uint16_t *qlut, float *qpar, int64_t cap_pairs, uint64_t *pairs,
+                           uint32_t *qlut, float *qpar, int64_t cap_pairs, uint64_t *pairs,
                            int64_t *n_pairs, int64_t cap_groups, int32_t *gtab,
                            int32_t *n_groups, int32_t *ttab);
 

@@ -21,6 +21,7 @@ _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 _u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 _u16p = np.ctypeslib.ndpointer(np.uint16, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 _vp = C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/peakachu_hip.h declares
@@ -65,7 +66,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_int32), _u64p, _i32p]),
     "pk_debug_forest_qimage": (C.c_int, [C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p, _u8p,
                                          _f64p, C.c_int, C.c_int, _i32p, _i32p, C.c_int64, _f32p,
-                                         _u16p, _f32p, C.c_int64, _u64p, C.POINTER(C.c_int64),
+                                         _u32p, _f32p, C.c_int64, _u64p, C.POINTER(C.c_int64),
                                          C.c_int64, _i32p, C.POINTER(C.c_int32), _i32p]),
     "pk_comm_unique_id": (C.c_int, [_u8p]),
     "pk_comm_create": (_vp, [C.c_int, C.c_int, C.c_int, _u8p]),

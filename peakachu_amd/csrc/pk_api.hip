@@ -232,6 +232,9 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_q_ch")) {
         if (value != 0 && value != 2 && value != 4) return PK_E_INVALID;
         g_opt.forest_q_ch = value;
+    } else if (!strcmp(name, "forest_q_wpt")) {
+        if (value < 0 || value > 2) return PK_E_INVALID;
+        g_opt.forest_q_wpt = value;
     } else if (!strcmp(name, "forest_img")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
         g_opt.forest_img = value;
@@ -262,6 +265,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_img")) return g_opt.forest_img;
     if (!strcmp(name, "forest_q")) return g_opt.forest_q;
     if (!strcmp(name, "forest_q_ch")) return g_opt.forest_q_ch;
+    if (!strcmp(name, "forest_q_wpt")) return g_opt.forest_q_wpt;
     return -1;
 }
 

@@ -76,6 +76,7 @@ struct pk_options {
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
     int64_t forest_q = 1;       // rank-quantised tiles + 4-byte nodes (forest_q_kernel) when the forest fits
     int64_t forest_q_ch = 0;    // walks per lane of forest_q_kernel: 0 = auto (4 when F <= 128), 2, 4
+    int64_t forest_q_wpt = 0;   // waves per tree with 4 walks per lane: 0 = auto (2), 1, 2
     int64_t forest_img = 1;     // LDS-image forest kernel (fixed-depth walks, absolute LDS addresses)
                                 // when every tree fits; 0 = the grouped preorder kernel
 };
@@ -164,12 +165,12 @@ struct pk_forest {
     // rank image (forest_q_kernel): 0 = not tried, 1 = built, -1 = does not apply
     int q_state = 0;
     int q_slots = 0, q_ch = 0, q_n_grp = 0;
-    int64_t q_opt_slots = -1, q_opt_ch = -1;
+    int64_t q_opt_slots = -1, q_opt_ch = -1, q_opt_wpt = -1;
     struct pk_q_layout *q_layout = nullptr;
     uint4 *q_img = nullptr;        // device: tree images
     int32_t *q_gtab = nullptr, *q_ttab = nullptr, *q_off = nullptr;  // device
     float *q_thr = nullptr, *q_par = nullptr;                        // device
-    uint16_t *q_lut = nullptr;                                       // device
+    uint32_t *q_lut = nullptr;                                       // device
 };
 // ---- LDS-image forest (pk_image.hip builds it, pk_forest_img.hip walks it) ----
 struct pk_img_layout {
@@ -206,7 +207,7 @@ int pk_launch_forest_img(pk_device_ctx *, pk_forest *f, const float *tiles, cons
                          int64_t c0, int64_t cn, double *d_prob, double prune_sum);
 
 // ---- rank image (pk_qimage.hip builds it, pk_forest_q.hip quantizes tiles and walks it) ----
-#define PK_Q_CELLS 1024
+#define PK_Q_CELLS 4096
 struct pk_q_layout {
     int F, slots, ch;   // ch = walks per lane: 2 (128 candidates per workgroup) or 4 (256)
     int HB;             // bytes of a half tile: [F][128] u16
@@ -217,7 +218,7 @@ struct pk_q_layout {
 struct pk_q_out {
     std::vector<float> qthr;      // per feature: sorted distinct float32 thresholds, laid end to end
     std::vector<int32_t> qoff;    // F+1 offsets into qthr
-    std::vector<uint16_t> qlut;   // [F][PK_Q_CELLS] first guess of the rank for a lookup cell
+    std::vector<uint32_t> qlut;   // [F][PK_Q_CELLS]: thresholds below the cell | thresholds in it << 16
     std::vector<float> qpar;      // [F][2]: lower end of the cells, cells per unit
     std::vector<uint2> pairs;     // tree images (8-byte child pairs), tree after tree
     std::vector<uint32_t> troot;  // per tree: the word a walk starts from
@@ -226,6 +227,16 @@ struct pk_q_out {
     std::vector<int32_t> ttab;    // per tree: byte offset inside its group, depth, root word, 0
     int n_grp = 0;
 };
+// lookup cell of a feature value: the SAME float operations on the host (tables) and on
+// the device (quantizer); monotone in x, which is all the tables rely on
+__host__ __device__ inline int pk_q_cell(float x, float lo, float inv)
+{
+    float cf = (x - lo) * inv;  // +-inf, or NaN from inf * 0: fmaxf / fminf return the other operand
+    cf = fminf(fmaxf(cf, 0.f), (float)(PK_Q_CELLS - 1));
+    return (int)cf;
+}
+// rebuilds qlut from the cell of every threshold (qcell, parallel to qthr)
+void pk_q_fill_lut(pk_q_out *out, int F, const std::vector<int32_t> &qcell);
 inline int pk_q_stage_regs() { return 8; }  // uint4 staging registers per thread (1024) of forest_q_kernel
 bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L);
 int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,

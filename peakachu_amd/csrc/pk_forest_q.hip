@@ -41,27 +41,34 @@ constexpr int Q_HALF1 = 32768;  // LDS offset of the rank tile of candidates 128
 // float32 feature tiles [tile][F][128] -> rank codes [tile][F][64][2] u16.
 // Block (f, s): the tables of feature f in LDS, every s-th group of tiles.
 // code = r(x) << 5 with r(x) = number of the feature's distinct thresholds
-// below x (exact: the lookup cell only gives the first guess), NaN -> 0xFFFF.
+// below x (exact: the lookup cell settles all thresholds but the few -- mostly
+// none or one -- that share the cell, which are compared), NaN -> 0xFFFF.
 // ------------------------------------------------------------------------
-__device__ __forceinline__ unsigned q_code(float x, const float *thr, const unsigned short *lut, int n,
-                                           float lo, float inv)
+__device__ __forceinline__ unsigned q_code(float x, const float *thr, const unsigned *lut, float lo, float inv)
 {
     if (x != x) return 0xFFFFu;
-    float cf = (x - lo) * inv;  // +-inf, or NaN from inf * 0: fmaxf / fminf return the other operand
-    cf = fminf(fmaxf(cf, 0.f), (float)(PK_Q_CELLS - 1));
-    int r = lut[(int)cf];
-    while (r > 0 && thr[r - 1] >= x) r--;
-    while (r < n && thr[r] < x) r++;
-    return (unsigned)r << 5;
+    const unsigned e = lut[pk_q_cell(x, lo, inv)];
+    unsigned r = e & 0xFFFFu;             // thresholds in lower cells: all below x
+    for (unsigned k = e >> 16; k != 0 && thr[r] < x; k--) r++;  // those of x's own cell, ascending
+    return r << 5;
+}
+
+// the cell of every threshold, computed where the quantizer computes the cells of the features
+__global__ void q_cells_kernel(const float *__restrict__ qthr, const int32_t *__restrict__ qoff,
+                               const float *__restrict__ qpar, int F, int32_t *__restrict__ cells)
+{
+    const int f = blockIdx.x;
+    for (int i = qoff[f] + threadIdx.x; i < qoff[f + 1]; i += blockDim.x)
+        cells[i] = pk_q_cell(qthr[i], qpar[2 * f], qpar[2 * f + 1]);
 }
 
 __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     const float *__restrict__ tiles, int64_t n_tiles, int F, const float *__restrict__ qthr,
-    const int32_t *__restrict__ qoff, const unsigned short *__restrict__ qlut,
+    const int32_t *__restrict__ qoff, const unsigned *__restrict__ qlut,
     const float *__restrict__ qpar, unsigned short *__restrict__ qtiles)
 {
     __shared__ float thr[2048];
-    __shared__ unsigned short lut[PK_Q_CELLS];
+    __shared__ unsigned lut[PK_Q_CELLS];
     const int f = blockIdx.x;
     const int o = qoff[f], n = qoff[f + 1] - o;
     for (int i = threadIdx.x; i < n; i += 256) thr[i] = qthr[o + i];
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
             // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
             // half): the two walks of a lane read the same LDS bank, different lanes different banks
             const size_t row = ((size_t)tk * F + f) * 128;
-            const unsigned c0 = q_code(xa[k], thr, lut, n, lo, inv), c1 = q_code(xb[k], thr, lut, n, lo, inv);
+            const unsigned c0 = q_code(xa[k], thr, lut, lo, inv), c1 = q_code(xb[k], thr, lut, lo, inv);
             reinterpret_cast<unsigned *>(qtiles + row)[lane] = c0 | (c1 << 16);
         }
     }
@@ -106,7 +113,8 @@ __device__ __forceinline__ unsigned q_pair_index(unsigned w)
 
 // one level of CH walks of one tree.  Walk c belongs to candidate lane + 64 c of the
 // workgroup: code address = (c >> 1) * 32 KiB + feature * 256 + lane * 4 + (c & 1) * 2
-template <int CH, bool WITH_NAN, bool ALL_LEFT>
+// HB0: index of the rank tile (0 or 1) walks 0 and 1 read; walks 2 and 3 read the next one
+template <int CH, int HB0, bool WITH_NAN, bool ALL_LEFT>
 __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsigned lk0, unsigned lk1)
 {
     unsigned xv[CH];
@@ -115,7 +123,7 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
     for (int c = 0; c < CH; c++) {
         // byte 0 <- lane constant, byte 1 <- the word's feature byte
         const unsigned xa = __builtin_amdgcn_perm(w[c], (c & 1) ? lk1 : lk0, 0x0c0c0400u);
-        xv[c] = *LDS_AT(const lds_u16, xa + (c >> 1) * Q_HALF1);
+        xv[c] = *LDS_AT(const lds_u16, xa + (HB0 + (c >> 1)) * Q_HALF1);
         pr[c] = *LDS_AT(const lds_u64, tbase + (q_pair_index(w[c]) << 3));
     }
 #pragma unroll
@@ -127,7 +135,7 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
     }
 }
 
-template <int CH, bool WITH_NAN, bool ALL_LEFT = false>
+template <int CH, int HB0, bool WITH_NAN, bool ALL_LEFT = false>
 __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase, unsigned lk0,
                                        unsigned lk1, double (&v)[CH])
 {
@@ -136,10 +144,10 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
     for (int c = 0; c < CH; c++) w[c] = root;
     int d = depth;
     for (; d >= 2; d -= 2) {  // two levels per trip: a taken branch costs an instruction refetch
-        q_level<CH, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-        q_level<CH, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+        q_level<CH, HB0, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+        q_level<CH, HB0, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
     }
-    if (d) q_level<CH, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+    if (d) q_level<CH, HB0, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
 #pragma unroll
     for (int c = 0; c < CH; c++)  // the leaf's float64 value follows its pair
         v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index(w[c]) + 1) << 3));
@@ -155,13 +163,15 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
         if (u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q;            \
     }
 
-// One workgroup = 64 * CH candidates and 16 waves; wave s walks tree s of the group for
-// all of them (CH walks per lane); waves beyond the group's trees only help to move
-// data (tile load, staging of the next group: the LDS store path wants all SIMDs busy).
-// Trees arrive group by group: the next group travels global -> VGPR during the walk and
-// VGPR -> LDS behind the barrier.
+// One workgroup = 64 * CH candidates and 16 waves.  WPT = 1: wave s walks tree s of the
+// group for all candidates (CH walks per lane).  WPT = 2 (CH = 4, at most 8 trees per
+// group): waves 2s and 2s+1 walk tree s, one for each rank tile (2 walks per lane), so
+// that all 16 waves walk.  Waves without a tree only help to move data (tile load,
+// staging of the next group: the LDS store path wants all SIMDs busy).  Trees arrive
+// group by group: the next group travels global -> VGPR during the walk and VGPR -> LDS
+// behind the barrier.
 constexpr int Q_THREADS = 1024;
-template <int CH, bool PRUNE>
+template <int CH, int WPT, bool PRUNE>
 __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp,
     const int4 *__restrict__ ttab, int T, int F, int dec_off, int val_off, int img_off,
@@ -172,11 +182,14 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     constexpr int THREADS = Q_THREADS;
     constexpr int C = 64 * CH;
     constexpr int PFN = 8;  // staging registers: 8 x 1024 x 16 B = 128 KiB per group (pk_q_stage_regs)
+    constexpr int NCH = CH / WPT;  // walks per lane of one wave
     static_assert(THREADS >= C, "one thread per candidate owns the ordered sum");
+    static_assert(WPT == 1 || (WPT == 2 && CH == 4), "two waves per tree = one per rank tile");
     extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = wave / WPT, sub = wave % WPT;  // tree slot; which part of the candidates
     const int HB = F * 256;
     const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
     const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
@@ -197,13 +210,13 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             *LDS_AT(lds_u4, o < HB ? o : o - HB + Q_HALF1) = src[i];
         }
     }
-    // every wave walks for all C candidates: walk c of a lane = candidate lane + 64 c
-    unsigned stc[CH];
-    bool act[CH];
+    // walk c of a lane = candidate lane + 64 (NCH * sub + c) of the workgroup
+    unsigned stc[NCH];
+    bool act[NCH];
     bool any_nan = false;
 #pragma unroll
-    for (int c = 0; c < CH; c++) {
-        const int64_t loc = cbase + lane + 64 * c;
+    for (int c = 0; c < NCH; c++) {
+        const int64_t loc = cbase + lane + 64 * (NCH * sub + c);
         stc[c] = loc < cn ? status[c0 + loc] : 0;
         act[c] = stc[c] != 0 && lds_at_zero;
         any_nan = any_nan || stc[c] == 2;
@@ -253,23 +266,31 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
                 for (int line = tid; line < F * CH; line += THREADS)
                     warm_sink += reinterpret_cast<const unsigned *>(qtiles + (size_t)ahead * C * F)[line * 32];
         }
-        bool walk[CH];
+        bool walk[NCH];
         bool any_walk = false;
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            walk[c] = act[c] && (!PRUNE || *LDS_AT(lds_i32, dec_off + 4 * (lane + 64 * c)) == 0);
+        for (int c = 0; c < NCH; c++) {
+            walk[c] = act[c] &&
+                      (!PRUNE || *LDS_AT(lds_i32, dec_off + 4 * (lane + 64 * (NCH * sub + c))) == 0);
             any_walk = any_walk || walk[c];
         }
         if (slot < gt && !(dbg & 2) && __any(any_walk)) {
-            double v[CH];
+            double v[NCH];
             const unsigned tbase = (unsigned)(img_off + tt.x);
+            const unsigned root = (unsigned)tt.z;
             // lanes without a live candidate walk along (their values are not stored)
-            if (dbg & 8) q_walk<CH, false, true>((unsigned)tt.z, tt.y, tbase, lk0, lk1, v);  // wrong results
-            else if (wave_nan) q_walk<CH, true>((unsigned)tt.z, tt.y, tbase, lk0, lk1, v);
-            else q_walk<CH, false>((unsigned)tt.z, tt.y, tbase, lk0, lk1, v);
+            if (WPT == 2 && sub) {  // the second rank tile (the tile index is an immediate offset)
+                if (wave_nan) q_walk<NCH, 1, true>(root, tt.y, tbase, lk0, lk1, v);
+                else q_walk<NCH, 1, false>(root, tt.y, tbase, lk0, lk1, v);
+            } else {
+                if (dbg & 8) q_walk<NCH, 0, false, true>(root, tt.y, tbase, lk0, lk1, v);  // wrong results
+                else if (wave_nan) q_walk<NCH, 0, true>(root, tt.y, tbase, lk0, lk1, v);
+                else q_walk<NCH, 0, false>(root, tt.y, tbase, lk0, lk1, v);
+            }
 #pragma unroll
-            for (int c = 0; c < CH; c++)
-                if (walk[c]) *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * c) * 8) = v[c];
+            for (int c = 0; c < NCH; c++)
+                if (walk[c])
+                    *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * (NCH * sub + c)) * 8) = v[c];
         }
         Q_STAMP(1);
         __syncthreads();  // every walk of the group is done: the trees may be overwritten
@@ -360,7 +381,10 @@ static int q_plan_build(pk_forest *f)
     int best_slots = 0;
     double best_score = 0.0;
     const int forced = (int)g_opt.forest_slots;
-    for (int slots = 2; slots <= 16; slots++) {  // slots = trees per group at most
+    // (4 walks per lane: at most 8 trees per group, so that two waves can share a tree and
+    // all 16 walk; measured faster than 9 trees on 9 of 16 waves)
+    const int max_slots = (ch == 4 && g_opt.forest_q_wpt != 1) ? 8 : 16;
+    for (int slots = 2; slots <= max_slots; slots++) {  // slots = trees per group at most
         if (forced && slots != forced) continue;
         pk_q_layout L;
         if (!pk_q_make_layout(F, slots, ch, &L)) continue;
@@ -393,19 +417,38 @@ static int q_plan_build(pk_forest *f)
     if (!rc) rc = q_upload((void **)&f->q_off, best.qoff);
     if (!rc) rc = q_upload((void **)&f->q_thr, best.qthr);
     if (!rc) rc = q_upload((void **)&f->q_par, best.qpar);
-    if (!rc) rc = q_upload((void **)&f->q_lut, best.qlut);
-    return rc;
+    if (rc) return rc;
+    // the lookup table must agree with the cells the DEVICE computes: take the thresholds'
+    // cells from the device (they equal the host's unless the two float units disagree)
+    {
+        int32_t *d_cells = nullptr;
+        std::vector<int32_t> cells(best.qthr.size(), 0);
+        PK_HIP(hipMalloc((void **)&d_cells, cells.size() * sizeof(int32_t)));
+        PK_HIP(hipMemset(d_cells, 0, cells.size() * sizeof(int32_t)));
+        hipLaunchKernelGGL(q_cells_kernel, dim3((unsigned)F), dim3(256), 0, 0, f->q_thr, f->q_off, f->q_par,
+                           F, d_cells);
+        hipError_t e = hipMemcpy(cells.data(), d_cells, cells.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+        hipFree(d_cells);
+        if (e != hipSuccess) {
+            pk_set_error("forest rank image: reading the lookup cells back failed: %s", hipGetErrorString(e));
+            return PK_E_HIP;
+        }
+        pk_q_fill_lut(&best, F, cells);
+    }
+    return q_upload((void **)&f->q_lut, best.qlut);
 }
 
 int pk_forest_q_plan(pk_forest *f)
 {
-    if (f->q_state != 0 && (f->q_opt_slots != g_opt.forest_slots || f->q_opt_ch != g_opt.forest_q_ch)) {
+    if (f->q_state != 0 && (f->q_opt_slots != g_opt.forest_slots || f->q_opt_ch != g_opt.forest_q_ch ||
+                            f->q_opt_wpt != g_opt.forest_q_wpt)) {
         q_free(f);
         f->q_state = 0;
     }
     if (f->q_state == 0) {
         f->q_opt_slots = g_opt.forest_slots;
         f->q_opt_ch = g_opt.forest_q_ch;
+        f->q_opt_wpt = g_opt.forest_q_wpt;
         const int rc = q_plan_build(f);
         f->q_state = rc == PK_OK ? 1 : -1;
         if (rc != PK_OK) q_free(f);
@@ -414,11 +457,11 @@ int pk_forest_q_plan(pk_forest *f)
     return f->q_state == 1 ? PK_OK : PK_E_UNSUPPORTED;
 }
 
-#define Q_LAUNCH_P(CH, PRUNE)                                                                  \
+#define Q_LAUNCH_P(CH, WPT, PRUNE)                                                             \
     do {                                                                                       \
-        int rc__ = q_set_max_lds(forest_q_kernel<CH, PRUNE>, 163840);                          \
+        int rc__ = q_set_max_lds(forest_q_kernel<CH, WPT, PRUNE>, 163840);                     \
         if (rc__) return rc__;                                                                 \
-        hipLaunchKernelGGL((forest_q_kernel<CH, PRUNE>), dim3(grid), dim3(Q_THREADS),          \
+        hipLaunchKernelGGL((forest_q_kernel<CH, WPT, PRUNE>), dim3(grid), dim3(Q_THREADS),     \
                            163840, ctx->stream, reinterpret_cast<const v4u *>(f->q_img),       \
                            reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp,              \
                            reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
@@ -427,10 +470,10 @@ int pk_forest_q_plan(pk_forest *f)
                            g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
                            (int)g_opt.forest_dbg, ctx->dbg_buf);                               \
     } while (0)
-#define Q_LAUNCH(CH)                                                                           \
+#define Q_LAUNCH(CH, WPT)                                                                      \
     do {                                                                                       \
-        if (prune_sum > -1e300) Q_LAUNCH_P(CH, true);                                          \
-        else Q_LAUNCH_P(CH, false);                                                            \
+        if (prune_sum > -1e300) Q_LAUNCH_P(CH, WPT, true);                                     \
+        else Q_LAUNCH_P(CH, WPT, false);                                                       \
     } while (0)
 
 int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, const uint8_t *d_status,
@@ -470,8 +513,11 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
     pk_prof_scope prof(ctx, PK_K_FOREST);
     const int C = 64 * L.ch;
     const unsigned grid = (unsigned)((cn + C - 1) / C);
-    if (L.ch == 4) Q_LAUNCH(4);
-    else Q_LAUNCH(2);
+    // two waves per tree when the groups leave half the waves without one
+    const bool wpt2 = L.ch == 4 && f->q_slots <= 8 && g_opt.forest_q_wpt != 1;
+    if (L.ch == 4 && wpt2) Q_LAUNCH(4, 2);
+    else if (L.ch == 4) Q_LAUNCH(4, 1);
+    else Q_LAUNCH(2, 1);
     PK_HIP(hipGetLastError());
     return PK_OK;
 }

@@ -213,6 +213,21 @@ bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L)
     return L->cap >= 4096;
 }
 
+void pk_q_fill_lut(pk_q_out *out, int F, const std::vector<int32_t> &qcell)
+{
+    out->qlut.assign((size_t)F * PK_Q_CELLS, 0);
+    for (int f = 0; f < F; f++) {
+        const int o = out->qoff[(size_t)f], n = out->qoff[(size_t)f + 1] - o;
+        uint32_t *lut = out->qlut.data() + (size_t)f * PK_Q_CELLS;
+        int i = 0;
+        for (int c = 0; c < PK_Q_CELLS; c++) {
+            const int below = i;
+            while (i < n && qcell[(size_t)o + i] <= c) i++;  // (cells of sorted thresholds never decrease)
+            lut[c] = (uint32_t)below | ((uint32_t)(i - below) << 16);
+        }
+    }
+}
+
 // Rank tables + tree images + groups for one layout.  PK_E_UNSUPPORTED when the forest
 // does not fit the format (more than 2047 distinct thresholds on a feature, a tree of
 // more than 4096 pairs or larger than the LDS budget).
@@ -244,9 +259,11 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
         out->qthr.insert(out->qthr.end(), p.begin(), p.end());
     }
     out->qthr.push_back(0.f);
-    // lookup cells for the quantizer: the first guess of r(x) for x in cell c of [lo, hi]
-    out->qlut.assign((size_t)F * PK_Q_CELLS, 0);
+    // lookup cells for the quantizer.  cell(x) = pk_q_cell(x) is monotone in x, so every
+    // threshold in a lower cell is below x and every threshold in a higher cell is not:
+    // r(x) = thresholds in lower cells + those of x's own cell that are below x.
     out->qpar.assign((size_t)F * 2, 0.f);
+    std::vector<int32_t> qcell(out->qthr.size(), 0);
     for (int f = 0; f < F; f++) {
         const float *b = out->qthr.data() + out->qoff[(size_t)f];
         const int n = out->qoff[(size_t)f + 1] - out->qoff[(size_t)f];
@@ -259,15 +276,9 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
         }
         out->qpar[(size_t)f * 2] = lo;
         out->qpar[(size_t)f * 2 + 1] = inv;
-        for (int c = 0; c < PK_Q_CELLS; c++) {
-            int r = 0;
-            if (inv > 0.f) {
-                const double edge = (double)lo + (double)c / (double)inv;
-                r = (int)(std::lower_bound(b, b + n, (float)edge) - b);
-            }
-            out->qlut[(size_t)f * PK_Q_CELLS + c] = (uint16_t)r;
-        }
+        for (int i = 0; i < n; i++) qcell[(size_t)out->qoff[(size_t)f] + i] = pk_q_cell(b[i], lo, inv);
     }
+    pk_q_fill_lut(out, F, qcell);
     // tree images
     out->troot.assign((size_t)T, 0);
     out->tdepth.assign((size_t)T, 0);
@@ -325,7 +336,7 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
                                       const int32_t *right, const int32_t *feat, const double *thr,
                                       const uint8_t *miss_left, const double *p1, int slots, int ch,
                                       int32_t *layout8, int32_t *qoff, int64_t cap_thr, float *qthr,
-                                      uint16_t *qlut, float *qpar, int64_t cap_pairs, uint64_t *pairs,
+                                      uint32_t *qlut, float *qpar, int64_t cap_pairs, uint64_t *pairs,
                                       int64_t *n_pairs, int64_t cap_groups, int32_t *gtab,
                                       int32_t *n_groups, int32_t *ttab)
 {
@@ -355,7 +366,7 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
     memcpy(layout8, lay, sizeof(lay));
     memcpy(qoff, out.qoff.data(), out.qoff.size() * sizeof(int32_t));
     memcpy(qthr, out.qthr.data(), out.qthr.size() * sizeof(float));
-    memcpy(qlut, out.qlut.data(), out.qlut.size() * sizeof(uint16_t));
+    memcpy(qlut, out.qlut.data(), out.qlut.size() * sizeof(uint32_t));
     memcpy(qpar, out.qpar.data(), out.qpar.size() * sizeof(float));
     for (size_t i = 0; i < out.pairs.size(); i++)
         pairs[i] = ((uint64_t)out.pairs[i].y << 32) | out.pairs[i].x;

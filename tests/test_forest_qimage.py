@@ -24,7 +24,7 @@ from peakachu_amd.forest import FlatForest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LDS_BYTES = 163840
-CELLS = 1024
+CELLS = 4096
 
 
 def build_qimage(fo, F, slots, ch):
@@ -34,7 +34,7 @@ def build_qimage(fo, F, slots, ch):
     lay = np.zeros(8, np.int32)
     qoff = np.zeros(F + 1, np.int32)
     qthr = np.zeros(nn + 8, np.float32)
-    qlut = np.zeros(F * CELLS, np.uint16)
+    qlut = np.zeros(F * CELLS, np.uint32)
     qpar = np.zeros(F * 2, np.float32)
     cap_pairs = 2 * nn + 64 * T + 64
     pairs = np.zeros(cap_pairs, np.uint64)
@@ -57,7 +57,8 @@ def build_qimage(fo, F, slots, ch):
 
 
 def quantize(img, X):
-    """q_code of pk_forest_q.hip, per feature column: lookup cell, then the exact scan."""
+    """q_code of pk_forest_q.hip, per feature column: the lookup cell settles the thresholds
+    of lower cells; those of the value's own cell are compared one by one."""
     N, F = X.shape
     codes = np.zeros((N, F), np.uint16)
     steps = 0
@@ -67,24 +68,23 @@ def quantize(img, X):
             n = thr.size
             lo, inv = img["qpar"][f]
             x = X[:, f]
-            cf = (x - lo) * inv                              # float32 arithmetic, like the kernel
+            cf = (x - lo) * inv                              # float32 arithmetic, like pk_q_cell
             cf = np.where(np.isnan(cf), np.float32(0), cf)   # fmaxf(NaN, 0) = 0
             cf = np.minimum(np.maximum(cf, np.float32(0)), np.float32(CELLS - 1))
-            r = img["qlut"][f][cf.astype(np.int64)].astype(np.int64)
-            for _ in range(n + 1):
-                down = (r > 0) & (thr[np.maximum(r - 1, 0)] >= x) if n else np.zeros(N, bool)
-                if not down.any():
-                    break
-                r -= down
-                steps += int(down.sum())
-            for _ in range(n + 1):
-                up = (r < n) & (thr[np.minimum(r, max(n - 1, 0))] < x) if n else np.zeros(N, bool)
+            e = img["qlut"][f][cf.astype(np.int64)]
+            r = (e & 0xFFFF).astype(np.int64)
+            k = (e >> 16).astype(np.int64)
+            assert (r + k <= n).all()
+            while True:
+                up = (k > 0) & (thr[np.minimum(r, max(n - 1, 0))] < x) if n else np.zeros(N, bool)
                 if not up.any():
                     break
                 r += up
+                k -= up
                 steps += int(up.sum())
             # the definition: number of distinct thresholds below x
-            assert np.array_equal(r[~np.isnan(x)], np.searchsorted(thr, x[~np.isnan(x)], side="left"))
+            ok = ~np.isnan(x)
+            assert np.array_equal(r[ok], np.searchsorted(thr, x[ok], side="left"))
             codes[:, f] = np.where(np.isnan(x), 0xFFFF, r << 5)
     return codes, steps
 
@@ -160,8 +160,8 @@ def test_rank_image_of_benchmark_forests(name, slots, ch):
     X[13, 1] = -np.inf
     X[14, 2] = -0.0
     codes, steps = quantize(img, X)
-    # the lookup cells do their job: the exact scan moves less than two steps per value
-    assert steps < 2 * X.size
+    # the lookup cells do their job: less than one threshold comparison per value
+    assert steps < X.size
     p = walk_qimage(img, codes, ff.T)
     ref = onp.predict(fo, X)
     assert np.array_equal(gio.bits(p), gio.bits(ref))

@@ -105,6 +105,50 @@ def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img, q):
     assert np.array_equal(gio.bits(p), gio.bits(z["p"]))
 
 
+@pytest.mark.parametrize("name,opts", [("forest_w5_t100.npz", {}), ("forest_w5_t100.npz", {"forest_q_wpt": 1}),
+                                       ("forest_w5_t100.npz", {"forest_q_ch": 2}),
+                                       ("forest_w5_t100.npz", {"forest_q": 0}),
+                                       ("forest_w6_t100.npz", {}), ("forest_w6_t100.npz", {"forest_slots": 5})])
+def test_forest_threshold_edges(hip_lib, name, opts):
+    """Features sitting exactly on split thresholds, one ulp below and above, +-inf, -0.0
+    and NaN, on the benchmark forests: the rank quantizer (lookup cells + exact compare)
+    and the 4-byte-node walk must decide every split like sklearn's float compare."""
+    import os
+    from peakachu_amd.forest import FlatForest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ff = FlatForest.load(os.path.join(root, "peakachu_amd", "data", name))
+    fo = {k: getattr(ff, k) for k in FlatForest.FIELDS}
+    rng = np.random.default_rng(11)
+    N = 3000
+    X = rng.random((N, ff.F)).astype(np.float32)
+    inner = np.flatnonzero(ff.left != -1)
+    t32 = ff.thr[inner].astype(np.float32)
+    t32 = np.where(t32.astype(np.float64) > ff.thr[inner], np.nextafter(t32, np.float32(-np.inf)), t32)
+    for k in range(N):
+        for j in rng.choice(inner.size, 12, replace=False):
+            t = t32[j]
+            X[k, ff.feat[inner[j]]] = (t, np.nextafter(t, np.float32(-np.inf)),
+                                       np.nextafter(t, np.float32(np.inf)))[(k + j) % 3]
+    X[5, 3] = np.nan
+    X[6, :] = np.nan
+    X[7, 0] = np.inf
+    X[8, 1] = -np.inf
+    X[9, 2] = -0.0
+    X[10, :] = 0.0
+    X[11, :] = 1.0
+    ref = onp.predict(fo, X)
+    old = {k: _lib.load().pk_get_option(k.encode()) for k in opts}
+    try:
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        hf = _lib.HipForest(ff)
+        p = hf.predict(X)
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+    assert np.array_equal(gio.bits(p), gio.bits(ref))
+
+
 def _g3_matrix(z):
     raw = gio.sym_matrix(z, "R")
     mode = str(z["mode"])
