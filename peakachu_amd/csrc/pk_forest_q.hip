@@ -135,27 +135,15 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
     }
 }
 
-// issue priority of the wave (0..3): rotated while walking so that no wave is favoured
-__device__ __forceinline__ void q_setprio(int p)
-{
-    switch (p & 3) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-
 template <int CH, int HB0, bool WITH_NAN, bool ALL_LEFT = false>
 __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase, unsigned lk0,
-                                       unsigned lk1, double (&v)[CH], int prio)
+                                       unsigned lk1, double (&v)[CH])
 {
     unsigned w[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) w[c] = root;
     int d = depth;
     for (; d >= 2; d -= 2) {  // two levels per trip: a taken branch costs an instruction refetch
-        if (prio >= 0) q_setprio(prio++);
         q_level<CH, HB0, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
         q_level<CH, HB0, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
     }
@@ -290,24 +278,20 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             double v[NCH];
             const unsigned tbase = (unsigned)(img_off + tt.x);
             const unsigned root = (unsigned)tt.z;
-            // experiment (dbg bit 5 / 6): rotate the waves' issue priorities during the walk,
-            // youngest waves first (bit 6: oldest first)
-            const int prio = (dbg & 32) ? 3 - (wave >> 2) : (dbg & 64) ? (wave >> 2) : -1;
             // lanes without a live candidate walk along (their values are not stored)
             if (WPT == 2 && sub) {  // the second rank tile (the tile index is an immediate offset)
-                if (wave_nan) q_walk<NCH, 1, true>(root, tt.y, tbase, lk0, lk1, v, prio);
-                else q_walk<NCH, 1, false>(root, tt.y, tbase, lk0, lk1, v, prio);
+                if (wave_nan) q_walk<NCH, 1, true>(root, tt.y, tbase, lk0, lk1, v);
+                else q_walk<NCH, 1, false>(root, tt.y, tbase, lk0, lk1, v);
             } else {
-                if (dbg & 8) q_walk<NCH, 0, false, true>(root, tt.y, tbase, lk0, lk1, v, prio);  // wrong results
-                else if (wave_nan) q_walk<NCH, 0, true>(root, tt.y, tbase, lk0, lk1, v, prio);
-                else q_walk<NCH, 0, false>(root, tt.y, tbase, lk0, lk1, v, prio);
+                if (dbg & 8) q_walk<NCH, 0, false, true>(root, tt.y, tbase, lk0, lk1, v);  // wrong results
+                else if (wave_nan) q_walk<NCH, 0, true>(root, tt.y, tbase, lk0, lk1, v);
+                else q_walk<NCH, 0, false>(root, tt.y, tbase, lk0, lk1, v);
             }
 #pragma unroll
             for (int c = 0; c < NCH; c++)
                 if (walk[c])
                     *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * (NCH * sub + c)) * 8) = v[c];
         }
-        if (dbg & 96) __builtin_amdgcn_s_setprio(0);
         Q_STAMP(1);
         __syncthreads();  // every walk of the group is done: the trees may be overwritten
         Q_STAMP(2);
