@@ -10,10 +10,13 @@ threshold/compact [-> RCCL gather of the scored pixels when N > 1]) over the
 candidate list, with matrix, forest and candidates already resident in HBM.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scores
-its own synthetic chromosome (weak scaling; chromosomes shard embarrassingly,
-peakachu/score_genome.py:46-84) and rank 0 collects the scored pixels with
-one RCCL gather.  torch.distributed (gloo) is used only for the rendezvous,
-the barriers and the max-over-ranks of the timings.
+its own synthetic chromosome (weak scaling, the default; chromosomes shard
+embarrassingly, peakachu/score_genome.py:46-84) or, with --scaling strong, its
+batch-aligned block of ONE chromosome's candidate list (matrix and forest
+replicated); rank 0 collects the scored pixels with one RCCL gather.
+torch.distributed (gloo) is used only for the rendezvous, the barriers and the
+max-over-ranks of the timings.  If the RCCL communicator cannot be built the
+run fails (exit code 3) unless --allow-gloo-gather is given.
 
 Prints ONE JSON line (rank 0).
 """
@@ -114,10 +117,12 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, target_s=15.0):
+def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, gpu_pixels=None, target_s=15.0):
     """The CPU oracle (a port of the reference's algorithm, bit-exact against
     its golden vectors) timed on this box's host cores on a strided sample of
-    the same candidate list."""
+    the same candidate list.  When the sample is the whole list, its scored
+    pixels are compared bit for bit with the GPU's (`pixels_equal`): the oracle
+    acts as the checker here, the number it produces stays a reported baseline."""
     from oracle import oracle_np as onp
     from peakachu_amd.forest import FlatForest
     fod = {k: getattr(fo, k) for k in FlatForest.FIELDS}
@@ -128,15 +133,72 @@ def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, target_s=15.0):
         stride = max(1, N // max(1, m))
         xs, ys = x[::stride], y[::stride]
         t0 = time.perf_counter()
-        onp.score(Mf, exp_arr, w, fod, thre, xs, ys, batch=batch, threads=cores)
+        res = onp.score(Mf, exp_arr, w, fod, thre, xs, ys, batch=batch, threads=cores)
         dt = time.perf_counter() - t0
         if dt >= 0.6 * target_s or xs.size >= N:
             break
         m = int(min(N, xs.size * min(10.0, 1.1 * target_s / max(dt, 1e-3))))
-    return dict(value=xs.size / dt, unit="candidates/s", cores=cores, kind="port",
-                sample="every %d-th candidate of the workload (%d of %d), %.1f s wall, "
-                       "oracle/pk_oracle.c pko_score_mt with OpenMP over candidates"
-                       % (stride, xs.size, N, dt))
+    out = dict(value=xs.size / dt, unit="candidates/s", cores=cores, kind="port",
+               sample="every %d-th candidate of the workload (%d of %d), %.1f s wall, "
+                      "oracle/pk_oracle.c pko_score_mt with OpenMP over candidates"
+                      % (stride, xs.size, N, dt))
+    if gpu_pixels is not None and xs.size == N:
+        out["pixels_equal"] = bool(
+            all(np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+                for a, b in zip(res, gpu_pixels)))
+        out["pixels_compared"] = int(res[0].size)
+    else:
+        out["pixels_equal"] = None  # the sample did not grow to the whole list in the time budget
+    return out
+
+
+def source_sha():
+    """Hash of the kernel sources (tools/make_traffic.py stamps profiles/pmc.json with it)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "peakachu_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_rooflines(dom, launches_per_step_live):
+    """HBM traffic and the two binding rooflines of the dominant kernel from the committed
+    PMC passes (profiles/pmc.json, made by tools/pmc.sh + tools/make_traffic.py).  Every
+    figure can be recomputed from that file; `stale` tells whether the kernel sources
+    have changed since it was measured."""
+    path = os.path.join(ROOT, "profiles", "pmc.json")
+    if not os.path.exists(path):
+        return None, None, None
+    try:
+        P = json.load(open(path))
+        d = P[dom]
+        c = d["counters_per_launch"]
+        cyc = d["cycles_per_launch"]
+    except Exception:
+        return None, None, None
+    stale = P.get("source_sha") != source_sha()
+    note = "profiles/pmc.json (sources %s)" % ("CHANGED since: stale" if stale else "unchanged")
+    traffic = None if stale else d.get("hbm_bytes_per_launch")
+    issue = {"bound": "valu issue", "valu_wave_insts_per_launch": c.get("SQ_INSTS_VALU"),
+             "cycles_per_inst": 4, "simds": 1024, "cycles_per_launch": cyc,
+             "frac": (c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc)) if "SQ_INSTS_VALU" in c else None,
+             "formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8)", "stale": stale,
+             "source": note}
+    lds = {"bound": "lds", "lds_wave_insts_per_launch": c.get("SQ_INSTS_LDS"),
+           "lds_array_cycles_per_launch": c.get("SQ_LDS_IDX_ACTIVE"),
+           "bank_conflict_cycles_per_launch": c.get("SQ_LDS_BANK_CONFLICT"), "cus": 256,
+           "cycles_per_launch": cyc,
+           # an LDS wave-instruction occupies the CU's LDS pipe for >= 4 cycles whatever its
+           # width (tools/micro/lds_chain.hip on MI355X: 16 waves x 4 walks saturate at
+           # 11.9 cycles per 3 reads), so instructions / 4-cycle slots is the binding ratio
+           "frac_issue_slots": (c["SQ_INSTS_LDS"] * 4.0 / (256.0 * cyc)) if "SQ_INSTS_LDS" in c else None,
+           "frac_array_busy": (c["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)) if "SQ_LDS_IDX_ACTIVE" in c else None,
+           "formula": "SQ_INSTS_LDS x 4 cycles / (256 CUs x GRBM_GUI_ACTIVE/8); SQ_LDS_IDX_ACTIVE / (256 x cycles)",
+           "stale": stale, "source": note}
+    return traffic, issue, lds
 
 
 def main():
@@ -155,6 +217,13 @@ def main():
                     help="flat-forest .npz, or random:T[:depth] for untrained random trees "
                          "(default: the committed forest for -w)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = every rank its own chromosome (default); strong = one chromosome, "
+                         "the candidate list cut into batch-aligned blocks")
+    ap.add_argument("--allow-gloo-gather", action="store_true",
+                    help="N > 1: fall back to a gloo gather when the RCCL communicator cannot be built "
+                         "(otherwise the run fails)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive extra leg")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use device 0 and the RCCL gather is skipped "
                          "(RCCL refuses two ranks on one GPU); the result is not a valid measurement")
@@ -186,10 +255,18 @@ def main():
     w = a.w
     F = (2 * w + 1) ** 2
     fo = load_forest(a.forest, w, F)
-    # weak scaling: rank r scores its own synthetic chromosome (seed r)
-    Mf, exp_arr, x, y, upper = build_workload(rank, a.n, a.band, w, 6, a.upper or a.band)
+    # weak scaling: rank r scores its own synthetic chromosome (seed r); strong scaling: all
+    # ranks hold chromosome 0 and rank r scores block r of its candidate list, cut at
+    # multiples of the reference batch so that the batch rule sees the same batches
+    strong = a.scaling == "strong" and world > 1
+    Mf, exp_arr, x, y, upper = build_workload(0 if strong else rank, a.n, a.band, w, 6, a.upper or a.band)
     if a.stride > 1:
         x, y = x[::a.stride].copy(), y[::a.stride].copy()
+    x_all, y_all = x, y
+    if strong:
+        from peakachu_amd import dist as pkdist
+        lo, hi = pkdist.block_ranges(x.size, world, a.batch)[rank]
+        x, y = x[lo:hi].copy(), y[lo:hi].copy()
     t0 = time.perf_counter()
     hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], exp_arr,
                         -2 * w + 1, upper + 2 * w - 1, device=dev)
@@ -222,14 +299,33 @@ def main():
                 L.pk_comm_destroy(comm)
             comm = None
             gather_mode = "gloo"
-    cap = int(x.size) * world
+            if not (a.allow_gloo_gather or a.rehearse_shared_gpu):
+                if rank == 0:
+                    sys.stderr.write("bench.py: the RCCL communicator could not be built on every rank; "
+                                     "refusing to measure a gloo gather (pass --allow-gloo-gather to do so)\n")
+                dist.barrier()
+                dist.destroy_process_group()
+                sys.exit(3)
+    cap = int(x_all.size) * (1 if strong else world)
+    cap = max(cap, int(x.size) * world)
     counts = np.zeros(world, np.int64)
     if rank == 0 and world > 1:
         gx = np.empty(cap, np.int32); gy = np.empty(cap, np.int32)
         gp = np.empty(cap, np.float64); gs = np.empty(cap, np.float64)
 
+    t_run = [0.0]
+    t_gather = [0.0]
+
     def step():
-        n_out = cd.run(hm, hf, w, a.thre, a.batch)
+        ts = time.perf_counter()
+        n_out = cd.run(hm, hf, w, a.thre, a.batch)   # returns after the stream has drained
+        tg = time.perf_counter()
+        t_run[0] += tg - ts
+        _gather()
+        t_gather[0] += time.perf_counter() - tg
+        return n_out
+
+    def _gather():
         if comm:
             if rank == 0:
                 _lib.check(L.pk_comm_gather_scored(comm, cd.h, counts, cap, gx.ctypes.data,
@@ -249,7 +345,6 @@ def main():
                     gx[o:o + px.size] = px; gy[o:o + px.size] = py
                     gp[o:o + px.size] = pp; gs[o:o + px.size] = ps
                     o += px.size
-        return n_out
 
     def sync():
         _lib.check(L.pk_device_synchronize(dev), "sync")
@@ -261,6 +356,7 @@ def main():
     L.pk_prof_enable(1)
     L.pk_prof_reset()
     sync()
+    t_run[0] = t_gather[0] = 0.0
     t0 = time.perf_counter()
     n_out = 0
     for _ in range(a.steps):
@@ -268,7 +364,9 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     L.pk_prof_enable(0)
-    kern = {k: _lib.prof_get(k) for k in ("extract", "forest", "compact")}
+    kern = {k: _lib.prof_get(k) for k in ("extract", "quant", "forest", "compact")}
+    run_ms, gather_ms = t_run[0] / a.steps * 1e3, t_gather[0] / a.steps * 1e3
+    gpu_pixels = cd.fetch() if world == 1 else None
 
     # extra, not the headline: the same pass with exact early termination (option
     # early_exit: candidates that provably end at p <= thre stop walking; same pixels)
@@ -287,9 +385,49 @@ def main():
                  "scored_pixels": int(n_early), "same_pixels_as_full_evaluation": bool(n_early == n_out),
                  "note": "opt-in exact pruning at threshold %g; NOT the headline value" % a.thre}
 
+    # extra, not the headline: SURVEY.md 8d's literal metric -- the same steps through
+    # pk_score with HOST coordinate / result buffers (H2D of the candidates and D2H of the
+    # scored pixels inside the timed region; matrix and forest stay resident)
+    pcie = None
+    if world == 1 and not a.no_pcie:
+        hm.score(hf, w, a.thre, x, y, batch=a.batch)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            r_pcie = hm.score(hf, w, a.thre, x, y, batch=a.batch)
+        sync()
+        p_el = time.perf_counter() - t0
+        pcie = {"value": int(x.size) * a.steps / p_el, "unit": "candidates/s",
+                "ms_per_step": p_el / a.steps * 1e3, "scored_pixels": int(r_pcie[0].size),
+                "note": "pk_score with host buffers: candidate upload (8 B each), per-call device "
+                        "allocations and result download included; NOT the headline value"}
+
+    # strong scaling: the merged result must equal the single-GPU result of the whole list
+    strong_check = None
+    if strong:
+        total_pix = int(counts.sum())
+        if rank == 0:
+            import hashlib
+            cd_all = _lib.HipCands(x_all, y_all, device=dev)
+            cd_all.run(hm, hf, w, a.thre, a.batch)
+            ref = cd_all.fetch()
+            cd_all.close()
+            got = (gx[:total_pix], gy[:total_pix], gp[:total_pix], gs[:total_pix])
+            same = all(np.array_equal(np.ascontiguousarray(r).view(np.uint8),
+                                      np.ascontiguousarray(g_).view(np.uint8)) for r, g_ in zip(ref, got))
+            h = hashlib.sha256()
+            for arr in got:
+                h.update(np.ascontiguousarray(arr).tobytes())
+            strong_check = {"merged_equals_single_gpu": bool(same), "pixels": total_pix,
+                            "sha256": h.hexdigest()[:16]}
+
     n_local = int(x.size)
+    per_rank_ms = [run_ms]
     if dist:
         import torch
+        pr = [None] * world
+        dist.all_gather_object(pr, float(run_ms))
+        per_rank_ms = [float(v) for v in pr]
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
@@ -303,21 +441,18 @@ def main():
         ms_per_step = elapsed / a.steps * 1e3
         value = n_total * a.steps / elapsed
         # dominant kernel = the class with the most device time on rank 0
-        dom = max(("extract", "forest"), key=lambda k: kern[k][0])
+        dom = max(("extract", "quant", "forest"), key=lambda k: kern[k][0])
         dom_ms, dom_n = kern[dom]
         alg_bytes_total = float(n_local) * a.steps * b_alg(F)
         achieved = alg_bytes_total / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel, from the committed PMC
-        # passes (profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # gfx950 correction applied); only valid for the default w=5 workload
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and w == 5 and dom_n:
-            try:
-                per_cand = json.load(open(tpath))[dom]["bytes_per_candidate"]
-                traffic = per_cand * n_local * a.steps / dom_n
-            except Exception:
-                traffic = None
+        # HBM bytes per launch of the dominant kernel and its binding rooflines, from the
+        # committed PMC passes (profiles/pmc.json); only valid for the default workload and
+        # reported as stale (traffic = null) when the kernel sources changed since
+        traffic = issue_roof = lds_roof = None
+        default_workload = (w == 5 and a.n == 30000 and a.band == 200 and a.stride == 1 and not a.forest
+                            and not a.opt and world == 1)
+        if default_workload and dom_n:
+            traffic, issue_roof, lds_roof = pmc_rooflines(dom, dom_n / a.steps)
         fst = fo.stats()
         out = {
             "metric": "candidate pixels scored/sec",
@@ -328,7 +463,7 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -346,8 +481,10 @@ def main():
                 "threshold": a.thre,
                 "reference_batch": a.batch,
                 "scored_pixels_rank0": int(n_out),
-                "parallelism": "chromosome-sharded x%d, one %s gather of the scored pixels%s"
-                               % (world, {"rccl": "RCCL", "gloo": "gloo (RCCL unavailable)",
+                "parallelism": "%s x%d, one %s gather of the scored pixels%s"
+                               % ("batch-aligned candidate blocks of one chromosome" if strong
+                                  else "chromosome-sharded", world,
+                                  {"rccl": "RCCL", "gloo": "gloo (RCCL unavailable)",
                                           "none": "(single rank: no)"}[gather_mode],
                                   " (REHEARSAL: shared GPU)" if a.rehearse_shared_gpu else ""),
                 "gather": gather_mode,
@@ -371,11 +508,20 @@ def main():
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kern.items()},
             "whole_path_alg_GBs": value * b_alg(F) / 1e9,
             "upload_s": upload_s,
+            "per_rank_ms": per_rank_ms,       # device work of a step (pk_score_run), per rank
+            "gather_ms": gather_ms,           # the exchange of a step, as seen by rank 0
         }
+        if issue_roof is not None:
+            out["roofline_issue"] = issue_roof
+            out["roofline_lds"] = lds_roof
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
+        if strong_check is not None:
+            out["strong_check"] = strong_check
         if early is not None:
             out["early_exit"] = early
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(Mf, exp_arr, w, fo, a.thre, x, y, a.batch)
+            out["cpu_baseline"] = cpu_baseline(Mf, exp_arr, w, fo, a.thre, x, y, a.batch, gpu_pixels)
         print(json.dumps(out))
         sys.stdout.flush()
 

@@ -95,6 +95,12 @@ int pk_predict(pk_forest *, int64_t N, const float *fea32, double *p1);
  * peakachu/scoreUtils.py:68) and all per-candidate outputs in HBM. */
 pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y);
 void pk_cands_destroy(pk_cands *);
+/* exact early termination for the runs of THIS candidate list (what Chromosome.score
+ * needs: only the pixels with p > thre, peakachu/scoreUtils.py:110-113): a candidate
+ * stops walking the forest once its sum can no longer exceed thre * T.  The scored
+ * pixels are identical; pk_score_fetch_all then reports 0 for pruned candidates.
+ * Off by default (every candidate gets its full probability). */
+int pk_cands_set_prune(pk_cands *, int on);
 /* extract -> predict -> (p > thre) -> compact, with the reference's batch
  * rule (a batch of `batch` candidates with fewer than two surviving windows
  * contributes nothing; peakachu/scoreUtils.py:104-108).  Results stay on the

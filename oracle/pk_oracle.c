@@ -325,15 +325,19 @@ int pko_max_threads(void)
 #endif
 }
 
-int64_t pko_score_mt(int nthreads, int32_t n, const int32_t *indptr,
-                     const int32_t *indices, const double *data,
-                     const double *exp_arr, int64_t exp_len, int w, int T,
-                     const int32_t *tree_off, const int32_t *left,
-                     const int32_t *right, const int32_t *feat,
-                     const double *thr, const uint8_t *miss_left,
-                     const double *p1, double thre, int64_t batch, int64_t N,
-                     const int64_t *x, const int64_t *y, int64_t *ox,
-                     int64_t *oy, double *op, double *osig)
+/* all_status / all_prob (either may be NULL): per candidate, whether its window
+ * survived getwindow's filters and predict_proba[:,1] of its features (0 where
+ * it did not) -- what pk_score_fetch_all reports, for full-size parity tests. */
+int64_t pko_score_all_mt(int nthreads, int32_t n, const int32_t *indptr,
+                         const int32_t *indices, const double *data,
+                         const double *exp_arr, int64_t exp_len, int w, int T,
+                         const int32_t *tree_off, const int32_t *left,
+                         const int32_t *right, const int32_t *feat,
+                         const double *thr, const uint8_t *miss_left,
+                         const double *p1, double thre, int64_t batch, int64_t N,
+                         const int64_t *x, const int64_t *y, int64_t *ox,
+                         int64_t *oy, double *op, double *osig,
+                         uint8_t *all_status, double *all_prob)
 {
     const int S = 2 * w + 1, F = S * S;
     if (batch <= 0)
@@ -375,7 +379,28 @@ int64_t pko_score_mt(int nthreads, int32_t n, const int32_t *indptr,
                 n_out++;
             }
     }
+    for (int64_t c = 0; c < N; c++) {
+        if (all_status)
+            all_status[c] = ok[c];
+        if (all_prob)
+            all_prob[c] = ok[c] ? p[c] : 0.0;
+    }
     free(ok);
     free(p);
     return n_out;
+}
+
+int64_t pko_score_mt(int nthreads, int32_t n, const int32_t *indptr,
+                     const int32_t *indices, const double *data,
+                     const double *exp_arr, int64_t exp_len, int w, int T,
+                     const int32_t *tree_off, const int32_t *left,
+                     const int32_t *right, const int32_t *feat,
+                     const double *thr, const uint8_t *miss_left,
+                     const double *p1, double thre, int64_t batch, int64_t N,
+                     const int64_t *x, const int64_t *y, int64_t *ox,
+                     int64_t *oy, double *op, double *osig)
+{
+    return pko_score_all_mt(nthreads, n, indptr, indices, data, exp_arr, exp_len, w, T,
+                            tree_off, left, right, feat, thr, miss_left, p1, thre, batch,
+                            N, x, y, ox, oy, op, osig, NULL, NULL);
 }

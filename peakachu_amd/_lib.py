@@ -44,6 +44,7 @@ SIGNATURES = {
     "pk_predict": (C.c_int, [_vp, C.c_int64, _f32p, _f64p]),
     "pk_cands_create": (_vp, [C.c_int, C.c_int64, _i32p, _i32p]),
     "pk_cands_destroy": (None, [_vp]),
+    "pk_cands_set_prune": (C.c_int, [_vp, C.c_int]),
     "pk_score_run": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int64,
                                C.POINTER(C.c_int64)]),
     "pk_score_fetch": (C.c_int, [_vp, _i32p, _i32p, _f64p, _f64p]),
@@ -273,6 +274,10 @@ class HipCands:
         if not self.h:
             raise PeakachuHipError("pk_cands_create: " + last_error())
         self.n_out = 0
+
+    def set_prune(self, on=True):
+        """Exact early termination for this list's runs (same scored pixels)."""
+        check(self._L.pk_cands_set_prune(self.h, 1 if on else 0), "pk_cands_set_prune")
 
     def run(self, matrix, forest, w, thre, batch=100000):
         nout = C.c_int64(0)

@@ -693,6 +693,14 @@ extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, co
     return c;
 }
 
+extern "C" int pk_cands_set_prune(pk_cands *c, int on)
+{
+    PK_API_LOCK;
+    if (!c) return PK_E_INVALID;
+    c->prune = on != 0;
+    return PK_OK;
+}
+
 extern "C" void pk_cands_destroy(pk_cands *c)
 {
     PK_API_LOCK;
@@ -931,7 +939,8 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
         cd->n_batches_cap = nb;
     }
     // optional exact early termination (option early_exit): only meaningful for thre >= 0
-    const double prune_sum = (g_opt.early_exit && thre >= 0.0) ? thre * (double)f->T : -INFINITY;
+    const double prune_sum =
+        ((g_opt.early_exit || cd->prune) && thre >= 0.0) ? thre * (double)f->T : -INFINITY;
     int rc = run_pipeline(ctx, m, f, cd, w, prune_sum);
     if (rc) return rc;
     rc = pk_launch_compact(ctx, m, cd, thre, batch);

@@ -22,7 +22,26 @@ struct pk_comm {
     int device, nranks, rank;
     ncclComm_t comm;
     int64_t *d_counts;  // device [nranks]
+    int64_t *d_mine;    // device scalar: this rank's byte count (pk_comm_gatherv_bytes)
+    // staging areas that live as long as the communicator and only ever grow: a gather is
+    // part of the timed step of a multi-GPU run and must not allocate
+    void *stage[2];     // [0] send bytes / root's gathered pixels, [1] root's gathered bytes
+    size_t stage_cap[2];
 };
+
+// makes stage[i] at least `bytes` large (grows by half again so that repeated gathers of
+// slightly different sizes settle after a few calls)
+static int comm_reserve(pk_comm *c, int i, size_t bytes)
+{
+    if (bytes <= c->stage_cap[i]) return PK_OK;
+    size_t want = bytes + bytes / 2 + 4096;
+    if (c->stage[i]) PK_HIP(hipFree(c->stage[i]));
+    c->stage[i] = nullptr;
+    c->stage_cap[i] = 0;
+    PK_HIP(hipMalloc(&c->stage[i], want));
+    c->stage_cap[i] = want;
+    return PK_OK;
+}
 
 #define PK_NCCL(call)                                                                  \
     do {                                                                               \
@@ -60,6 +79,9 @@ extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8
     c->rank = rank;
     c->comm = nullptr;
     c->d_counts = nullptr;
+    c->d_mine = nullptr;
+    c->stage[0] = c->stage[1] = nullptr;
+    c->stage_cap[0] = c->stage_cap[1] = 0;
     ncclUniqueId u;
     memcpy(&u, id, 128);
     ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
@@ -68,7 +90,8 @@ extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8
         delete c;
         return nullptr;
     }
-    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * (size_t)nranks) != hipSuccess) {
+    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * (size_t)nranks) != hipSuccess ||
+        hipMalloc((void **)&c->d_mine, sizeof(int64_t)) != hipSuccess) {
         pk_set_error("pk_comm_create: device allocation failed");
         ncclCommDestroy(c->comm);
         delete c;
@@ -83,6 +106,9 @@ extern "C" void pk_comm_destroy(pk_comm *c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->d_counts) hipFree(c->d_counts);
+    if (c->d_mine) hipFree(c->d_mine);
+    for (int i = 0; i < 2; i++)
+        if (c->stage[i]) hipFree(c->stage[i]);
     if (c->comm) ncclCommDestroy(c->comm);
     delete c;
 }
@@ -131,18 +157,14 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
                      (long long)total, (long long)cap);
         // still drain the peers' sends into a scratch area to keep ranks in step
     }
-    const size_t t1 = (size_t)(total > 0 ? total : 1);
-    int32_t *gx = nullptr, *gy = nullptr;
-    double *gp = nullptr, *gs = nullptr;
-    if (hipMalloc((void **)&gx, t1 * 4) != hipSuccess || hipMalloc((void **)&gy, t1 * 4) != hipSuccess ||
-        hipMalloc((void **)&gp, t1 * 8) != hipSuccess || hipMalloc((void **)&gs, t1 * 8) != hipSuccess) {
-        pk_set_error("pk_comm_gather_scored: staging allocation failed");
-        if (gx) hipFree(gx);
-        if (gy) hipFree(gy);
-        if (gp) hipFree(gp);
-        if (gs) hipFree(gs);
-        return PK_E_NOMEM;
+    // one staging area [x | y | p | signal], 8-byte aligned parts
+    const size_t t1 = ((size_t)(total > 0 ? total : 1) + 1) & ~(size_t)1;
+    {
+        const int rcs = comm_reserve(c, 0, t1 * 24);
+        if (rcs) return rcs;
     }
+    int32_t *gx = static_cast<int32_t *>(c->stage[0]), *gy = gx + t1;
+    double *gp = reinterpret_cast<double *>(gy + t1), *gs = gp + t1;
     int rc = PK_OK;
     do {
         const size_t k0 = (size_t)h_counts[0];
@@ -192,10 +214,6 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
             rc = PK_E_HIP;
         }
     } while (0);
-    hipFree(gx);
-    hipFree(gy);
-    hipFree(gp);
-    hipFree(gs);
     return rc;
 }
 
@@ -211,17 +229,13 @@ extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbyte
     if (!ctx) return PK_E_NODEVICE;
     hipStream_t s = ctx->stream;
     const int R = c->nranks;
-    int64_t *d_mine = nullptr;
+    int64_t *d_mine = c->d_mine;
     uint8_t *d_send = nullptr, *d_recv = nullptr;
-    int rc = PK_OK;
+    int rc = comm_reserve(c, 0, (size_t)(nbytes > 0 ? nbytes : 1));
+    if (rc) return rc;
+    d_send = static_cast<uint8_t *>(c->stage[0]);
     std::vector<int64_t> h_counts((size_t)R);
     do {
-        if (hipMalloc((void **)&d_mine, 8) != hipSuccess ||
-            hipMalloc((void **)&d_send, (size_t)(nbytes > 0 ? nbytes : 1)) != hipSuccess) {
-            pk_set_error("pk_comm_gatherv_bytes: device allocation failed");
-            rc = PK_E_NOMEM;
-            break;
-        }
         if (hipMemcpyAsync(d_mine, &nbytes, 8, hipMemcpyHostToDevice, s) != hipSuccess ||
             (nbytes > 0 &&
              hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, s) != hipSuccess)) {
@@ -254,11 +268,9 @@ extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbyte
             if (hipStreamSynchronize(s) != hipSuccess) rc = PK_E_HIP;
             break;
         }
-        if (hipMalloc((void **)&d_recv, (size_t)(total > 0 ? total : 1)) != hipSuccess) {
-            pk_set_error("pk_comm_gatherv_bytes: staging allocation failed");
-            rc = PK_E_NOMEM;
-            break;
-        }
+        rc = comm_reserve(c, 1, (size_t)(total > 0 ? total : 1));
+        if (rc) break;
+        d_recv = static_cast<uint8_t *>(c->stage[1]);
         if (nbytes > 0 &&
             hipMemcpyAsync(d_recv, d_send, (size_t)nbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
             rc = PK_E_HIP;
@@ -287,8 +299,5 @@ extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbyte
         }
         if (hipStreamSynchronize(s) != hipSuccess) rc = PK_E_HIP;
     } while (0);
-    if (d_mine) hipFree(d_mine);
-    if (d_send) hipFree(d_send);
-    if (d_recv) hipFree(d_recv);
     return rc;
 }

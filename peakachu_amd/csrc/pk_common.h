@@ -282,6 +282,7 @@ struct pk_cands {
     int64_t n_out;         // host copy after the run
     int32_t *batch_cnt;    // device [n_batches] survivors per reference batch
     int64_t n_batches_cap;
+    int prune;             // pk_cands_set_prune: exact early termination for this list's runs
 };
 
 // ------------------------------------------------------------ kernel entry

@@ -73,6 +73,12 @@ class GlooTransport:
     def barrier(self):
         self.dist.barrier()
 
+    def all_failures(self, failure):
+        """Every rank passes None (fine) or a message; every rank gets the list of messages."""
+        out = [None] * self.world
+        self.dist.all_gather_object(out, failure)
+        return [m for m in out if m]
+
     def close(self):
         pass
 
@@ -123,6 +129,13 @@ class RcclTransport:
 
     def barrier(self):
         self.dist.barrier()
+
+    def all_failures(self, failure):
+        """Every rank passes None (fine) or a message; every rank gets the list of messages
+        (over the host rendezvous: a rank whose GPU failed can still take part)."""
+        out = [None] * self.world
+        self.dist.all_gather_object(out, failure)
+        return [m for m in out if m]
 
     def close(self):
         if getattr(self, "h", None):

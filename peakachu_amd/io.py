@@ -54,6 +54,11 @@ class PkMap:
         self.binsize = int(self._z["resolution"])
         self.weight_name = str(self._z["weight_name"])
 
+    def chrom_bins(self, chrom):
+        """Number of bins of a chromosome, from the container's metadata (no matrix is
+        decompressed for it)."""
+        return int(self._z[chrom + "/n"])
+
     def _raw(self, chrom):
         # score_genome fetches a chromosome twice in balanced mode (raw counts for the
         # Poisson candidates, balanced values for the windows): decompress it once
@@ -88,6 +93,15 @@ class PkMap:
             b[self.weight_name] = _Col(self._weights(chrom))
             return b
         return _Selector(fetch)
+
+
+def chrom_bins(lib, chrom):
+    """Bins of `chrom` without fetching its matrix: PkMap metadata, or cooler's
+    chromsizes / binsize (what cooler itself derives the bin table from)."""
+    if hasattr(lib, "chrom_bins"):
+        return lib.chrom_bins(chrom)
+    size, binsize = int(lib.chromsizes[chrom]), int(lib.binsize)
+    return (size + binsize - 1) // binsize
 
 
 def open_map(path):

@@ -133,14 +133,11 @@ class Chromosome():
         same = (self._cands is not None and self._cands_key[0] is self.ridx
                 and self._cands_key[1] is self.cidx)
         cd = self._cands if same else _lib.HipCands(self.ridx, self.cidx, device=self.device)
-        # exact early termination: a candidate stops once its sum can no longer exceed
-        # thre*T; the reported pixels are identical (tests/test_gpu_fullsize.py)
-        prev = _lib.load().pk_get_option(b"early_exit")
-        _lib.set_option("early_exit", 1)
-        try:
-            cd.run(self._matrix(), self._forest(), self.w, thre, batch=100000)
-        finally:
-            _lib.set_option("early_exit", prev)
+        # exact early termination, a property of this candidate list (no process-wide
+        # option is touched): a candidate stops once its sum can no longer exceed thre*T;
+        # the reported pixels are identical (tests/test_gpu_fullsize.py)
+        cd.set_prune(True)
+        cd.run(self._matrix(), self._forest(), self.w, thre, batch=100000)
         ri, ci, prob_pool, signal = cd.fetch()
         ri = ri.astype(int)
         ci = ci.astype(int)

@@ -59,29 +59,45 @@ def main(args):
         return
 
     # N ranks: chromosomes are independent units; weigh them by bin count^1
-    # (candidates grow linearly with the chromosome length at a fixed band)
-    from scipy import sparse
-    sizes = [Lib.matrix(balance=False, sparse=True).fetch(k).shape[0] for k in queue]
+    # (candidates grow linearly with the chromosome length at a fixed band).  The sizes
+    # come from the container's metadata: no rank reads a matrix it does not score.
+    sizes = [io.chrom_bins(Lib, k) for k in queue]
     mine = dist.lpt_assign(sizes, world)[rank]
-    recs = []
-    for qi in mine:
-        key = queue[qi]
-        cname = key if key.startswith('chr') else 'chr' + key
-        X = build_chromosome(Lib, key, cname, model, correct, args, width, local_rank)
-        result, R = X.score(thre=args.minimum_prob)
-        r, c = result.nonzero()
-        p = np.asarray(result[r, c]).ravel() if r.size else np.zeros(0)
-        s = np.asarray(R[r, c]).ravel() if r.size else np.zeros(0)
-        recs.append(dist.pack_records(qi, r, c, p, s))
-    local = np.concatenate(recs) if recs else np.empty(0, dist.RECORD)
-    transport = dist.RcclTransport(local_rank)
+    # the transport exists BEFORE any scoring, so that a rank that fails can tell the
+    # others: all ranks leave together, with an error, instead of waiting in the gather
+    transport = make_transport(local_rank)
     try:
+        recs, failure = [], None
+        try:
+            for qi in mine:
+                key = queue[qi]
+                cname = key if key.startswith('chr') else 'chr' + key
+                X = build_chromosome(Lib, key, cname, model, correct, args, width, local_rank)
+                result, R = X.score(thre=args.minimum_prob)
+                r, c = result.nonzero()
+                p = np.asarray(result[r, c]).ravel() if r.size else np.zeros(0)
+                s = np.asarray(R[r, c]).ravel() if r.size else np.zeros(0)
+                recs.append(dist.pack_records(qi, r, c, p, s))
+        except Exception as e:  # reported below, on every rank
+            failure = "rank %d: %s: %s" % (rank, type(e).__name__, e)
+        failures = transport.all_failures(failure)
+        if failures:
+            raise RuntimeError("score_genome failed on %d of %d ranks: %s"
+                               % (len(failures), world, "; ".join(failures)))
+        local = np.concatenate(recs) if recs else np.empty(0, dist.RECORD)
         allrec = dist.gather_records(local, transport)
         if rank == 0:
             write_gathered(args.output, allrec, queue, args.resolution, Lib)
         transport.barrier()
     finally:
         transport.close()
+
+
+def make_transport(local_rank):
+    """RCCL on GPUs; PK_TRANSPORT=gloo selects the CPU transport (tests)."""
+    if os.environ.get("PK_TRANSPORT") == "gloo":
+        return dist.GlooTransport()
+    return dist.RcclTransport(local_rank)
 
 
 def write_gathered(output, allrec, queue, res, Lib=None):

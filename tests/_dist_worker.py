@@ -37,7 +37,8 @@ def main():
     lib = io.open_map(os.path.join(gio.GOLD, str(z["container"])))
     # ---- 1. score_genome: chromosomes dealt to ranks, one gather, ordered merge
     queue = score_genome.select_chromosomes(lib.chromnames[:], ["#", "X"])
-    sizes = [lib.matrix(balance=False, sparse=True).fetch(k).shape[0] for k in queue]
+    sizes = [io.chrom_bins(lib, k) for k in queue]   # container metadata, no matrix is read
+    assert sizes == [lib.matrix(balance=False, sparse=True).fetch(k).shape[0] for k in queue]
     mine = dist.lpt_assign(sizes, world)[rank]
     recs = []
     for qi in mine:
@@ -52,6 +53,10 @@ def main():
         score_genome.write_gathered(path, allrec, queue, 10000)
         text = open(path).read() if os.path.exists(path) else ""
         ok = ok and (text == str(z["genome_raw"]))
+    # ---- 1b. a failing rank is reported to every rank (score_genome leaves together)
+    fails = tr.all_failures("rank 1: boom" if rank == 1 else None)
+    ok = ok and fails == ["rank 1: boom"]
+    ok = ok and tr.all_failures(None) == []
     # ---- 2. one chromosome, candidate blocks cut at batch boundaries
     q = gio.load("g4_batch_quirk.npz")
     w, upper = int(q["w"]), int(q["upper"])
@@ -60,6 +65,8 @@ def main():
     lo, hi = dist.block_ranges(q["bx"].size, world, 100000)[rank]
     ox, oy, op, osig = onp.score(Mf, q["exp_arr"], w, fo4, 0.5, q["bx"][lo:hi], q["by"][lo:hi])
     allrec = dist.gather_records(dist.pack_records(0, ox, oy, op, osig), tr)
+    oks = tr.all_failures(None if ok else "rank %d: mismatch" % rank)
+    ok = ok and not oks
     if rank == 0:
         order = np.lexsort((allrec["y"], allrec["x"]))
         a = allrec[order]

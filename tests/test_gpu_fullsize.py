@@ -1,9 +1,10 @@
-"""BASELINE.json-size runs on the GPU, checked through size-independent
-properties (the oracle cannot score millions of candidates in a test):
+"""BASELINE.json-size runs on the GPU:
+  * FULL parity: every one of the 5.56 M candidates of configs[1] (and every 4th of
+    the 34.9 M of configs[3]) against the CPU oracle run on all host cores -- scored
+    pixels (row, col, probability, signal) and the per-candidate status and
+    probability (pk_score_fetch_all), bit for bit;
   * invariance: the result does not depend on chunking, the forest kernel
     variant or how candidates are sharded into blocks (cut at batch multiples);
-  * sampled parity: a random 1/400 of the candidates against the CPU oracle,
-    bit-exact (per-candidate status and probability via pk_score_fetch_all);
   * order: outputs are in candidate order; signal equals M[row, col];
   * idempotence: a second run of the same handles gives the same bytes.
 Needs an MI355X: -m gpu."""
@@ -105,16 +106,39 @@ def test_config2_properties(config2):
         cdr.close()
     cat = [np.concatenate([p[i] for p in parts]) for i in range(4)]
     assert digest(*cat) == base
-    # sampled parity with the oracle (status + probability of every sampled candidate)
-    rng = np.random.default_rng(1)
-    sel = np.sort(rng.choice(x.size, x.size // 400, replace=False))
+    # full parity with the oracle: every candidate's status and probability, every scored pixel
     fod = {k: getattr(c["fo"], k) for k in FlatForest.FIELDS}
-    fea, keep = onp.extract(c["Mf"], c["e"], w, x[sel], y[sel])
-    p_ref = onp.predict(fod, fea.astype(np.float32))
-    st_ref = np.zeros(sel.size, np.uint8)
-    st_ref[keep] = 1
-    assert np.array_equal(st[sel] != 0, st_ref != 0)
-    assert np.array_equal(gio.bits(pr[sel][keep]), gio.bits(p_ref))
+    (rx, ry, rp, rs), st_ref, pr_ref = onp.score_all(c["Mf"], c["e"], w, fod, 0.5, x, y)
+    assert np.array_equal(ox, rx) and np.array_equal(oy, ry)
+    assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
+    assert np.array_equal(st != 0, st_ref != 0)
+    assert np.array_equal(gio.bits(pr), gio.bits(pr_ref))
+
+
+def test_config4_full_parity_trained_forest(hip_lib):
+    """configs[3]: 5 kb map (60 000 bins, 800-bin band, upper = 800), the TRAINED w=5
+    forest, every 4th band pixel (8.7 M candidates): scored pixels and per-candidate
+    status / probability bit-exact against the oracle on all host cores."""
+    w, n, band, upper, stride = 5, 60000, 800, 800, 4
+    M, _ = synth.synth_band(n, band, seed=4)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    x, y = x[::stride].copy(), y[::stride].copy()
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w5_t100.npz"))
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, n, e, -2 * w + 1, upper + 2 * w - 1)
+    hf = _lib.HipForest(fo)
+    cd = _lib.HipCands(x, y)
+    n1 = cd.run(hm, hf, w, 0.5)
+    ox, oy, op, osig = cd.fetch()
+    st, pr = cd.fetch_all()
+    assert x.size > 8_000_000 and n1 > 0
+    fod = {k: getattr(fo, k) for k in FlatForest.FIELDS}
+    (rx, ry, rp, rs), st_ref, pr_ref = onp.score_all(Mf, e, w, fod, 0.5, x, y)
+    assert np.array_equal(ox, rx) and np.array_equal(oy, ry)
+    assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
+    assert np.array_equal(st != 0, st_ref != 0)
+    assert np.array_equal(gio.bits(pr), gio.bits(pr_ref))
 
 
 @pytest.mark.parametrize("w,T,n,band,upper,stride", [(6, 100, 20000, 300, 300, 7),

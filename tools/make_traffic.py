@@ -1,53 +1,85 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the PMC passes of tools/pmc.sh.
+"""profiles/pmc.json from the PMC passes of tools/pmc.sh.
 
-HBM-side bytes per launch of the two hot kernels: FETCH_SIZE and WRITE_SIZE
-(rocprofv3 --pmc, separate passes, values in KiB summed over the dimensions
-rocprofv3 reports), FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md
-prescribes for gfx950.  Only the full-evaluation forest instantiation
-(forest_lds_kernel<SLOTS, false>) is counted, not the early-exit extra pass.
+Per kernel class (extract / quant / forest), the mean per launch of every counter the
+passes collected, plus what bench.py derives its roofline blocks from:
+  * HBM-side bytes per launch: FETCH_SIZE and WRITE_SIZE (rocprofv3 --pmc, separate
+    passes, KiB), FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes
+    for gfx950;
+  * cycles per launch: GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs);
+  * SQ_INSTS_VALU, SQ_INSTS_LDS (wave instructions), SQ_LDS_IDX_ACTIVE,
+    SQ_LDS_BANK_CONFLICT (LDS array cycles, summed over the CUs).
+Only full-evaluation instantiations are counted (not the early-exit extra pass of
+bench.py).  The file carries a hash of the kernel sources it was measured on; bench.py
+reports the derived figures as stale when the sources have changed since.
 
-usage: tools/make_traffic.py <pmc dir> <candidates in the workload> <launches per step> > traffic.json
+usage: tools/make_traffic.py <pmc dir> <candidates in the workload> > pmc.json
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 from collections import defaultdict
 
-root, n_cand, launches = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-acc = defaultdict(lambda: defaultdict(float))
-ids = defaultdict(lambda: defaultdict(set))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def source_sha():
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "peakachu_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kclass(name):
-    if "forest_lds_kernel" in name and "false>" in name.replace(" ", ""):
-        return "forest"
-    if "extract_pair_clean_kernel" in name or "extract_pair_kernel" in name:
+    n = name.replace(" ", "")
+    if "forest_q_kernel" in n or "forest_img_kernel" in n or "forest_img2_kernel" in n or "forest_lds_kernel" in n:
+        return "forest" if "false>" in n else None
+    if "quantize_tiles_kernel" in n:
+        return "quant"
+    if "extract_pair_clean_kernel" in n or "extract_pair_kernel" in n or "extract_lds_kernel" in n:
         return "extract"
     return None
 
 
-for path in sorted(glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True)):
-    with open(path) as fh:
-        for r in csv.DictReader(fh):
-            if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
-                continue
-            k = kclass(r["Kernel_Name"])
-            if k:
-                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-                ids[k][r["Counter_Name"]].add(r["Dispatch_Id"])
-out = {}
-for k in ("forest", "extract"):
-    f = acc[k]["FETCH_SIZE"] / max(1, len(ids[k]["FETCH_SIZE"]))
-    w = acc[k]["WRITE_SIZE"] / max(1, len(ids[k]["WRITE_SIZE"]))
-    b = (2.0 * f + w) * 1024.0
-    cpl = n_cand / launches
-    out[k] = {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "bytes_per_launch": b,
-              "dispatches_seen": len(ids[k]["FETCH_SIZE"]), "candidates_per_launch": cpl,
-              "bytes_per_candidate": b / cpl}
-out["_note"] = ("HBM-side bytes per kernel launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
-                "passes, tools/pmc.sh), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; "
-                "%d candidates in %d launches per step; made by tools/make_traffic.py" % (n_cand, launches))
-print(json.dumps(out, indent=1))
+def main():
+    root, n_cand = sys.argv[1], int(sys.argv[2])
+    acc = defaultdict(lambda: defaultdict(float))
+    ids = defaultdict(lambda: defaultdict(set))
+    names = defaultdict(set)
+    for path in sorted(glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True)):
+        with open(path) as fh:
+            for r in csv.DictReader(fh):
+                k = kclass(r["Kernel_Name"])
+                if k:
+                    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                    ids[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+                    names[k].add(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", ""))
+    out = {"source_sha": source_sha(), "candidates": n_cand}
+    for k in ("extract", "quant", "forest"):
+        if k not in acc:
+            continue
+        per = {c: acc[k][c] / max(1, len(ids[k][c])) for c in acc[k]}
+        n_disp = max(len(v) for v in ids[k].values())
+        # launches per step: dispatches seen in one pass / steps of that pass (bench --steps 2 --warmup 1 = 3 passes
+        # over the candidate list, plus the early-exit extra which kclass() filters for the forest)
+        d = {"kernels": sorted(names[k]), "counters_per_launch": {c: round(v, 1) for c, v in sorted(per.items())},
+             "dispatches_seen": n_disp}
+        if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
+            d["hbm_bytes_per_launch"] = (2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]) * 1024.0
+        if "GRBM_GUI_ACTIVE" in per:
+            d["cycles_per_launch"] = per["GRBM_GUI_ACTIVE"] / 8.0
+        out[k] = d
+    out["_note"] = ("means per kernel launch from rocprofv3 --pmc passes (tools/pmc.sh: separate passes, "
+                    "--kernel-trace only); hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB per "
+                    "MI355X_MICROARCH.md (gfx950 reports half of streamed reads); cycles = GRBM_GUI_ACTIVE / 8 XCDs")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

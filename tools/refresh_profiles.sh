@@ -6,9 +6,9 @@ root="${GRAFT_REPO_ROOT:-/root/repo}"
 out="gpurun_out/${tag}_refresh"
 mkdir -p "$root/$out"
 bash "$root/tools/pmc.sh" "$out/pmc" > "$root/$out/pmc.log" 2>&1 || exit 1
-read ncand nlaunch < <(python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(d['config']['candidates_per_gpu'], d['roofline']['launches'] // d['steps'])" "$root/$out/pmc/pass3.json")
-python3 "$root/tools/make_traffic.py" "$root/$out/pmc" "$ncand" "$nlaunch" > "$root/$out/traffic.json" || exit 1
-cp "$root/$out/traffic.json" "$root/profiles/traffic.json"
+ncand=$(python3 -c "import json,sys; d=json.load(open(sys.argv[1])); print(d['config']['candidates_per_gpu'])" "$root/$out/pmc/pass3.json")
+python3 "$root/tools/make_traffic.py" "$root/$out/pmc" "$ncand" > "$root/$out/pmc.json" || exit 1
+cp "$root/$out/pmc.json" "$root/profiles/pmc.json"
 cp "$root/$out/pmc/summary.txt" "$root/$out/${tag}_pmc_summary.txt"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 python3 "$root/bench.py" > "$root/$out/${tag}_bench.json" 2> "$root/$out/bench.err" || exit 1
