@@ -143,9 +143,13 @@ def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, gpu_pixels=None, target_
                       "oracle/pk_oracle.c pko_score_mt with OpenMP over candidates"
                       % (stride, xs.size, N, dt))
     if gpu_pixels is not None and xs.size == N:
+        # rows / columns as integers, probability and signal bit for bit
         out["pixels_equal"] = bool(
-            all(np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
-                for a, b in zip(res, gpu_pixels)))
+            res[0].size == gpu_pixels[0].size
+            and np.array_equal(res[0], gpu_pixels[0].astype(np.int64))
+            and np.array_equal(res[1], gpu_pixels[1].astype(np.int64))
+            and np.array_equal(res[2].view(np.uint64), np.ascontiguousarray(gpu_pixels[2]).view(np.uint64))
+            and np.array_equal(res[3].view(np.uint64), np.ascontiguousarray(gpu_pixels[3]).view(np.uint64)))
         out["pixels_compared"] = int(res[0].size)
     else:
         out["pixels_equal"] = None  # the sample did not grow to the whole list in the time budget
