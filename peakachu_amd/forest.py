@@ -60,17 +60,25 @@ class FlatForest:
             m = getattr(t, "missing_go_to_left", None)
             parts["miss_left"].append(np.zeros(k, np.uint8) if m is None
                                       else np.asarray(m, np.uint8))
-            v = np.asarray(t.value)[:, 0, :]
-            s = v.sum(axis=1)
-            # scikit-learn < 1.3 stores weighted class counts and normalises
-            # per tree in predict_proba; >= 1.3 stores fractions already
-            if not np.allclose(s, 1.0):
-                s = np.where(s == 0.0, 1.0, s)
-                v = v / s[:, None]
-            parts["p1"].append(np.ascontiguousarray(v[:, 1], np.float64))
+            parts["p1"].append(class1_fraction(np.asarray(t.value)[:, 0, :]))
             offs.append(offs[-1] + k)
         F = int(getattr(rf, "n_features_in_", rf.feature_importances_.size))
         return cls(F, np.asarray(offs), *[np.concatenate(parts[k]) for k in cls.FIELDS[1:]])
+
+    @classmethod
+    def from_tree_states(cls, F, trees):
+        """Per-tree node arrays as peakachu_amd.sk_pickle.forest_arrays reads them from a
+        pickled forest of any scikit-learn version (no scikit-learn needed)."""
+        offs, parts = [0], {k: [] for k in cls.FIELDS[1:]}
+        for t in trees:
+            parts["left"].append(np.asarray(t["left"], np.int32))
+            parts["right"].append(np.asarray(t["right"], np.int32))
+            parts["feat"].append(np.asarray(t["feature"], np.int32))
+            parts["thr"].append(np.asarray(t["threshold"], np.float64))
+            parts["miss_left"].append(np.asarray(t["missing_go_to_left"], np.uint8))
+            parts["p1"].append(class1_fraction(t["value"]))
+            offs.append(offs[-1] + int(parts["left"][-1].size))
+        return cls(int(F), np.asarray(offs), *[np.concatenate(parts[k]) for k in cls.FIELDS[1:]])
 
     def save(self, path):
         np.savez_compressed(path, F=np.int32(self.F),
@@ -85,6 +93,20 @@ class FlatForest:
         sizes = np.diff(self.tree_off)
         return dict(T=self.T, F=self.F, nodes=int(self.n_nodes),
                     nodes_per_tree_mean=float(sizes.mean()), nodes_per_tree_max=int(sizes.max()))
+
+
+def class1_fraction(value):
+    """value: [nodes, 2] of `tree_.value`.  scikit-learn >= 1.4 stores class fractions
+    (rows sum to 1); older versions (the reference's README pins 1.1.2) store weighted
+    class COUNTS and `DecisionTreeClassifier.predict_proba` divides by the row sum at
+    predict time (`normalizer[normalizer == 0.0] = 1.0`).  The same division here, so an
+    old pickle yields the fractions its own scikit-learn would have predicted with."""
+    v = np.asarray(value, np.float64)
+    s = v.sum(axis=1)
+    if not np.allclose(s, 1.0):
+        s = np.where(s == 0.0, 1.0, s)
+        v = v / s[:, None]
+    return np.ascontiguousarray(v[:, 1], np.float64)
 
 
 def as_flat_forest(model):
@@ -103,5 +125,8 @@ def load_model(path):
     an sklearn RandomForestClassifier (peakachu/score_genome.py:14)."""
     if str(path).endswith(".npz"):
         return FlatForest.load(path)
-    import joblib
-    return FlatForest.from_sklearn(joblib.load(path))
+    # read the pickle's arrays directly: works whatever scikit-learn / joblib wrote it
+    # (and whether or not they are installed here); see sk_pickle.py
+    from . import sk_pickle
+    fa = sk_pickle.forest_arrays(path)
+    return FlatForest.from_tree_states(fa["F"], fa["trees"])
