@@ -211,6 +211,7 @@ int pk_launch_forest_img(pk_device_ctx *, pk_forest *f, const float *tiles, cons
 struct pk_q_layout {
     int F, slots, ch;   // ch = walks per lane: 2 (128 candidates per workgroup) or 4 (256)
     int HB;             // bytes of a half tile: [F][128] u16
+    int half1;          // LDS offset of the second half tile (ch == 4), 0 otherwise
     int dec_off;        // early-termination flags
     int val_off;        // [slots][64*ch] float64 leaf values parked for the ordered sum
     int img_off, cap;   // the group's trees: [img_off, img_off + cap)

@@ -35,7 +35,6 @@ typedef __attribute__((address_space(3))) u64 lds_u64;
 
 #define LDS_AT(type, byte_addr) (reinterpret_cast<type *>((__UINTPTR_TYPE__)(unsigned)(byte_addr)))
 
-constexpr int Q_HALF1 = 32768;  // LDS offset of the rank tile of candidates 128..255
 
 // ------------------------------------------------------------------------
 // float32 feature tiles [tile][F][128] -> rank codes [tile][F][64][2] u16.
@@ -113,8 +112,9 @@ __device__ __forceinline__ unsigned q_pair_index(unsigned w)
 
 // one level of CH walks of one tree.  Walk c belongs to candidate lane + 64 c of the
 // workgroup: code address = (c >> 1) * 32 KiB + feature * 256 + lane * 4 + (c & 1) * 2
-// HB0: index of the rank tile (0 or 1) walks 0 and 1 read; walks 2 and 3 read the next one
-template <int CH, int HB0, bool WITH_NAN, bool ALL_LEFT>
+// X0: LDS offset of the rank tile walks 0 and 1 read; walks 2 and 3 read the one HALF1
+// bytes further (both are immediate offsets of the ds_read)
+template <int CH, int X0, int HALF1, bool WITH_NAN, bool ALL_LEFT>
 __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsigned lk0, unsigned lk1)
 {
     unsigned xv[CH];
@@ -123,7 +123,7 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
     for (int c = 0; c < CH; c++) {
         // byte 0 <- lane constant, byte 1 <- the word's feature byte
         const unsigned xa = __builtin_amdgcn_perm(w[c], (c & 1) ? lk1 : lk0, 0x0c0c0400u);
-        xv[c] = *LDS_AT(const lds_u16, xa + (HB0 + (c >> 1)) * Q_HALF1);
+        xv[c] = *LDS_AT(const lds_u16, xa + X0 + (c >> 1) * HALF1);
         pr[c] = *LDS_AT(const lds_u64, tbase + (q_pair_index(w[c]) << 3));
     }
 #pragma unroll
@@ -135,7 +135,7 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
     }
 }
 
-template <int CH, int HB0, bool WITH_NAN, bool ALL_LEFT = false>
+template <int CH, int X0, int HALF1, bool WITH_NAN, bool ALL_LEFT = false>
 __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase, unsigned lk0,
                                        unsigned lk1, double (&v)[CH])
 {
@@ -144,10 +144,10 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
     for (int c = 0; c < CH; c++) w[c] = root;
     int d = depth;
     for (; d >= 2; d -= 2) {  // two levels per trip: a taken branch costs an instruction refetch
-        q_level<CH, HB0, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-        q_level<CH, HB0, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
     }
-    if (d) q_level<CH, HB0, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+    if (d) q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
 #pragma unroll
     for (int c = 0; c < CH; c++)  // the leaf's float64 value follows its pair
         v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index(w[c]) + 1) << 3));
@@ -171,7 +171,7 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
 // group by group: the next group travels global -> VGPR during the walk and VGPR -> LDS
 // behind the barrier.
 constexpr int Q_THREADS = 1024;
-template <int CH, int WPT, bool PRUNE>
+template <int CH, int WPT, int HALF1, bool PRUNE>
 __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp,
     const int4 *__restrict__ ttab, int T, int F, int dec_off, int val_off, int img_off,
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         const int nu = halves * (HB >> 4);
         for (int i = tid; i < nu; i += THREADS) {
             const int o = i << 4;
-            *LDS_AT(lds_u4, o < HB ? o : o - HB + Q_HALF1) = src[i];
+            *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = src[i];
         }
     }
     // walk c of a lane = candidate lane + 64 (NCH * sub + c) of the workgroup
@@ -280,12 +280,12 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             const unsigned root = (unsigned)tt.z;
             // lanes without a live candidate walk along (their values are not stored)
             if (WPT == 2 && sub) {  // the second rank tile (the tile index is an immediate offset)
-                if (wave_nan) q_walk<NCH, 1, true>(root, tt.y, tbase, lk0, lk1, v);
-                else q_walk<NCH, 1, false>(root, tt.y, tbase, lk0, lk1, v);
+                if (wave_nan) q_walk<NCH, HALF1, HALF1, true>(root, tt.y, tbase, lk0, lk1, v);
+                else q_walk<NCH, HALF1, HALF1, false>(root, tt.y, tbase, lk0, lk1, v);
             } else {
-                if (dbg & 8) q_walk<NCH, 0, false, true>(root, tt.y, tbase, lk0, lk1, v);  // wrong results
-                else if (wave_nan) q_walk<NCH, 0, true>(root, tt.y, tbase, lk0, lk1, v);
-                else q_walk<NCH, 0, false>(root, tt.y, tbase, lk0, lk1, v);
+                if (dbg & 8) q_walk<NCH, 0, HALF1, false, true>(root, tt.y, tbase, lk0, lk1, v);  // wrong results
+                else if (wave_nan) q_walk<NCH, 0, HALF1, true>(root, tt.y, tbase, lk0, lk1, v);
+                else q_walk<NCH, 0, HALF1, false>(root, tt.y, tbase, lk0, lk1, v);
             }
 #pragma unroll
             for (int c = 0; c < NCH; c++)
@@ -374,8 +374,8 @@ static int q_plan_build(pk_forest *f)
     const int F = f->F, T = f->T;
     if (F > 255 || f->h_tree_off.empty()) return PK_E_UNSUPPORTED;
     int ch = (int)g_opt.forest_q_ch;
-    if (ch == 0) ch = F <= 128 ? 4 : 2;
-    if (ch == 4 && F > 128) return PK_E_UNSUPPORTED;
+    if (ch == 0) ch = F <= 192 ? 4 : 2;  // two rank tiles of 256 B per feature fit 64 KiB of offsets
+    if (ch == 4 && F > 192) return PK_E_UNSUPPORTED;
     pk_q_out best;
     pk_q_layout bestL;
     int best_slots = 0;
@@ -457,11 +457,11 @@ int pk_forest_q_plan(pk_forest *f)
     return f->q_state == 1 ? PK_OK : PK_E_UNSUPPORTED;
 }
 
-#define Q_LAUNCH_P(CH, WPT, PRUNE)                                                             \
+#define Q_LAUNCH_P(CH, WPT, HALF1, PRUNE)                                                      \
     do {                                                                                       \
-        int rc__ = q_set_max_lds(forest_q_kernel<CH, WPT, PRUNE>, 163840);                     \
+        int rc__ = q_set_max_lds(forest_q_kernel<CH, WPT, HALF1, PRUNE>, 163840);              \
         if (rc__) return rc__;                                                                 \
-        hipLaunchKernelGGL((forest_q_kernel<CH, WPT, PRUNE>), dim3(grid), dim3(Q_THREADS),     \
+        hipLaunchKernelGGL((forest_q_kernel<CH, WPT, HALF1, PRUNE>), dim3(grid), dim3(Q_THREADS), \
                            163840, ctx->stream, reinterpret_cast<const v4u *>(f->q_img),       \
                            reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp,              \
                            reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
@@ -470,10 +470,10 @@ int pk_forest_q_plan(pk_forest *f)
                            g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
                            (int)g_opt.forest_dbg, ctx->dbg_buf);                               \
     } while (0)
-#define Q_LAUNCH(CH, WPT)                                                                      \
+#define Q_LAUNCH(CH, WPT, HALF1)                                                               \
     do {                                                                                       \
-        if (prune_sum > -1e300) Q_LAUNCH_P(CH, WPT, true);                                     \
-        else Q_LAUNCH_P(CH, WPT, false);                                                       \
+        if (prune_sum > -1e300) Q_LAUNCH_P(CH, WPT, HALF1, true);                              \
+        else Q_LAUNCH_P(CH, WPT, HALF1, false);                                                \
     } while (0)
 
 int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, const uint8_t *d_status,
@@ -515,9 +515,18 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
     const unsigned grid = (unsigned)((cn + C - 1) / C);
     // two waves per tree when the groups leave half the waves without one
     const bool wpt2 = L.ch == 4 && f->q_slots <= 8 && g_opt.forest_q_wpt != 1;
-    if (L.ch == 4 && wpt2) Q_LAUNCH(4, 2);
-    else if (L.ch == 4) Q_LAUNCH(4, 1);
-    else Q_LAUNCH(2, 1);
+    if (L.ch == 4 && L.half1 == 32768) {
+        if (wpt2) Q_LAUNCH(4, 2, 32768);
+        else Q_LAUNCH(4, 1, 32768);
+    } else if (L.ch == 4 && L.half1 == 49152) {
+        if (wpt2) Q_LAUNCH(4, 2, 49152);
+        else Q_LAUNCH(4, 1, 49152);
+    } else if (L.ch == 2) {
+        Q_LAUNCH(2, 1, 32768);
+    } else {
+        pk_set_error("forest rank kernel: layout not instantiated");
+        return PK_E_INVALID;
+    }
     PK_HIP(hipGetLastError());
     return PK_OK;
 }

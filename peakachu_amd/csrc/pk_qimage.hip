@@ -177,7 +177,8 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
 
 // LDS map of forest_q_kernel<slots, ch>:
 //   [0, HB)                  rank tile of candidates 0..127   ([F][128] u16)
-//   [32768, 32768 + HB)      rank tile of candidates 128..255 (ch == 4 only; needs F <= 128)
+//   [half1, half1 + HB)      rank tile of candidates 128..255 (ch == 4 only): half1 = 32 KiB
+//                            for F <= 128, 48 KiB for F <= 192 (an immediate ds_read offset)
 //   dec_off                  early-termination flags: one int per candidate + 3 vote words
 //   val_off                  [slots][64*ch] float64 leaf values parked for the ordered sum
 //   [img_off, 163840)        the group's trees
@@ -190,15 +191,17 @@ bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L)
     L->HB = F * 256;
     const int C = 64 * ch;
     int top;
+    L->half1 = 0;
     if (ch == 4) {
-        if (L->HB > 32768) return false;
-        top = 32768 + L->HB;
+        if (L->HB > 49152) return false;
+        L->half1 = L->HB <= 32768 ? 32768 : 49152;
+        top = L->half1 + L->HB;
     } else {
         top = L->HB;
     }
     const int dec_bytes = (C * 4 + 16 + 15) & ~15;
     // the flags go into the gap below the second half tile when they fit there
-    if (ch == 4 && L->HB + dec_bytes <= 32768) {
+    if (ch == 4 && L->HB + dec_bytes <= L->half1) {
         L->dec_off = L->HB;
     } else {
         L->dec_off = top;
@@ -362,7 +365,7 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
         pk_set_error("pk_debug_forest_qimage: output buffers too small");
         return PK_E_NOMEM;
     }
-    const int32_t lay[8] = {L.HB, L.ch, L.dec_off, L.val_off, L.img_off, L.cap, L.slots, L.F};
+    const int32_t lay[8] = {L.HB, L.ch | (L.half1 << 8), L.dec_off, L.val_off, L.img_off, L.cap, L.slots, L.F};
     memcpy(layout8, lay, sizeof(lay));
     memcpy(qoff, out.qoff.data(), out.qoff.size() * sizeof(int32_t));
     memcpy(qthr, out.qthr.data(), out.qthr.size() * sizeof(float));

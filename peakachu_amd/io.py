@@ -16,8 +16,10 @@ import numpy as np
 from scipy import sparse
 
 
-def write_pkmap(path, chroms, resolution=10000, weight_name="weight"):
-    """chroms: ordered dict name -> (raw symmetric CSR, weights or None)."""
+def write_pkmap(path, chroms, resolution=10000, weight_name="weight", compress=False):
+    """chroms: ordered dict name -> (raw symmetric CSR, weights or None).
+    Uncompressed by default: inflating a compressed container costs more host time per
+    chromosome than the whole GPU scoring of it."""
     out = {"chromnames": np.array(list(chroms.keys())), "resolution": np.int64(resolution),
            "weight_name": np.array(weight_name)}
     for name, (M, w) in chroms.items():
@@ -30,7 +32,7 @@ def write_pkmap(path, chroms, resolution=10000, weight_name="weight"):
         out[name + "/n"] = np.int64(M.shape[0])
         if w is not None:
             out[name + "/weights"] = np.asarray(w, np.float64)
-    np.savez_compressed(path, **out)
+    (np.savez_compressed if compress else np.savez)(path, **out)
 
 
 class _Selector:

@@ -90,13 +90,14 @@ def quantize(img, X):
 
 
 def walk_qimage(img, codes, T):
-    HB, ch, dec_off, val_off, img_off, cap, slots, F = [int(v) for v in img["lay"]]
+    HB, ch_half1, dec_off, val_off, img_off, cap, slots, F = [int(v) for v in img["lay"]]
+    ch, half1 = ch_half1 & 0xFF, ch_half1 >> 8
     N = codes.shape[0]
     acc = np.zeros(N, np.float64)
     assert img_off % 16 == 0 and img_off + cap <= LDS_BYTES
     assert dec_off >= HB and val_off >= HB and img_off >= val_off + slots * 64 * ch * 8
     if ch == 4:
-        assert HB <= 32768 and val_off >= 32768 + HB
+        assert half1 in (32768, 49152) and HB <= half1 and val_off >= half1 + HB
     for g in range(img["n_grp"]):
         t0, nt, off, nu = [int(v) for v in img["gtab"][g]]
         assert 0 < nt <= slots and nu * 16 <= cap
@@ -138,7 +139,7 @@ def test_rank_walk_equals_sklearn_golden(tag, slots, ch):
 
 
 @pytest.mark.parametrize("name,slots,ch", [("forest_w5_t100.npz", 9, 4), ("forest_w5_t100.npz", 13, 2),
-                                           ("forest_w6_t100.npz", 8, 2)])
+                                           ("forest_w6_t100.npz", 8, 2), ("forest_w6_t100.npz", 7, 4)])
 def test_rank_image_of_benchmark_forests(name, slots, ch):
     ff = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", name))
     fo = {k: getattr(ff, k) for k in FlatForest.FIELDS}
