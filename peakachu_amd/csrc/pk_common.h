@@ -226,6 +226,7 @@ struct pk_q_out {
     std::vector<int32_t> tdepth;  // per tree: levels to descend
     std::vector<int32_t> gtab;    // per group: first tree, trees, offset and size in 16-byte units
     std::vector<int32_t> ttab;    // per tree: byte offset inside its group, depth, root word, 0
+    std::vector<int32_t> toff;    // T+1 offsets of the trees in `pairs` (8-byte units)
     int n_grp = 0;
 };
 // lookup cell of a feature value: the SAME float operations on the host (tables) and on
@@ -243,6 +244,7 @@ bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L);
 int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
                const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
                const pk_q_layout &L, pk_q_out *out);
+int pk_q_group(pk_q_out *out, const pk_q_layout &L);  // (re)group the trees of `out` for a layout
 int pk_forest_q_plan(pk_forest *f);   // PK_OK when the rank image applies (built and uploaded)
 void pk_forest_q_release(pk_forest *f);
 int pk_launch_forest_q(pk_device_ctx *, pk_forest *f, const float *tiles, const uint8_t *d_status,

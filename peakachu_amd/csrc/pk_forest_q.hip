@@ -376,6 +376,8 @@ static int q_plan_build(pk_forest *f)
     int ch = (int)g_opt.forest_q_ch;
     if (ch == 0) ch = F <= 192 ? 4 : 2;  // two rank tiles of 256 B per feature fit 64 KiB of offsets
     if (ch == 4 && F > 192) return PK_E_UNSUPPORTED;
+    // tables and trees once (they do not depend on the layout), then only the grouping
+    // is tried for every slot count
     pk_q_out best;
     pk_q_layout bestL;
     int best_slots = 0;
@@ -384,26 +386,41 @@ static int q_plan_build(pk_forest *f)
     // (4 walks per lane: at most 8 trees per group, so that two waves can share a tree and
     // all 16 walk; measured faster than 9 trees on 9 of 16 waves)
     const int max_slots = (ch == 4 && g_opt.forest_q_wpt != 1) ? 8 : 16;
+    bool built = false;
+    std::vector<int32_t> best_gtab, best_ttab;
+    int best_n_grp = 0;
     for (int slots = 2; slots <= max_slots; slots++) {  // slots = trees per group at most
         if (forced && slots != forced) continue;
         pk_q_layout L;
         if (!pk_q_make_layout(F, slots, ch, &L)) continue;
-        pk_q_out out;
-        const int rc = pk_q_build(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(),
-                                  f->h_feat.data(), f->h_thr.data(),
-                                  f->h_miss.empty() ? nullptr : f->h_miss.data(), f->h_p1.data(), L,
-                                  &out);
+        int rc;
+        if (!built) {
+            rc = pk_q_build(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(),
+                            f->h_feat.data(), f->h_thr.data(),
+                            f->h_miss.empty() ? nullptr : f->h_miss.data(), f->h_p1.data(), L, &best);
+            built = rc == PK_OK || (rc == PK_E_UNSUPPORTED && !best.toff.empty());
+            if (!built) return rc;  // the forest does not fit the format at all, or is malformed
+        } else {
+            rc = pk_q_group(&best, L);
+        }
         if (rc == PK_E_UNSUPPORTED) continue;
         if (rc) return rc;
         // a group costs about the same whatever it holds: trees per group is the figure of
         // merit; a slot that adds less than a quarter tree per group only adds an idle wave
-        const double score = (double)T / (double)out.n_grp;
+        const double score = (double)T / (double)best.n_grp;
         if (score > best_score + 0.24) {
             best_score = score;
-            best = std::move(out);
+            best_gtab = best.gtab;
+            best_ttab = best.ttab;
+            best_n_grp = best.n_grp;
             bestL = L;
             best_slots = slots;
         }
+    }
+    if (best_slots) {
+        best.gtab = best_gtab;
+        best.ttab = best_ttab;
+        best.n_grp = best_n_grp;
     }
     if (!best_slots) return PK_E_UNSUPPORTED;
     q_free(f);

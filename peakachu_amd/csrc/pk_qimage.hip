@@ -301,10 +301,25 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
             pk_set_error("forest rank image: tree %d: %s", t, err.c_str());
             return PK_E_INVALID;
         }
-        if (np < 0 || np * 8 > L.cap) return PK_E_UNSUPPORTED;
+        if (np < 0) return PK_E_UNSUPPORTED;
         toff[(size_t)t + 1] = toff[(size_t)t] + np;
     }
-    // groups of consecutive trees: at most `slots`, at most `cap` bytes
+    out->toff = toff;
+    out->pairs.push_back(make_uint2(0, 0));  // the clamped staging loads stay inside
+    out->pairs.push_back(make_uint2(0, 0));
+    return pk_q_group(out, L);
+}
+
+// Groups of consecutive trees for one layout: at most `slots` trees and `cap` bytes each.
+// (The trees themselves do not depend on the layout.)  PK_E_UNSUPPORTED if a tree is
+// larger than the image area.
+int pk_q_group(pk_q_out *out, const pk_q_layout &L)
+{
+    const int T = (int)out->troot.size();
+    const std::vector<int32_t> &toff = out->toff;
+    out->gtab.clear();
+    for (int t = 0; t < T; t++)
+        if ((toff[(size_t)t + 1] - toff[(size_t)t]) * 8 > L.cap) return PK_E_UNSUPPORTED;
     out->ttab.assign((size_t)T * 4, 0);
     int t = 0;
     while (t < T) {
@@ -328,8 +343,6 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
         out->gtab.push_back(toff[(size_t)T] / 2);
         out->gtab.push_back(0);
     }
-    out->pairs.push_back(make_uint2(0, 0));  // the clamped staging loads stay inside
-    out->pairs.push_back(make_uint2(0, 0));
     return PK_OK;
 }
 

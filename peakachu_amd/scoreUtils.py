@@ -12,6 +12,24 @@ from . import _lib, utils
 from .forest import as_flat_forest
 
 
+# The device copy of a model (pk_forest: packed trees, rank tables, LDS images) is built
+# once per model object and device, not once per chromosome: score_genome constructs a
+# Chromosome per chromosome with the same model (peakachu/score_genome.py:58).
+_FOREST_CACHE = []  # [(model, device, HipForest)], most recent last, at most 4
+
+
+def _device_forest(model, device):
+    for i, (m, d, hf) in enumerate(_FOREST_CACHE):
+        if m is model and d == device and hf.h:
+            _FOREST_CACHE.append(_FOREST_CACHE.pop(i))
+            return hf
+    hf = _lib.HipForest(as_flat_forest(model), device=device)
+    _FOREST_CACHE.append((model, device, hf))
+    while len(_FOREST_CACHE) > 4:
+        _FOREST_CACHE.pop(0)[2].close()
+    return hf
+
+
 class Chromosome():
     def __init__(self, M, model, raw_M=None, weights=None,
                  lower=6, upper=300, cname='chrm', res=10000, width=5, device=0):
@@ -108,7 +126,7 @@ class Chromosome():
 
     def _forest(self):
         if self._hf is None:
-            self._hf = _lib.HipForest(as_flat_forest(self.model), device=self.device)
+            self._hf = _device_forest(self.model, self.device)
         return self._hf
 
     def getwindow(self, coords):
