@@ -59,7 +59,7 @@ def main():
                 if k:
                     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
                     ids[k][r["Counter_Name"]].add(r["Dispatch_Id"])
-                    names[k].add(r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", ""))
+                    names[k].add(r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0])
     out = {"source_sha": source_sha(), "candidates": n_cand}
     for k in ("extract", "quant", "forest"):
         if k not in acc:
