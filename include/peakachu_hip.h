@@ -41,6 +41,7 @@ typedef struct pk_forest pk_forest;
 typedef struct pk_matrix pk_matrix;
 typedef struct pk_cands pk_cands;
 typedef struct pk_comm pk_comm;
+typedef struct pk_csr pk_csr;
 
 /* ---- library / device --------------------------------------------------- */
 int pk_abi_version(void);
@@ -75,6 +76,30 @@ pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *indptr,
                             const double *exp_arr, int32_t exp_len,
                             int32_t dlo, int32_t dhi);
 void pk_matrix_destroy(pk_matrix *);
+
+/* ---- the per-chromosome preparation of Chromosome.__init__ on the device ----------
+ * (peakachu/scoreUtils.py:13-38, peakachu/utils.py:139-170): the contact matrix is
+ * uploaded ONCE as the canonical CSR the driver holds; the band filter, the validity
+ * flags and the diagonal means of calculate_expected and the facts get_candidate needs
+ * about the counts are computed from that copy on the device.
+ * pk_csr_info: info[0] finite non-zero entries, [1] non-finite entries, [2] finite entries
+ * that are not non-negative integers, [3] finite negative entries; *vmax largest finite value. */
+pk_csr *pk_csr_upload(int device, int32_t n, const int32_t *indptr, const int32_t *indices,
+                      const double *data);
+void pk_csr_destroy(pk_csr *);
+int pk_csr_info(const pk_csr *, int64_t info[4], double *vmax);
+/* band of col-row in [dlo, dhi] holding the finite non-zero entries (keep_nan = 0: the
+ * filter of peakachu/scoreUtils.py:30-33) or every non-zero entry, NaN included
+ * (keep_nan = 1: what utils.calculate_expected keeps in balanced mode, utils.py:156).
+ * The expected curve is attached later with pk_matrix_set_expected. */
+pk_matrix *pk_matrix_from_csr(pk_csr *, int32_t dlo, int32_t dhi, int keep_nan);
+int pk_matrix_set_expected(pk_matrix *, const double *exp_arr, int32_t exp_len);
+/* means of diagonals first..top of `band` over the valid bins, as pk_expected_means, with
+ * the validity flags taken from the uploaded matrix: mode 0 (raw, utils.py:145-148) a bin is
+ * valid when its column holds a positive finite entry (= column sum > 0 for non-negative
+ * counts; PK_E_UNSUPPORTED when negative entries exist), mode 1 (utils.py:150-155) when it
+ * is the row or column of a finite non-zero entry.  means[i - first]. */
+int pk_csr_expected_means(pk_csr *, pk_matrix *band, int first, int top, int mode, double *means);
 
 /* ---- Chromosome.getwindow (peakachu/scoreUtils.py:70-93) and the body of
  * trainUtils.buildmatrix (peakachu/trainUtils.py:31-42): gather the

@@ -39,6 +39,12 @@ SIGNATURES = {
     "pk_matrix_create": (_vp, [C.c_int, C.c_int32, _i32p, _i32p, _f64p, _f64p, C.c_int32,
                                C.c_int32, C.c_int32]),
     "pk_matrix_destroy": (None, [_vp]),
+    "pk_csr_upload": (_vp, [C.c_int, C.c_int32, _i32p, _i32p, _f64p]),
+    "pk_csr_destroy": (None, [_vp]),
+    "pk_csr_info": (C.c_int, [_vp, _i64p, C.POINTER(C.c_double)]),
+    "pk_matrix_from_csr": (_vp, [_vp, C.c_int32, C.c_int32, C.c_int]),
+    "pk_matrix_set_expected": (C.c_int, [_vp, _f64p, C.c_int32]),
+    "pk_csr_expected_means": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _f64p]),
     "pk_extract": (C.c_int, [_vp, C.c_int, C.c_int64, _i32p, _i32p, _vp, _vp, _i64p,
                              C.POINTER(C.c_int64)]),
     "pk_predict": (C.c_int, [_vp, C.c_int64, _f32p, _f64p]),
@@ -166,6 +172,46 @@ class HipForest:
     __del__ = close
 
 
+class HipCsr:
+    """A contact matrix uploaded once (pk_csr): canonical CSR in, device-side facts out."""
+
+    def __init__(self, M, device=0):
+        L = require_device()
+        self._L = L
+        self.n = int(M.shape[0])
+        nnz = int(M.indptr[-1])
+        self.h = L.pk_csr_upload(device, self.n, np.ascontiguousarray(M.indptr, np.int32),
+                                 np.ascontiguousarray(M.indices, np.int32) if nnz else np.zeros(1, np.int32),
+                                 np.ascontiguousarray(M.data, np.float64) if nnz else np.zeros(1))
+        if not self.h:
+            raise PeakachuHipError("pk_csr_upload: " + last_error())
+        self.device = device
+        info = np.zeros(4, np.int64)
+        vmax = C.c_double(0.0)
+        check(L.pk_csr_info(self.h, info, C.byref(vmax)), "pk_csr_info")
+        self.n_finite, self.n_nonfinite, self.n_noninteger, self.n_negative = [int(v) for v in info]
+        self.vmax = float(vmax.value)
+
+    def band(self, dlo, dhi, keep_nan=False):
+        h = self._L.pk_matrix_from_csr(self.h, int(dlo), int(dhi), 1 if keep_nan else 0)
+        if not h:
+            raise PeakachuHipError("pk_matrix_from_csr: " + last_error())
+        return HipMatrix._wrap(self._L, h, self.n, self.device)
+
+    def expected_means(self, band, first, top, balanced):
+        out = np.empty(top - first + 1, np.float64)
+        check(self._L.pk_csr_expected_means(self.h, band.h, int(first), int(top), 1 if balanced else 0, out),
+              "pk_csr_expected_means")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.pk_csr_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 class HipMatrix:
     """Device-resident band matrix + expected vector (pk_matrix)."""
 
@@ -183,6 +229,16 @@ class HipMatrix:
         if not self.h:
             raise PeakachuHipError("pk_matrix_create: " + last_error())
         self.n, self.dlo, self.dhi, self.device = int(n), int(dlo), int(dhi), device
+
+    @classmethod
+    def _wrap(cls, L, h, n, device):
+        self = cls.__new__(cls)
+        self._L, self.h, self.n, self.device = L, h, n, device
+        return self
+
+    def set_expected(self, exp_arr):
+        e = np.ascontiguousarray(exp_arr, np.float64)
+        check(self._L.pk_matrix_set_expected(self.h, e, int(e.size)), "pk_matrix_set_expected")
 
     def expected_means(self, top, valid):
         """Diagonal means of calculate_expected (this band must start at diagonal 0)."""

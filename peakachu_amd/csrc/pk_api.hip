@@ -631,7 +631,7 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
                  hipMemcpyAsync(d_data, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice,
                                 ctx->stream) == hipSuccess;
         if (ok && with_norm) m->norm = m->band + band_bytes / sizeof(double);
-        if (ok) ok = pk_launch_band_build(ctx, m, d_indptr, d_indices, d_data, nnz) == PK_OK;
+        if (ok) ok = pk_launch_band_build(ctx, m, d_indptr, d_indices, d_data, nnz, 0) == PK_OK;
         if (ok) ok = hipStreamSynchronize(ctx->stream) == hipSuccess;
         if (!ok && !g_err[0]) pk_set_error("pk_matrix_create: upload / band build failed");
     } else {
@@ -645,6 +645,171 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
         return nullptr;
     }
     return m;
+}
+
+// ------------------------------------------- uploaded CSR and what is made from it
+extern "C" pk_csr *pk_csr_upload(int device, int32_t n, const int32_t *indptr, const int32_t *indices,
+                                 const double *data)
+{
+    PK_API_LOCK;
+    if (n <= 0 || !indptr || indptr[0] != 0 || indptr[n] < 0 || (indptr[n] > 0 && (!indices || !data))) {
+        pk_set_error("pk_csr_upload: bad arguments / malformed CSR");
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(device);
+    if (!ctx) return nullptr;
+    pk_csr *c = new pk_csr();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->n = n;
+    c->nnz = indptr[n];
+    const size_t z = (size_t)(c->nnz > 0 ? c->nnz : 1);
+    unsigned long long *d_info = nullptr;
+    bool ok = hipMalloc((void **)&c->indptr, sizeof(int32_t) * (size_t)(n + 1)) == hipSuccess &&
+              hipMalloc((void **)&c->indices, sizeof(int32_t) * z) == hipSuccess &&
+              hipMalloc((void **)&c->data, sizeof(double) * z) == hipSuccess &&
+              hipMalloc((void **)&c->valid_raw, (size_t)n) == hipSuccess &&
+              hipMalloc((void **)&c->valid_bal, (size_t)n) == hipSuccess &&
+              hipMalloc((void **)&d_info, 5 * sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) pk_set_error("pk_csr_upload: device allocation failed (%lld entries)", (long long)c->nnz);
+    if (ok) {
+        ok = hipMemcpyAsync(c->indptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
+                            ctx->stream) == hipSuccess;
+        if (ok && c->nnz > 0)
+            ok = hipMemcpyAsync(c->indices, indices, sizeof(int32_t) * z, hipMemcpyHostToDevice,
+                                ctx->stream) == hipSuccess &&
+                 hipMemcpyAsync(c->data, data, sizeof(double) * z, hipMemcpyHostToDevice, ctx->stream) ==
+                     hipSuccess;
+        if (ok)
+            ok = pk_launch_csr_info(ctx, c->indptr, c->indices, c->data, c->nnz, n, d_info, c->valid_raw,
+                                    c->valid_bal) == PK_OK;
+        if (ok)
+            ok = hipMemcpyAsync(c->info, d_info, sizeof(c->info), hipMemcpyDeviceToHost, ctx->stream) ==
+                     hipSuccess &&
+                 hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (!ok && !g_err[0]) pk_set_error("pk_csr_upload: upload / scan failed");
+    }
+    if (d_info) hipFree(d_info);
+    if (!ok) {
+        pk_csr_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void pk_csr_destroy(pk_csr *c)
+{
+    PK_API_LOCK;
+    if (!c) return;
+    hipSetDevice(c->device);
+    void *ptrs[] = {c->indptr, c->indices, c->data, c->valid_raw, c->valid_bal};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    delete c;
+}
+
+extern "C" int pk_csr_info(const pk_csr *c, int64_t info[4], double *vmax)
+{
+    if (!c || !info) return PK_E_INVALID;
+    for (int i = 0; i < 4; i++) info[i] = (int64_t)c->info[i];
+    if (vmax) {
+        double v;
+        memcpy(&v, &c->info[4], 8);
+        *vmax = v;
+    }
+    return PK_OK;
+}
+
+extern "C" pk_matrix *pk_matrix_from_csr(pk_csr *c, int32_t dlo, int32_t dhi, int keep_nan)
+{
+    PK_API_LOCK;
+    if (!c || dhi < dlo) {
+        pk_set_error("pk_matrix_from_csr: bad arguments");
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(c->device);
+    if (!ctx) return nullptr;
+    pk_matrix *m = new pk_matrix();
+    m->device = c->device;
+    m->n = c->n;
+    m->dlo = dlo;
+    m->dhi = dhi;
+    m->ld = ((int64_t)c->n + 63) / 64 * 64;
+    m->band = nullptr;
+    m->exp_arr = nullptr;
+    m->exp_len = 0;
+    const size_t band_bytes = (size_t)(dhi - dlo + 1) * m->ld * sizeof(double);
+    const bool with_norm = !keep_nan && 2 * band_bytes < (1ull << 32) - 4096;
+    bool ok = hipMalloc((void **)&m->band, with_norm ? 2 * band_bytes : band_bytes) == hipSuccess;
+    if (!ok) pk_set_error("pk_matrix_from_csr: device allocation of %zu band bytes failed", band_bytes);
+    if (ok && with_norm) m->norm = m->band + band_bytes / sizeof(double);
+    if (ok)
+        ok = pk_launch_band_build(ctx, m, c->indptr, c->indices, c->data, c->nnz, keep_nan ? 2 : 1) == PK_OK &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) {
+        if (!g_err[0]) pk_set_error("pk_matrix_from_csr: band build failed");
+        pk_matrix_destroy(m);
+        return nullptr;
+    }
+    return m;
+}
+
+extern "C" int pk_matrix_set_expected(pk_matrix *m, const double *exp_arr, int32_t exp_len)
+{
+    PK_API_LOCK;
+    if (!m || !exp_arr || exp_len <= 0) {
+        pk_set_error("pk_matrix_set_expected: bad arguments");
+        return PK_E_INVALID;
+    }
+    pk_device_ctx *ctx = pk_ctx(m->device);
+    if (!ctx) return PK_E_NODEVICE;
+    if (m->exp_arr) PK_HIP(hipFree(m->exp_arr));
+    m->exp_arr = nullptr;
+    PK_HIP(hipMalloc((void **)&m->exp_arr, sizeof(double) * (size_t)exp_len));
+    PK_HIP(hipMemcpy(m->exp_arr, exp_arr, sizeof(double) * (size_t)exp_len, hipMemcpyHostToDevice));
+    m->exp_len = exp_len;
+    m->norm_tried = false;  // the quotient band depends on the expected values
+    m->clean = false;
+    return PK_OK;
+}
+
+extern "C" int pk_csr_expected_means(pk_csr *c, pk_matrix *band, int first, int top, int mode,
+                                     double *means)
+{
+    PK_API_LOCK;
+    if (!c || !band || !means || first < 0 || top < first || band->device != c->device ||
+        band->n != c->n || first < band->dlo || top > band->dhi || top >= band->n) {
+        pk_set_error("pk_csr_expected_means: bad arguments (diagonals %d..%d must lie in the band)", first, top);
+        return PK_E_INVALID;
+    }
+    if (mode == 0 && c->info[3] != 0) {
+        // the reference tests the SIGN of a column sum; with negative entries "holds a
+        // positive entry" is not the same thing
+        pk_set_error("pk_csr_expected_means: negative counts, use the host path");
+        return PK_E_UNSUPPORTED;
+    }
+    pk_device_ctx *ctx = pk_ctx(c->device);
+    if (!ctx) return PK_E_NODEVICE;
+    const int nd = top - first + 1;
+    double *d_scr = nullptr, *d_means = nullptr;
+    int rc = PK_OK;
+    if (hipMalloc((void **)&d_scr, (size_t)nd * band->ld * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_means, (size_t)nd * 8) != hipSuccess) {
+        pk_set_error("pk_csr_expected_means: device allocation failed");
+        rc = PK_E_NOMEM;
+    }
+    if (!rc)
+        rc = pk_launch_expected_means(ctx, band, first, top, mode == 0 ? c->valid_raw : c->valid_bal,
+                                      d_scr, d_means);
+    if (!rc && (hipMemcpyAsync(means, d_means, (size_t)nd * 8, hipMemcpyDeviceToHost, ctx->stream) !=
+                    hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        pk_set_error("pk_csr_expected_means: kernel / download failed");
+        rc = PK_E_HIP;
+    }
+    if (d_scr) hipFree(d_scr);
+    if (d_means) hipFree(d_means);
+    return rc;
 }
 
 extern "C" void pk_matrix_destroy(pk_matrix *m)
@@ -735,7 +900,7 @@ extern "C" int pk_expected_means(pk_matrix *m, int top, const uint8_t *valid, do
     if (!rc && hipMemcpyAsync(d_valid, valid, (size_t)m->n, hipMemcpyHostToDevice, ctx->stream) !=
                    hipSuccess)
         rc = PK_E_HIP;
-    if (!rc) rc = pk_launch_expected_means(ctx, m, top, d_valid, d_scr, d_means);
+    if (!rc) rc = pk_launch_expected_means(ctx, m, 0, top, d_valid, d_scr, d_means);
     if (!rc && (hipMemcpyAsync(means, d_means, (size_t)(top + 1) * 8, hipMemcpyDeviceToHost,
                                ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess)) {

@@ -271,6 +271,18 @@ struct pk_matrix {
     bool clean = false;
 };
 
+// a contact matrix uploaded once (CSR); bands, validity flags and value facts are made
+// from it on the device
+struct pk_csr {
+    int device;
+    int32_t n;
+    int64_t nnz;
+    int32_t *indptr, *indices;   // device
+    double *data;                // device
+    uint8_t *valid_raw, *valid_bal;  // device [n], see csr_info_kernel
+    unsigned long long info[5];  // host copy: finite, non-finite, non-integer, negative, max bits
+};
+
 struct pk_cands {
     int device;
     int64_t N;
@@ -291,7 +303,10 @@ struct pk_cands {
 // ------------------------------------------------------------ kernel entry
 // (implemented in the .hip files; all launch on ctx->stream)
 int pk_launch_band_build(pk_device_ctx *, pk_matrix *, const int32_t *d_indptr,
-                         const int32_t *d_indices, const double *d_data, int64_t nnz);
+                         const int32_t *d_indices, const double *d_data, int64_t nnz, int filter);
+int pk_launch_csr_info(pk_device_ctx *, const int32_t *d_indptr, const int32_t *d_indices,
+                       const double *d_data, int64_t nnz, int n, unsigned long long *d_info5,
+                       uint8_t *d_valid_raw, uint8_t *d_valid_bal);
 
 // features of candidates [c0, c0+cn) -> tiles (tile width BLK) + status.
 // If fea64_rows != nullptr also writes row-major float64 features [cn][F].
@@ -314,8 +329,8 @@ int pk_forest_tile_width(int F);  // candidates per feature tile for F features
 
 int pk_launch_compact(pk_device_ctx *, const pk_matrix *, pk_cands *, double thre,
                       int64_t batch);
-int pk_launch_expected_means(pk_device_ctx *, const pk_matrix *m, int top, const uint8_t *d_valid,
-                             double *d_scratch, double *d_means);
+int pk_launch_expected_means(pk_device_ctx *, const pk_matrix *m, int first, int top,
+                             const uint8_t *d_valid, double *d_scratch, double *d_means);
 int pk_launch_candidates(pk_device_ctx *, const pk_matrix *raw, int lower, int upper,
                          const int64_t *d_kstar, const double *d_bg, const double *d_w,
                          const double *d_mustar, int64_t n_mustar, int64_t *d_total,

@@ -7,26 +7,86 @@
 
 namespace {
 
-// ---- CSR -> diagonal-major band: one thread per stored entry ------------
-__global__ void band_build_kernel(const int32_t *__restrict__ indptr,
-                                  const int32_t *__restrict__ indices,
-                                  const double *__restrict__ data, int64_t nnz, int n, int dlo,
-                                  int dhi, int64_t ld, double *__restrict__ band)
+// row of CSR entry e: largest r with indptr[r] <= e
+__device__ __forceinline__ int csr_row_of(const int32_t *__restrict__ indptr, int n, int64_t e)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nnz) return;
-    // row of entry e: largest r with indptr[r] <= e
     int lo = 0, hi = n;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if ((int64_t)indptr[mid] <= e) lo = mid;
         else hi = mid;
     }
-    const int r = lo;
+    return lo;
+}
+
+// ---- CSR -> diagonal-major band: one thread per stored entry ------------
+// filter: 0 = every stored entry (the host has filtered already), 1 = finite non-zero
+// entries only (the band filter of peakachu/scoreUtils.py:30-33 done here), 2 = non-zero
+// entries including NaN (what utils.calculate_expected keeps in balanced mode)
+__global__ void band_build_kernel(const int32_t *__restrict__ indptr,
+                                  const int32_t *__restrict__ indices,
+                                  const double *__restrict__ data, int64_t nnz, int n, int dlo,
+                                  int dhi, int64_t ld, double *__restrict__ band, int filter)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
     const int col = indices[e];
+    const double v = data[e];
+    if (filter && (v == 0.0 || (filter == 1 && !(v - v == 0.0)))) return;  // (v - v != 0: inf or NaN)
+    const int r = csr_row_of(indptr, n, e);
     const int k = col - r;
     if (k < dlo || k > dhi || col < 0 || col >= n) return;
-    band[(int64_t)(k - dlo) * ld + r] = data[e];
+    band[(int64_t)(k - dlo) * ld + r] = v;
+}
+
+// ---- facts about the stored values, and the bins calculate_expected calls valid -------
+// info[0] finite non-zero entries, [1] non-finite entries, [2] finite entries that are not
+// non-negative integers, [3] finite negative entries; vmax_bits = largest finite value
+// (as ordered bits of a non-negative double).  valid_raw[c] = column c holds a positive
+// finite entry; valid_bal[r] = valid_bal[c] = 1 for every finite non-zero entry
+// (peakachu/utils.py:145-155).
+__global__ void csr_info_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                const double *__restrict__ data, int64_t nnz, int n,
+                                unsigned long long *__restrict__ info,
+                                unsigned long long *__restrict__ vmax_bits,
+                                uint8_t *__restrict__ valid_raw, uint8_t *__restrict__ valid_bal)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned c_fin = 0, c_non = 0, c_frac = 0, c_neg = 0;
+    unsigned long long mx = 0;
+    if (e < nnz) {
+        const double v = data[e];
+        const int col = indices[e];
+        if (!(v - v == 0.0)) {
+            c_non = 1;
+        } else if (v != 0.0) {
+            c_fin = 1;
+            if (v < 0.0) c_neg = 1;
+            if (v < 0.0 || v != __builtin_floor(v)) c_frac = 1;
+            if (v > 0.0) {
+                mx = (unsigned long long)__double_as_longlong(v);
+                if (col >= 0 && col < n) valid_raw[col] = 1;
+            }
+            if (col >= 0 && col < n) {
+                valid_bal[col] = 1;
+                valid_bal[csr_row_of(indptr, n, e)] = 1;
+            }
+        }
+    }
+    // wave-level reduction, one atomic per wave and counter
+    const unsigned long long m_fin = __ballot(c_fin), m_non = __ballot(c_non), m_frac = __ballot(c_frac),
+                             m_neg = __ballot(c_neg);
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (m_fin) atomicAdd(&info[0], (unsigned long long)__popcll(m_fin));
+        if (m_non) atomicAdd(&info[1], (unsigned long long)__popcll(m_non));
+        if (m_frac) atomicAdd(&info[2], (unsigned long long)__popcll(m_frac));
+        if (m_neg) atomicAdd(&info[3], (unsigned long long)__popcll(m_neg));
+        if (mx) atomicMax(vmax_bits, mx);
+    }
 }
 
 // ---- survivors per reference batch (scoreUtils.py:104-108) --------------
@@ -308,7 +368,7 @@ constexpr int EXP_MAXLEAF = 128;  // an 8192-element buffer splits into at most 
 
 // one workgroup per diagonal
 __global__ __launch_bounds__(EXP_THREADS) void expected_means_kernel(
-    const double *__restrict__ band, int64_t ld, int n, int top,
+    const double *__restrict__ band, int64_t ld, int dlo, int n, int first, int top,
     const uint8_t *__restrict__ valid, double *__restrict__ scratch, double *__restrict__ means)
 {
     __shared__ int cnt[EXP_THREADS + 1];
@@ -316,12 +376,12 @@ __global__ __launch_bounds__(EXP_THREADS) void expected_means_kernel(
     __shared__ double leaf_sum[EXP_MAXLEAF];
     __shared__ int n_leaf;
     __shared__ double total;
-    const int i = blockIdx.x;  // diagonal
+    const int i = first + blockIdx.x;  // diagonal
     if (i > top) return;
     const int tid = threadIdx.x;
     const int len = n - i;
-    const double *diag = band + (int64_t)i * ld;
-    double *vals = scratch + (int64_t)i * ld;
+    const double *diag = band + (int64_t)(i - dlo) * ld;
+    double *vals = scratch + (int64_t)(i - first) * ld;
     // 1. ordered compaction of diag[r] over valid[r] & valid[r+i] (thread t owns a
     //    contiguous run of rows, so thread order = row order)
     const int seg = (len + EXP_THREADS - 1) / EXP_THREADS;
@@ -412,14 +472,33 @@ __global__ __launch_bounds__(EXP_THREADS) void expected_means_kernel(
 
 }  // namespace
 
-// diagonal means for calculate_expected; `m` is a band with dlo == 0
-int pk_launch_expected_means(pk_device_ctx *ctx, const pk_matrix *m, int top,
+// diagonal means first..top for calculate_expected; `m` is a band with dlo <= first,
+// dhi >= top; d_means and d_scratch are indexed from diagonal `first`
+int pk_launch_expected_means(pk_device_ctx *ctx, const pk_matrix *m, int first, int top,
                              const uint8_t *d_valid, double *d_scratch, double *d_means)
 {
     pk_prof_scope prof(ctx, PK_K_BAND);
-    hipLaunchKernelGGL(expected_means_kernel, dim3((unsigned)(top + 1)), dim3(EXP_THREADS), 0,
-                       ctx->stream, m->band, m->ld, m->n, top, d_valid, d_scratch, d_means);
+    hipLaunchKernelGGL(expected_means_kernel, dim3((unsigned)(top - first + 1)), dim3(EXP_THREADS), 0,
+                       ctx->stream, m->band, m->ld, m->dlo, m->n, first, top, d_valid, d_scratch,
+                       d_means - first);
     PK_HIP(hipGetLastError());
+    return PK_OK;
+}
+
+int pk_launch_csr_info(pk_device_ctx *ctx, const int32_t *d_indptr, const int32_t *d_indices,
+                       const double *d_data, int64_t nnz, int n, unsigned long long *d_info5,
+                       uint8_t *d_valid_raw, uint8_t *d_valid_bal)
+{
+    pk_prof_scope prof(ctx, PK_K_BAND);
+    PK_HIP(hipMemsetAsync(d_info5, 0, 5 * sizeof(unsigned long long), ctx->stream));
+    PK_HIP(hipMemsetAsync(d_valid_raw, 0, (size_t)n, ctx->stream));
+    PK_HIP(hipMemsetAsync(d_valid_bal, 0, (size_t)n, ctx->stream));
+    if (nnz > 0) {
+        hipLaunchKernelGGL(csr_info_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream,
+                           d_indptr, d_indices, d_data, nnz, n, d_info5, d_info5 + 4, d_valid_raw,
+                           d_valid_bal);
+        PK_HIP(hipGetLastError());
+    }
     return PK_OK;
 }
 
@@ -452,7 +531,7 @@ int pk_launch_candidates(pk_device_ctx *ctx, const pk_matrix *raw, int lower, in
 }
 
 int pk_launch_band_build(pk_device_ctx *ctx, pk_matrix *m, const int32_t *d_indptr,
-                         const int32_t *d_indices, const double *d_data, int64_t nnz)
+                         const int32_t *d_indices, const double *d_data, int64_t nnz, int filter)
 {
     pk_prof_scope prof(ctx, PK_K_BAND);
     const size_t bytes = (size_t)(m->dhi - m->dlo + 1) * m->ld * sizeof(double);
@@ -460,7 +539,7 @@ int pk_launch_band_build(pk_device_ctx *ctx, pk_matrix *m, const int32_t *d_indp
     if (nnz > 0) {
         hipLaunchKernelGGL(band_build_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0,
                            ctx->stream, d_indptr, d_indices, d_data, nnz, m->n, m->dlo, m->dhi,
-                           m->ld, m->band);
+                           m->ld, m->band, filter);
         PK_HIP(hipGetLastError());
     }
     return PK_OK;

@@ -36,24 +36,9 @@ class Chromosome():
         # peakachu/scoreUtils.py:13-14
         lower = max(lower, width + 1)
         upper = min(upper, M.shape[0] - 2 * width)
-        # expected values (peakachu/scoreUtils.py:16-24)
-        # (diagonal means on the device, isotonic fit on the host)
-        if weights is None:
-            self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=True, device=device)
-            if M is raw_M:
-                self.background = self.exp_arr
-            else:
-                self.background = utils.calculate_expected(raw_M, upper + 2 * width, raw=True,
-                                                           device=device)
-        else:
-            self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=False, device=device)
-            self.background = self.exp_arr
-
         self.raw_M = raw_M
         self.weights = weights
         self._raw_is_M = M is raw_M
-        # peakachu/scoreUtils.py:30-33
-        self.M = utils.band_filter(M, width, upper)
         self.chromname = cname
         self.r = res
         self.w = width
@@ -63,7 +48,106 @@ class Chromosome():
         self._hm = None
         self._hf = None
         self._cands = None
+        self._M_src, self._M_val = M, None   # self.M (the band-filtered CSR) is made on demand
+        self._shape = M.shape
+        self._raw_facts = None
+        # expected values (peakachu/scoreUtils.py:16-24), band filter (:30-33): on the device
+        # from one upload of the matrix when its values allow it, else on the host
+        if not self._prepare_on_device(M, raw_M, weights, upper, width):
+            if weights is None:
+                self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=True, device=device)
+                if M is raw_M:
+                    self.background = self.exp_arr
+                else:
+                    self.background = utils.calculate_expected(raw_M, upper + 2 * width, raw=True,
+                                                               device=device)
+            else:
+                self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=False, device=device)
+                self.background = self.exp_arr
         self.get_candidate(lower, upper)
+
+    # self.M: peakachu/scoreUtils.py:30-33 (finite entries with -2w < col-row < upper+2w).
+    # The device builds its band straight from the unfiltered matrix with the same filter,
+    # so the host copy is only made when somebody reads it.
+    @property
+    def M(self):
+        if self._M_val is None:
+            self._M_val = utils.band_filter(self._M_src, self.w, self.upper)
+        return self._M_val
+
+    @M.setter
+    def M(self, value):
+        self._M_val = value
+
+    def _expected_on_device(self, csr, band, maxdis, balanced):
+        """utils.calculate_expected with the diagonal means taken from device bands of the
+        uploaded matrix.  `band` (finite entries, raw mode only) may cover a prefix of the
+        diagonals; the rest comes from a band built for the purpose."""
+        n = csr.n
+        top = min(int(maxdis), n - 1)
+        exp_arr = np.zeros(int(maxdis) + 1)
+        done = -1
+        if not balanced and band is not None and band.dlo <= 0:
+            done = min(top, band.dhi)
+            exp_arr[:done + 1] = csr.expected_means(band, 0, done, False)
+        if done < top:
+            # balanced mode keeps NaN entries in the diagonals (peakachu/utils.py:156)
+            extra = csr.band(done + 1, top, keep_nan=balanced)
+            try:
+                exp_arr[done + 1:top + 1] = csr.expected_means(extra, done + 1, top, balanced)
+            finally:
+                extra.close()
+        return utils.isotonic_expected(exp_arr)
+
+    def _prepare_on_device(self, M, raw_M, weights, upper, width):
+        Mc = utils.canonical_csr(M)
+        n = Mc.shape[0]
+        if Mc.nnz == 0 or n <= 2 * width:
+            return False
+        maxdis = upper + 2 * width
+        dlo, dhi = -2 * width + 1, max(upper + 2 * width - 1, -2 * width + 1)
+        csr = rcsr = None
+        try:
+            csr = _lib.HipCsr(Mc, device=self.device)
+            balanced = weights is not None
+            if not balanced and csr.n_negative:
+                return False  # the validity test is a sign of a column sum: host path
+            band = csr.band(dlo, dhi)
+            band.dlo, band.dhi = dlo, dhi
+            self.exp_arr = self._expected_on_device(csr, band, maxdis, balanced)
+            band.set_expected(self.exp_arr)
+            self._hm = band
+            if balanced or self._raw_is_M:
+                self.background = self.exp_arr
+            if self._raw_is_M:
+                self._raw_facts = dict(integer=csr.n_noninteger == 0, vmax=csr.vmax, nnz=Mc.nnz, band=band)
+            else:
+                Rc = utils.canonical_csr(raw_M)
+                if Rc.nnz == 0:
+                    if not balanced:
+                        self._hm = None
+                        return False
+                    self._raw_facts = dict(integer=True, vmax=0.0, nnz=0, band=None)
+                    return True
+                rcsr = _lib.HipCsr(Rc, device=self.device)
+                if not balanced:
+                    # .hic style: M holds normalised values, the background comes from the raw counts
+                    if rcsr.n_negative:
+                        self._hm = None
+                        return False
+                    self.background = self._expected_on_device(rcsr, None, maxdis, False)
+                hi = min(int(upper), self.background.size - 1, n - 1)
+                rband = None
+                if hi >= self.lower:
+                    rband = rcsr.band(self.lower, hi)
+                    rband.dlo, rband.dhi = self.lower, hi
+                self._raw_facts = dict(integer=rcsr.n_noninteger == 0, vmax=rcsr.vmax, nnz=Rc.nnz,
+                                       band=rband, own=True)
+            return True
+        finally:
+            for c in (csr, rcsr):
+                if c is not None:
+                    c.close()
 
     # ----------------------------------------------------------- host side
     def get_candidate(self, lower, upper):
@@ -83,30 +167,43 @@ class Chromosome():
         self._cands_key = (self.ridx, self.cidx)
 
     def _candidates_on_device(self, lower, upper):
-        raw = utils.canonical_csr(self.raw_M)
-        n = raw.shape[0]
-        hi = min(int(upper), self.background.size - 1, n - 1)
-        if hi < lower or raw.nnz == 0:
-            return None
-        if not np.all(raw.data[np.isfinite(raw.data)] == np.floor(raw.data[np.isfinite(raw.data)])):
-            return None  # the tables assume integer counts
-        if self.weights is None and self._raw_is_M:
-            rawm = self._matrix()  # the scoring band already holds these counts
-            own = False
+        facts = self._raw_facts
+        self._raw_facts = None
+        own = False
+        if facts is not None and (lower, upper) == (self.lower, self.upper):
+            # everything get_candidate needs to know about the raw counts came with the upload
+            n = self._M_src.shape[0]
+            hi = min(int(upper), self.background.size - 1, n - 1)
+            if hi < lower or facts["nnz"] == 0 or not facts["integer"] or facts["band"] is None:
+                if facts.get("own") and facts["band"] is not None:
+                    facts["band"].close()
+                return None
+            rawm, own, kmax = facts["band"], bool(facts.get("own")), int(facts["vmax"])
         else:
-            rawm = _lib.HipMatrix(raw.indptr, raw.indices, raw.data, n, self.background,
-                                  lower, hi, device=self.device)
-            own = True
+            raw = utils.canonical_csr(self.raw_M)
+            n = raw.shape[0]
+            hi = min(int(upper), self.background.size - 1, n - 1)
+            if hi < lower or raw.nnz == 0:
+                return None
+            fin = raw.data[np.isfinite(raw.data)]
+            if not np.all(fin == np.floor(fin)):
+                return None  # the tables assume integer counts
+            kmax = int(fin.max()) if fin.size else 0
+            if self.weights is None and self._raw_is_M:
+                rawm = self._matrix()  # the scoring band already holds these counts
+            else:
+                rawm = _lib.HipMatrix(raw.indptr, raw.indices, raw.data, n, self.background,
+                                      lower, hi, device=self.device)
+                own = True
         try:
             bg = np.ascontiguousarray(self.background[:hi + 1], np.float64)
             if self.weights is None:
                 kstar = utils._poisson_count_thresholds(bg)
                 cands, amb = _lib.HipCands.from_band(rawm, lower, hi, bg, kstar=kstar)
             else:
-                kmax = int(np.nanmax(raw.data)) if raw.nnz else 0
                 cands, amb = _lib.HipCands.from_band(rawm, lower, hi, bg,
                                                      weights=np.asarray(self.weights, np.float64),
-                                                     mustar=utils.poisson_mu_thresholds(kmax))
+                                                     mustar=utils.poisson_mu_thresholds(max(kmax, 0)))
         finally:
             if own:
                 rawm.close()
@@ -159,9 +256,9 @@ class Chromosome():
         ri, ci, prob_pool, signal = cd.fetch()
         ri = ri.astype(int)
         ci = ci.astype(int)
-        result = sparse.csr_matrix((prob_pool, (ri, ci)), shape=self.M.shape)
+        result = sparse.csr_matrix((prob_pool, (ri, ci)), shape=self._shape)
         if ri.size > 0:
-            self.M = sparse.csr_matrix((signal, (ri, ci)), shape=self.M.shape)
+            self.M = sparse.csr_matrix((signal, (ri, ci)), shape=self._shape)
         else:
             self.M = result
         self._hm = None  # self.M changed, as in the reference

@@ -94,10 +94,17 @@ def calculate_expected(M, maxdis, raw=False, device=None):
             diag = D[i, :n - i][valid]
             if diag.size > 10:
                 exp_arr[i] = diag.mean()
+    return isotonic_expected(exp_arr)
+
+
+def isotonic_expected(exp_arr):
+    """peakachu/utils.py:173-178: non-increasing isotonic fit through the positive
+    diagonal means, evaluated at every distance (tiny: <= upper + 2w + 1 points)."""
+    from sklearn.isotonic import IsotonicRegression
     IR = IsotonicRegression(increasing=False, out_of_bounds="clip")
     _d = np.where(exp_arr > 0)[0]
     IR.fit(_d, exp_arr[_d])
-    return IR.predict(list(range(maxdis + 1)))
+    return IR.predict(list(range(exp_arr.size)))
 
 
 def _diagonal_means_device(M, keep, n, top, valid_cols, device):
