@@ -155,12 +155,14 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
 
 #define Q_PF16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define Q_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u};
-#define Q_PF_LOAD(q) \
-    if constexpr ((q) < PFN) pf##q = pf_src[min(tid + (q) * THREADS, pf_nu - 1)];
+// (register q is only moved when the group reaches it: a wave-uniform test)
+#define Q_PF_LOAD(q)                                                           \
+    if constexpr ((q) < PFN)                                                   \
+        if ((q) * THREADS < pf_nu) pf##q = pf_src[min(tid + (q) * THREADS, pf_nu - 1)];
 #define Q_PF_STORE(q)                                                          \
     if constexpr ((q) < PFN) {                                                 \
         const int u = tid + (q) * THREADS;                                     \
-        if (u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q;            \
+        if ((q) * THREADS < pf_nu && u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q; \
     }
 
 // One workgroup = 64 * CH candidates and 16 waves.  WPT = 1: wave s walks tree s of the
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         Q_STAMP(1);
         __syncthreads();  // every walk of the group is done: the trees may be overwritten
         Q_STAMP(2);
-        if (g + 1 < n_grp) { Q_PF16(Q_PF_STORE) }
+        if (g + 1 < n_grp && !(dbg & 4)) { Q_PF16(Q_PF_STORE) }  // (dbg 4: timing ablation, wrong results)
         const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
         if (owner && active && undecided) {
             for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
