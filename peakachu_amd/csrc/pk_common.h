@@ -208,6 +208,7 @@ int pk_launch_forest_img(pk_device_ctx *, pk_forest *f, const float *tiles, cons
 
 // ---- rank image (pk_qimage.hip builds it, pk_forest_q.hip quantizes tiles and walks it) ----
 #define PK_Q_CELLS 4096
+#define PK_Q_FTILE 8   // 128-candidate tiles per float32 tile handed to the quantizer
 struct pk_q_layout {
     int F, slots, ch;   // ch = walks per lane: 2 (128 candidates per workgroup) or 4 (256)
     int HB;             // bytes of a half tile: [F][128] u16

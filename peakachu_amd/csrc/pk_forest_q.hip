@@ -37,7 +37,10 @@ typedef __attribute__((address_space(3))) u64 lds_u64;
 
 
 // ------------------------------------------------------------------------
-// float32 feature tiles [tile][F][128] -> rank codes [tile][F][64][2] u16.
+// float32 feature tiles [tile / 8][F][8 x 128] -> rank codes [tile][F][64][2] u16.
+// (The extractor is asked for 1024-candidate float tiles: a feature's values of 8
+// consecutive 128-candidate tiles are then 4 KiB of contiguous HBM for the block that
+// converts this feature, instead of 8 pieces 60 KiB apart.)
 // Block (f, s): the tables of feature f in LDS, every s-th group of tiles.
 // code = r(x) << 5 with r(x) = number of the feature's distinct thresholds
 // below x (exact: the lookup cell settles all thresholds but the few -- mostly
@@ -47,8 +50,14 @@ __device__ __forceinline__ unsigned q_code(float x, const float *thr, const unsi
 {
     if (x != x) return 0xFFFFu;
     const unsigned e = lut[pk_q_cell(x, lo, inv)];
-    unsigned r = e & 0xFFFFu;             // thresholds in lower cells: all below x
-    for (unsigned k = e >> 16; k != 0 && thr[r] < x; k--) r++;  // those of x's own cell, ascending
+    unsigned r = e & 0xFFFFu;  // thresholds in lower cells: all below x
+    unsigned k = e >> 16;      // thresholds of x's own cell (ascending): mostly none or one
+    // the first one without a branch (thr[] is padded, so thr[r] is always readable) ...
+    const unsigned first = (k != 0) & (thr[r] < x);
+    r += first;
+    // ... the rare others in a loop only lanes with a crowded cell enter
+    if (first & (k > 1))
+        for (k--; k != 0 && thr[r] < x; k--) r++;
     return r << 5;
 }
 
@@ -66,34 +75,33 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     const int32_t *__restrict__ qoff, const unsigned *__restrict__ qlut,
     const float *__restrict__ qpar, unsigned short *__restrict__ qtiles)
 {
-    __shared__ float thr[2048];
+    __shared__ float thr[2048];  // n <= 2047 entries + padding
     __shared__ unsigned lut[PK_Q_CELLS];
     const int f = blockIdx.x;
     const int o = qoff[f], n = qoff[f + 1] - o;
-    for (int i = threadIdx.x; i < n; i += 256) thr[i] = qthr[o + i];
+    for (int i = threadIdx.x; i < 2048; i += 256) thr[i] = i < n ? qthr[o + i] : __builtin_inff();
     for (int i = threadIdx.x; i < PK_Q_CELLS; i += 256) lut[i] = qlut[(size_t)f * PK_Q_CELLS + i];
     const float lo = qpar[2 * f], inv = qpar[2 * f + 1];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // a wave converts four rows per trip: the loads of all four are in flight together
     // (one row per trip left the kernel waiting for HBM: 1.55 ms per 5.6 M candidates)
-    const int64_t stride = (int64_t)gridDim.y * 4;
-    for (int64_t t = (int64_t)blockIdx.y * 4 + wave; t < n_tiles; t += 4 * stride) {
+    // (a wave takes four consecutive tiles, the block sixteen: 8 KiB of this feature's values)
+    for (int64_t t = ((int64_t)blockIdx.y * 4 + wave) * 4; t < n_tiles; t += (int64_t)gridDim.y * 16) {
         float xa[4], xb[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int64_t tk = t + k * stride;
-            const size_t row = ((size_t)(tk < n_tiles ? tk : t) * F + f) * 128;
+            const int64_t ts = t + k < n_tiles ? t + k : t;
+            const size_t row = ((size_t)(ts >> 3) * F + f) * (128 * PK_Q_FTILE) + (size_t)(ts & 7) * 128;
             xa[k] = tiles[row + lane];
             xb[k] = tiles[row + 64 + lane];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int64_t tk = t + k * stride;
-            if (tk >= n_tiles) break;
+            if (t + k >= n_tiles) break;
             // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
             // half): the two walks of a lane read the same LDS bank, different lanes different banks
-            const size_t row = ((size_t)tk * F + f) * 128;
+            const size_t row = ((size_t)(t + k) * F + f) * 128;
             const unsigned c0 = q_code(xa[k], thr, lut, lo, inv), c1 = q_code(xb[k], thr, lut, lo, inv);
             reinterpret_cast<unsigned *>(qtiles + row)[lane] = c0 | (c1 << 16);
         }
@@ -521,7 +529,7 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
         pk_prof_scope prof(ctx, PK_K_QUANT);
         // enough blocks per feature to fill the chip, few enough that the tables are
         // loaded for many tiles each
-        int64_t split = (n_tiles + 63) / 64;
+        int64_t split = (n_tiles + 255) / 256;
         if (split > 64) split = 64;
         if (split < 1) split = 1;
         hipLaunchKernelGGL(quantize_tiles_kernel, dim3((unsigned)F, (unsigned)split), dim3(256), 0,
