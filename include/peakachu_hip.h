@@ -224,8 +224,10 @@ int pk_comm_gatherv_bytes(pk_comm *, const void *send, int64_t nbytes, int64_t *
 /* diagnostic, needs no device: the rank tables and the RANK image (4-byte nodes over
  * 16-bit rank codes) the default forest kernel walks, for `slots` tree slots and `ch`
  * walks per lane, so that tests can quantize and walk on the CPU.
- * layout8 = {half-tile bytes, walks per lane | second tile's offset << 8, flag area offset, value area offset,
- * image offset, image capacity, slots, F}; qoff = F+1 offsets into qthr (per feature the
+ * `ch` | 0x100 asks for fixed tree slots (the early-staging mode of the kernel).
+ * layout8 (32 ints) = {half-tile bytes, walks per lane | second tile's offset << 8, flag
+ * area offset, value area offset, image offset, image capacity, slots, F, total bytes of the
+ * fixed tree slots or 0, then 17 slot offsets}; qoff = F+1 offsets into qthr (per feature the
  * sorted distinct float32 thresholds); qlut = [F][4096] lookup cells (thresholds in
  * lower cells | thresholds in the cell << 16), qpar = [F][2] (lower end, cells per unit); pairs = the trees' 8-byte child pairs; gtab = 4 ints per
  * group (first tree, trees, offset and size in 16-byte units); ttab = 4 ints per tree

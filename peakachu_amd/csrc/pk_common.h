@@ -77,6 +77,7 @@ struct pk_options {
     int64_t forest_q = 1;       // rank-quantised tiles + 4-byte nodes (forest_q_kernel) when the forest fits
     int64_t forest_q_ch = 0;    // walks per lane of forest_q_kernel: 0 = auto (4 when F <= 128), 2, 4
     int64_t forest_q_wpt = 0;   // waves per tree with 4 walks per lane: 0 = auto (2), 1, 2
+    int64_t forest_q_early = 1; // two waves per tree: stage the slot's next tree as soon as both are done with it
     int64_t forest_img = 1;     // LDS-image forest kernel (fixed-depth walks, absolute LDS addresses)
                                 // when every tree fits; 0 = the grouped preorder kernel
 };
@@ -165,7 +166,8 @@ struct pk_forest {
     // rank image (forest_q_kernel): 0 = not tried, 1 = built, -1 = does not apply
     int q_state = 0;
     int q_slots = 0, q_ch = 0, q_n_grp = 0;
-    int64_t q_opt_slots = -1, q_opt_ch = -1, q_opt_wpt = -1;
+    int q_slot_bytes = 0;  // > 0: fixed tree slots, early staging
+    int64_t q_opt_slots = -1, q_opt_ch = -1, q_opt_wpt = -1, q_opt_early = -1;
     struct pk_q_layout *q_layout = nullptr;
     uint4 *q_img = nullptr;        // device: tree images
     int32_t *q_gtab = nullptr, *q_ttab = nullptr, *q_off = nullptr;  // device
@@ -216,6 +218,8 @@ struct pk_q_layout {
     int dec_off;        // early-termination flags
     int val_off;        // [slots][64*ch] float64 leaf values parked for the ordered sum
     int img_off, cap;   // the group's trees: [img_off, img_off + cap)
+    int slot_bytes;     // > 0: fixed tree slots (early staging): tree s of a group lives at
+    int slot_off[17];   //      img_off + slot_off[s]; slot_bytes = slot_off[slots] = their total size
 };
 struct pk_q_out {
     std::vector<float> qthr;      // per feature: sorted distinct float32 thresholds, laid end to end
@@ -245,7 +249,11 @@ bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L);
 int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
                const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
                const pk_q_layout &L, pk_q_out *out);
-int pk_q_group(pk_q_out *out, const pk_q_layout &L);  // (re)group the trees of `out` for a layout
+int pk_q_group(pk_q_out *out, const pk_q_layout &L);
+// fixed tree slots for groups of exactly `slots` consecutive trees: slot s is as large as the
+// largest tree in position s of any group; fills L->slot_off / slot_bytes, returns their sum
+int pk_q_fixed_slots(const pk_q_out &out, int slots, pk_q_layout *L);
+int pk_q_max_tree_bytes(const pk_q_out &out);  // largest tree image, a multiple of 16  // (re)group the trees of `out` for a layout
 int pk_forest_q_plan(pk_forest *f);   // PK_OK when the rank image applies (built and uploaded)
 void pk_forest_q_release(pk_forest *f);
 int pk_launch_forest_q(pk_device_ctx *, pk_forest *f, const float *tiles, const uint8_t *d_status,

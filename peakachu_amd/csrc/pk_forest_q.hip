@@ -163,14 +163,16 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
 
 #define Q_PF16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define Q_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u};
-// (register q is only moved when the group reaches it: a wave-uniform test)
+// (register q is only moved when the piece reaches it: a wave-uniform test).  The piece
+// is pf_nu 16-byte units at pf_src, destined for LDS offset pf_dst; thread i0 + q * stride
+// moves unit q of its column (all threads of the workgroup, or the lanes of one wave).
 #define Q_PF_LOAD(q)                                                           \
     if constexpr ((q) < PFN)                                                   \
-        if ((q) * THREADS < pf_nu) pf##q = pf_src[min(tid + (q) * THREADS, pf_nu - 1)];
+        if ((q) * pf_stride < pf_nu) pf##q = pf_src[min(pf_i0 + (q) * pf_stride, pf_nu - 1)];
 #define Q_PF_STORE(q)                                                          \
     if constexpr ((q) < PFN) {                                                 \
-        const int u = tid + (q) * THREADS;                                     \
-        if ((q) * THREADS < pf_nu && u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q; \
+        const int u = pf_i0 + (q) * pf_stride;                                 \
+        if ((q) * pf_stride < pf_nu && u < pf_nu) *LDS_AT(lds_u4, pf_dst + (u << 4)) = pf##q; \
     }
 
 // One workgroup = 64 * CH candidates and 16 waves.  WPT = 1: wave s walks tree s of the
@@ -181,10 +183,20 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
 // group by group: the next group travels global -> VGPR during the walk and VGPR -> LDS
 // behind the barrier.
 constexpr int Q_THREADS = 1024;
-template <int CH, int WPT, int HALF1, bool PRUNE>
+// EARLY (WPT = 2 only): every tree has a fixed slot of slot_bytes in LDS, and the two
+// waves that walk tree s stage the NEXT group's tree s themselves -- each its half, from
+// its own registers -- as soon as both are done with the current one (an LDS counter per
+// slot, not a workgroup barrier).  The commit of a group then overlaps the walks of the
+// waves that are still busy instead of standing between two barriers (it was 11 % of the
+// kernel: 4.21 -> 3.76 ms with the stores switched off).
+struct q_slot_table {
+    int off[16];  // EARLY: LDS offset (relative to img_off) of the tree slot of each wave pair
+};
+template <int CH, int WPT, int HALF1, bool PRUNE, bool EARLY>
 __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp,
     const int4 *__restrict__ ttab, int T, int F, int dec_off, int val_off, int img_off,
+    const q_slot_table slots_at,
     const unsigned short *__restrict__ qtiles, const uint8_t *__restrict__ status, int64_t c0,
     int64_t cn, double *__restrict__ prob, double prune_sum, int warm_ahead, int dbg,
     long long *__restrict__ stamps)
@@ -195,6 +207,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     constexpr int NCH = CH / WPT;  // walks per lane of one wave
     static_assert(THREADS >= C, "one thread per candidate owns the ordered sum");
     static_assert(WPT == 1 || (WPT == 2 && CH == 4), "two waves per tree = one per rank tile");
+    static_assert(!EARLY || WPT == 2, "early staging is written for two waves per tree");
+    const int done_off = dec_off + 4 * (C + 4);  // EARLY: per tree slot, waves done with it (counts up)
     extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -207,6 +221,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 
     if (PRUNE)
         for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
+    if (EARLY && tid < 8) *LDS_AT(lds_i32, done_off + 4 * tid) = 0;
     const int64_t wg = blockIdx.x;
     const int64_t cbase = wg * C;  // first candidate of this workgroup (relative to c0)
     {
@@ -241,12 +256,26 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 
     Q_PF16(Q_PF_DECL)
     const v4u *pf_src;
-    int pf_nu;
+    int pf_nu, pf_dst;
+    const int pf_i0 = EARLY ? lane : tid, pf_stride = EARLY ? 64 : THREADS;
     int4 g_cur = gtab[0];
-    int4 tt = ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree of the group: offset, depth, root
+    int4 tt = ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree of the group: offset, units, depth, root
+    // what this thread stages of group `gi`: the whole group (all threads together), or,
+    // EARLY, this wave's half of the tree of its slot
+    auto stage_of = [&](const int4 gi, const int4 ti) {
+        if (EARLY) {
+            const int tu = ti.w, half = (tu + 1) >> 1, u0 = sub * half;
+            pf_src = img + gi.z + (ti.x >> 4) + u0;
+            pf_nu = slot < gi.y ? max(0, min(tu, u0 + half) - u0) : 0;
+            pf_dst = img_off + slots_at.off[min(slot, 15)] + (u0 << 4);
+        } else {
+            pf_src = img + gi.z;
+            pf_nu = gi.w;
+            pf_dst = img_off;
+        }
+    };
     {
-        pf_src = img + g_cur.z;
-        pf_nu = g_cur.w;
+        stage_of(g_cur, tt);
         Q_PF16(Q_PF_LOAD)
         Q_PF16(Q_PF_STORE)
     }
@@ -265,8 +294,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];  // (scalar loads: in flight during the walk)
         Q_STAMP(0);
         if (g + 1 < n_grp) {  // loads fly while this group is walked
-            pf_src = img + g_nxt.z;
-            pf_nu = g_nxt.w;
+            stage_of(g_nxt, tt_nxt);
             Q_PF16(Q_PF_LOAD)
         } else if (warm_ahead > 0) {
             // last group: pull the tiles of the workgroup that follows this one on this XCD
@@ -286,7 +314,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         }
         if (slot < gt && !(dbg & 2) && __any(any_walk)) {
             double v[NCH];
-            const unsigned tbase = (unsigned)(img_off + tt.x);
+            const unsigned tbase = (unsigned)(EARLY ? img_off + slots_at.off[min(slot, 15)] : img_off + tt.x);
             const unsigned root = (unsigned)tt.z;
             // lanes without a live candidate walk along (their values are not stored)
             if (WPT == 2 && sub) {  // the second rank tile (the tile index is an immediate offset)
@@ -303,9 +331,27 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
                     *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * (NCH * sub + c)) * 8) = v[c];
         }
         Q_STAMP(1);
-        __syncthreads();  // every walk of the group is done: the trees may be overwritten
+        if (EARLY) {
+            // this wave no longer reads the tree of its slot; when its partner does not
+            // either, each stages its half of the slot's next tree.  The partner waits for
+            // nothing before it counts itself in, so the wait is bounded by its walk.
+            if (lane == 0)
+                __hip_atomic_fetch_add(LDS_AT(lds_i32, done_off + 4 * slot), 1, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (g + 1 < n_grp && pf_nu > 0 && !(dbg & 4)) {
+                bool both = false;
+                for (int spin = 0; spin < (1 << 22) && !both; spin++) {
+                    both = __hip_atomic_load(LDS_AT(lds_i32, done_off + 4 * slot), __ATOMIC_ACQUIRE,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP) >= 2 * (g + 1);
+                    if (!both) __builtin_amdgcn_s_sleep(2);
+                }
+                if (!both && lane == 0 && stamps) stamps[65535] = 1;  // reported by the host as an error
+                Q_PF16(Q_PF_STORE)
+            }
+        }
+        __syncthreads();  // every walk of the group is done (EARLY: and the next group staged)
         Q_STAMP(2);
-        if (g + 1 < n_grp && !(dbg & 4)) { Q_PF16(Q_PF_STORE) }  // (dbg 4: timing ablation, wrong results)
+        if (!EARLY && g + 1 < n_grp && !(dbg & 4)) { Q_PF16(Q_PF_STORE) }  // (dbg 4: timing ablation, wrong results)
         const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
         if (owner && active && undecided) {
             for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
@@ -432,10 +478,30 @@ static int q_plan_build(pk_forest *f)
         best.ttab = best_ttab;
         best.n_grp = best_n_grp;
     }
+    // early staging (two waves per tree): fixed tree slots, slot s as large as the largest
+    // tree in position s of any group; each wave stages half a tree from 6 registers
+    // (<= 6 KiB per half).  Only taken when it does not cost a tree per group.
+    int slot_bytes = 0;
+    if (best_slots && ch == 4 && best_slots <= 8 && g_opt.forest_q_wpt != 1 && g_opt.forest_q_early &&
+        pk_q_max_tree_bytes(best) <= 2 * 6 * 64 * 16) {
+        pk_q_layout L2;
+        if (pk_q_make_layout(F, best_slots, ch, &L2)) {
+            pk_q_fixed_slots(best, best_slots, &L2);
+            if (L2.slot_bytes <= L2.cap && pk_q_group(&best, L2) == PK_OK) {
+                bestL = L2;
+                slot_bytes = L2.slot_bytes;
+            } else {  // restore the packed grouping
+                best.gtab = best_gtab;
+                best.ttab = best_ttab;
+                best.n_grp = best_n_grp;
+            }
+        }
+    }
     if (!best_slots) return PK_E_UNSUPPORTED;
     q_free(f);
     f->q_layout = new pk_q_layout(bestL);
     f->q_slots = best_slots;
+    f->q_slot_bytes = slot_bytes;
     f->q_ch = ch;
     f->q_n_grp = best.n_grp;
     int rc = q_upload((void **)&f->q_img, best.pairs);
@@ -468,7 +534,7 @@ static int q_plan_build(pk_forest *f)
 int pk_forest_q_plan(pk_forest *f)
 {
     if (f->q_state != 0 && (f->q_opt_slots != g_opt.forest_slots || f->q_opt_ch != g_opt.forest_q_ch ||
-                            f->q_opt_wpt != g_opt.forest_q_wpt)) {
+                            f->q_opt_wpt != g_opt.forest_q_wpt || f->q_opt_early != g_opt.forest_q_early)) {
         q_free(f);
         f->q_state = 0;
     }
@@ -476,6 +542,7 @@ int pk_forest_q_plan(pk_forest *f)
         f->q_opt_slots = g_opt.forest_slots;
         f->q_opt_ch = g_opt.forest_q_ch;
         f->q_opt_wpt = g_opt.forest_q_wpt;
+        f->q_opt_early = g_opt.forest_q_early;
         const int rc = q_plan_build(f);
         f->q_state = rc == PK_OK ? 1 : -1;
         if (rc != PK_OK) q_free(f);
@@ -484,23 +551,24 @@ int pk_forest_q_plan(pk_forest *f)
     return f->q_state == 1 ? PK_OK : PK_E_UNSUPPORTED;
 }
 
-#define Q_LAUNCH_P(CH, WPT, HALF1, PRUNE)                                                      \
+#define Q_LAUNCH_P(CH, WPT, HALF1, PRUNE, EARLY)                                               \
     do {                                                                                       \
-        int rc__ = q_set_max_lds(forest_q_kernel<CH, WPT, HALF1, PRUNE>, 163840);              \
+        int rc__ = q_set_max_lds(forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>, 163840);       \
         if (rc__) return rc__;                                                                 \
-        hipLaunchKernelGGL((forest_q_kernel<CH, WPT, HALF1, PRUNE>), dim3(grid), dim3(Q_THREADS), \
+        hipLaunchKernelGGL((forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>), dim3(grid), dim3(Q_THREADS), \
                            163840, ctx->stream, reinterpret_cast<const v4u *>(f->q_img),       \
                            reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp,              \
                            reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
-                           L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob,       \
+                           L.val_off, L.img_off, slots_at, ctx->q_tiles, d_status, c0,         \
+                           cn, d_prob,                                                         \
                            prune_sum,                                                          \
                            g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
                            (int)g_opt.forest_dbg, ctx->dbg_buf);                               \
     } while (0)
-#define Q_LAUNCH(CH, WPT, HALF1)                                                               \
+#define Q_LAUNCH(CH, WPT, HALF1, EARLY)                                                        \
     do {                                                                                       \
-        if (prune_sum > -1e300) Q_LAUNCH_P(CH, WPT, HALF1, true);                              \
-        else Q_LAUNCH_P(CH, WPT, HALF1, false);                                                \
+        if (prune_sum > -1e300) Q_LAUNCH_P(CH, WPT, HALF1, true, EARLY);                       \
+        else Q_LAUNCH_P(CH, WPT, HALF1, false, EARLY);                                         \
     } while (0)
 
 int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, const uint8_t *d_status,
@@ -542,14 +610,19 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
     const unsigned grid = (unsigned)((cn + C - 1) / C);
     // two waves per tree when the groups leave half the waves without one
     const bool wpt2 = L.ch == 4 && f->q_slots <= 8 && g_opt.forest_q_wpt != 1;
+    const bool early = wpt2 && f->q_slot_bytes > 0;
+    q_slot_table slots_at;
+    for (int i = 0; i < 16; i++) slots_at.off[i] = L.slot_off[i];
     if (L.ch == 4 && L.half1 == 32768) {
-        if (wpt2) Q_LAUNCH(4, 2, 32768);
-        else Q_LAUNCH(4, 1, 32768);
+        if (early) Q_LAUNCH(4, 2, 32768, true);
+        else if (wpt2) Q_LAUNCH(4, 2, 32768, false);
+        else Q_LAUNCH(4, 1, 32768, false);
     } else if (L.ch == 4 && L.half1 == 49152) {
-        if (wpt2) Q_LAUNCH(4, 2, 49152);
-        else Q_LAUNCH(4, 1, 49152);
+        if (early) Q_LAUNCH(4, 2, 49152, true);
+        else if (wpt2) Q_LAUNCH(4, 2, 49152, false);
+        else Q_LAUNCH(4, 1, 49152, false);
     } else if (L.ch == 2) {
-        Q_LAUNCH(2, 1, 32768);
+        Q_LAUNCH(2, 1, 32768, false);
     } else {
         pk_set_error("forest rank kernel: layout not instantiated");
         return PK_E_INVALID;

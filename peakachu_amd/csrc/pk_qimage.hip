@@ -188,6 +188,8 @@ bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L)
     L->F = F;
     L->slots = slots;
     L->ch = ch;
+    L->slot_bytes = 0;
+    memset(L->slot_off, 0, sizeof(L->slot_off));
     L->HB = F * 256;
     const int C = 64 * ch;
     int top;
@@ -199,7 +201,7 @@ bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L)
     } else {
         top = L->HB;
     }
-    const int dec_bytes = (C * 4 + 16 + 15) & ~15;
+    const int dec_bytes = (C * 4 + 16 + 32 + 15) & ~15;  // flags, 3 vote words (+1), 8 slot counters
     // the flags go into the gap below the second half tile when they fit there
     if (ch == 4 && L->HB + dec_bytes <= L->half1) {
         L->dec_off = L->HB;
@@ -214,6 +216,27 @@ bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L)
     const int stage = pk_q_stage_regs() * 1024 * 16;  // what the register staging moves per group
     if (L->cap > stage) L->cap = stage;
     return L->cap >= 4096;
+}
+
+int pk_q_max_tree_bytes(const pk_q_out &out)
+{
+    int m = 0;
+    for (size_t t = 0; t + 1 < out.toff.size(); t++) m = std::max(m, (out.toff[t + 1] - out.toff[t]) * 8);
+    return (m + 15) & ~15;
+}
+
+int pk_q_fixed_slots(const pk_q_out &out, int slots, pk_q_layout *L)
+{
+    const int T = (int)out.toff.size() - 1;
+    L->slot_off[0] = 0;
+    for (int s = 0; s < 16; s++) {
+        int m = 0;
+        if (s < slots)
+            for (int t = s; t < T; t += slots) m = std::max(m, (out.toff[(size_t)t + 1] - out.toff[(size_t)t]) * 8);
+        L->slot_off[s + 1] = L->slot_off[s] + ((m + 15) & ~15);
+    }
+    L->slot_bytes = L->slot_off[slots];
+    return L->slot_bytes;
 }
 
 void pk_q_fill_lut(pk_q_out *out, int F, const std::vector<int32_t> &qcell)
@@ -319,12 +342,18 @@ int pk_q_group(pk_q_out *out, const pk_q_layout &L)
     const std::vector<int32_t> &toff = out->toff;
     out->gtab.clear();
     for (int t = 0; t < T; t++)
-        if ((toff[(size_t)t + 1] - toff[(size_t)t]) * 8 > L.cap) return PK_E_UNSUPPORTED;
+        if ((toff[(size_t)t + 1] - toff[(size_t)t]) * 8 >
+            (L.slot_bytes ? L.slot_off[t % L.slots + 1] - L.slot_off[t % L.slots] : L.cap))
+            return PK_E_UNSUPPORTED;
+    if (L.slot_bytes > L.cap) return PK_E_UNSUPPORTED;
     out->ttab.assign((size_t)T * 4, 0);
     int t = 0;
     while (t < T) {
         int t1 = t + 1;
-        while (t1 < T && t1 - t < L.slots && (toff[(size_t)t1 + 1] - toff[(size_t)t]) * 8 <= L.cap) t1++;
+        // (fixed tree slots: every tree fits its slot, so only the count limits a group)
+        while (t1 < T && t1 - t < L.slots &&
+               (L.slot_bytes || (toff[(size_t)t1 + 1] - toff[(size_t)t]) * 8 <= L.cap))
+            t1++;
         out->gtab.push_back(t);
         out->gtab.push_back(t1 - t);
         out->gtab.push_back(toff[(size_t)t] / 2);                        // 16-byte units
@@ -333,6 +362,7 @@ int pk_q_group(pk_q_out *out, const pk_q_layout &L)
             out->ttab[(size_t)k * 4] = (toff[(size_t)k] - toff[(size_t)t]) * 8;  // bytes inside the group
             out->ttab[(size_t)k * 4 + 1] = out->tdepth[(size_t)k];
             out->ttab[(size_t)k * 4 + 2] = (int32_t)out->troot[(size_t)k];
+            out->ttab[(size_t)k * 4 + 3] = (toff[(size_t)k + 1] - toff[(size_t)k]) / 2;  // 16-byte units
         }
         t = t1;
     }
@@ -351,7 +381,7 @@ int pk_q_group(pk_q_out *out, const pk_q_layout &L)
 extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, const int32_t *left,
                                       const int32_t *right, const int32_t *feat, const double *thr,
                                       const uint8_t *miss_left, const double *p1, int slots, int ch,
-                                      int32_t *layout8, int32_t *qoff, int64_t cap_thr, float *qthr,
+                                      int32_t *layout8 /* 32 entries */, int32_t *qoff, int64_t cap_thr, float *qthr,
                                       uint32_t *qlut, float *qpar, int64_t cap_pairs, uint64_t *pairs,
                                       int64_t *n_pairs, int64_t cap_groups, int32_t *gtab,
                                       int32_t *n_groups, int32_t *ttab)
@@ -361,6 +391,8 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
         pk_set_error("pk_debug_forest_qimage: bad arguments");
         return PK_E_INVALID;
     }
+    const bool fixed_slots = (ch & 0x100) != 0;
+    ch &= 0xFF;
     pk_q_layout L;
     if (!pk_q_make_layout(F, slots, ch, &L)) {
         pk_set_error("pk_debug_forest_qimage: no LDS layout for F=%d, %d slots, %d walks per lane", F,
@@ -368,7 +400,11 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
         return PK_E_UNSUPPORTED;
     }
     pk_q_out out;
-    const int rc = pk_q_build(T, F, tree_off, left, right, feat, thr, miss_left, p1, L, &out);
+    int rc = pk_q_build(T, F, tree_off, left, right, feat, thr, miss_left, p1, L, &out);
+    if (fixed_slots && (rc == PK_OK || (rc == PK_E_UNSUPPORTED && !out.toff.empty()))) {
+        pk_q_fixed_slots(out, slots, &L);
+        rc = pk_q_group(&out, L);
+    }
     if (rc) {
         if (rc == PK_E_UNSUPPORTED) pk_set_error("pk_debug_forest_qimage: the forest does not fit the rank format");
         return rc;
@@ -378,7 +414,9 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
         pk_set_error("pk_debug_forest_qimage: output buffers too small");
         return PK_E_NOMEM;
     }
-    const int32_t lay[8] = {L.HB, L.ch | (L.half1 << 8), L.dec_off, L.val_off, L.img_off, L.cap, L.slots, L.F};
+    int32_t lay[32] = {L.HB, L.ch | (L.half1 << 8), L.dec_off, L.val_off, L.img_off, L.cap, L.slots, L.F,
+                       L.slot_bytes};
+    for (int i = 0; i < 17; i++) lay[9 + i] = L.slot_off[i];
     memcpy(layout8, lay, sizeof(lay));
     memcpy(qoff, out.qoff.data(), out.qoff.size() * sizeof(int32_t));
     memcpy(qthr, out.qthr.data(), out.qthr.size() * sizeof(float));

@@ -31,7 +31,7 @@ def build_qimage(fo, F, slots, ch):
     L = _lib.load()
     T = int(len(fo["tree_off"]) - 1)
     nn = int(fo["tree_off"][-1])
-    lay = np.zeros(8, np.int32)
+    lay = np.zeros(32, np.int32)
     qoff = np.zeros(F + 1, np.int32)
     qthr = np.zeros(nn + 8, np.float32)
     qlut = np.zeros(F * CELLS, np.uint32)
@@ -90,7 +90,8 @@ def quantize(img, X):
 
 
 def walk_qimage(img, codes, T):
-    HB, ch_half1, dec_off, val_off, img_off, cap, slots, F = [int(v) for v in img["lay"]]
+    HB, ch_half1, dec_off, val_off, img_off, cap, slots, F, slot_bytes = [int(v) for v in img["lay"][:9]]
+    slot_off = [int(v) for v in img["lay"][9:26]]   # slot_bytes > 0: fixed tree slots (early staging)
     ch, half1 = ch_half1 & 0xFF, ch_half1 >> 8
     N = codes.shape[0]
     acc = np.zeros(N, np.float64)
@@ -100,20 +101,31 @@ def walk_qimage(img, codes, T):
         assert half1 in (32768, 49152) and HB <= half1 and val_off >= half1 + HB
     for g in range(img["n_grp"]):
         t0, nt, off, nu = [int(v) for v in img["gtab"][g]]
-        assert 0 < nt <= slots and nu * 16 <= cap
+        assert 0 < nt <= slots and (slot_bytes or nu * 16 <= cap)
         lds = np.full(LDS_BYTES // 8, 0xDEADBEEFDEADBEEF, np.uint64)
-        lds[img_off // 8: img_off // 8 + 2 * nu] = img["pairs"][2 * off: 2 * (off + nu)]
+        if not slot_bytes:
+            lds[img_off // 8: img_off // 8 + 2 * nu] = img["pairs"][2 * off: 2 * (off + nu)]
         for t in range(t0, t0 + nt):
-            toff, depth, root, _ = [int(v) for v in img["ttab"][t]]
-            assert toff % 16 == 0 and toff < nu * 16
+            toff, depth, root, tu = [int(v) for v in img["ttab"][t]]
+            assert toff % 16 == 0 and toff < nu * 16 and toff + tu * 16 <= nu * 16
             tbase = img_off + toff
+            if slot_bytes:  # the two waves of the slot stage their halves of the tree
+                j = t - t0
+                assert t0 % slots == 0 and tu * 16 <= slot_off[j + 1] - slot_off[j] and slot_bytes <= cap
+                tbase = img_off + slot_off[j]
+                half = (tu + 1) // 2
+                for sub in (0, 1):
+                    u0, u1 = sub * half, min(tu, (sub + 1) * half)
+                    assert u1 - u0 <= 6 * 64
+                    src = 2 * off + toff // 8 + 2 * u0
+                    lds[tbase // 8 + 2 * u0: tbase // 8 + 2 * u1] = img["pairs"][src: src + 2 * (u1 - u0)]
             w = np.full(N, np.uint32(root & 0xFFFFFFFF), np.uint32)
             for _ in range(depth):
                 f = (w & 0xFF).astype(np.int64)
                 assert f.max() < F
                 xv = codes[np.arange(N), f].astype(np.uint32)
                 ca = tbase + ((w >> 8) & 0xFFF).astype(np.int64) * 8
-                assert (ca + 8 <= img_off + nu * 16).all()
+                assert (ca + 8 <= (img_off + slot_off[t - t0 + 1] if slot_bytes else img_off + nu * 16)).all()
                 pr = lds[ca // 8]
                 gl = (xv <= (w >> 16)) | ((xv == 0xFFFF) & ((w >> 20) & 1 != 0))
                 w = np.where(gl, pr & np.uint64(0xFFFFFFFF), pr >> np.uint64(32)).astype(np.uint32)
@@ -122,7 +134,8 @@ def walk_qimage(img, codes, T):
     return acc / float(T)
 
 
-@pytest.mark.parametrize("slots,ch", [(2, 2), (5, 2), (13, 2), (16, 2), (4, 4), (9, 4), (16, 4)])
+@pytest.mark.parametrize("slots,ch", [(2, 2), (5, 2), (13, 2), (16, 2), (4, 4), (9, 4), (16, 4),
+                                      (8, 4 | 0x100), (3, 4 | 0x100)])
 @pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
 def test_rank_walk_equals_sklearn_golden(tag, slots, ch):
     z = gio.load("g2_forest_%s.npz" % tag)
@@ -139,7 +152,9 @@ def test_rank_walk_equals_sklearn_golden(tag, slots, ch):
 
 
 @pytest.mark.parametrize("name,slots,ch", [("forest_w5_t100.npz", 9, 4), ("forest_w5_t100.npz", 13, 2),
-                                           ("forest_w6_t100.npz", 8, 2), ("forest_w6_t100.npz", 7, 4)])
+                                           ("forest_w6_t100.npz", 8, 2), ("forest_w6_t100.npz", 7, 4),
+                                           ("forest_w5_t100.npz", 8, 4 | 0x100),
+                                           ("forest_w6_t100.npz", 6, 4 | 0x100)])
 def test_rank_image_of_benchmark_forests(name, slots, ch):
     ff = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", name))
     fo = {k: getattr(ff, k) for k in FlatForest.FIELDS}

@@ -149,6 +149,41 @@ def test_forest_threshold_edges(hip_lib, name, opts):
     assert np.array_equal(gio.bits(p), gio.bits(ref))
 
 
+@pytest.mark.parametrize("opts", [{}, {"forest_q_early": 0}, {"forest_q_wpt": 1}, {"forest_q_ch": 2},
+                                  {"forest_slots": 5}, {"forest_slots": 5, "forest_q_early": 0},
+                                  {"forest_slots": 3}, {"forest_q_early": 1, "early_exit": 1},
+                                  {"forest_q_early": 0, "early_exit": 1}])
+@pytest.mark.parametrize("name", ["forest_w5_t100.npz", "forest_w6_t100.npz"])
+def test_forest_q_modes(hip_lib, name, opts):
+    """The rank kernel's shapes (early staging through fixed tree slots or packed groups,
+    one or two waves per tree, 2 or 4 walks per lane, forced group sizes, pruning) on the
+    benchmark forests: random features incl. exact 0 / 1 and NaN rows, 2 999 rows so that
+    the last workgroup is partial, bit-exact against the oracle."""
+    import os
+    from peakachu_amd.forest import FlatForest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ff = FlatForest.load(os.path.join(root, "peakachu_amd", "data", name))
+    fo = {k: getattr(ff, k) for k in FlatForest.FIELDS}
+    rng = np.random.default_rng(21)
+    X = rng.random((2999, ff.F)).astype(np.float32)
+    X[::5] = (X[::5] > 0.5).astype(np.float32)
+    X[7, 3] = np.nan
+    X[300, :] = np.nan
+    X[2998, 0] = np.nan
+    ref = onp.predict(fo, X)
+    keys = [k for k in opts if k != "early_exit"]
+    old = {k: _lib.load().pk_get_option(k.encode()) for k in keys}
+    try:
+        for k in keys:
+            _lib.set_option(k, opts[k])
+        hf = _lib.HipForest(ff)
+        p = hf.predict(X)
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+    assert np.array_equal(gio.bits(p), gio.bits(ref))
+
+
 def _g3_matrix(z):
     raw = gio.sym_matrix(z, "R")
     mode = str(z["mode"])
