@@ -188,7 +188,10 @@ constexpr int Q_THREADS = 1024;
 // its own registers -- as soon as both are done with the current one (an LDS counter per
 // slot, not a workgroup barrier).  The commit of a group then overlaps the walks of the
 // waves that are still busy instead of standing between two barriers (it was 11 % of the
-// kernel: 4.21 -> 3.76 ms with the stores switched off).
+// kernel: 4.21 -> 3.76 ms with the stores switched off).  MEASURED: slower, 4.51 vs 4.09 ms
+// -- LDS stores issued by two waves alone run at half rate (the store path wants waves on
+// all four SIMDs) and delay the reads of the waves still walking; option forest_q_early,
+// off by default.
 struct q_slot_table {
     int off[16];  // EARLY: LDS offset (relative to img_off) of the tree slot of each wave pair
 };

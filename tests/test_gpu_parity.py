@@ -149,10 +149,9 @@ def test_forest_threshold_edges(hip_lib, name, opts):
     assert np.array_equal(gio.bits(p), gio.bits(ref))
 
 
-@pytest.mark.parametrize("opts", [{}, {"forest_q_early": 0}, {"forest_q_wpt": 1}, {"forest_q_ch": 2},
-                                  {"forest_slots": 5}, {"forest_slots": 5, "forest_q_early": 0},
-                                  {"forest_slots": 3}, {"forest_q_early": 1, "early_exit": 1},
-                                  {"forest_q_early": 0, "early_exit": 1}])
+@pytest.mark.parametrize("opts", [{}, {"forest_q_early": 1}, {"forest_q_wpt": 1}, {"forest_q_ch": 2},
+                                  {"forest_slots": 5}, {"forest_slots": 5, "forest_q_early": 1},
+                                  {"forest_slots": 3, "forest_q_early": 1}])
 @pytest.mark.parametrize("name", ["forest_w5_t100.npz", "forest_w6_t100.npz"])
 def test_forest_q_modes(hip_lib, name, opts):
     """The rank kernel's shapes (early staging through fixed tree slots or packed groups,
