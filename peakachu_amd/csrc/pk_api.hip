@@ -1171,11 +1171,31 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
     }
     int rc = check_coords("pk_score", m->n, N, x, y);
     if (rc) return rc;
-    pk_cands *cd = pk_cands_create(m->device, N, x, y);
-    if (!cd) return PK_E_HIP;
+    // the device-side candidate list of the host-buffer convenience call is kept per device
+    // and reused while it is large enough: nine allocations per call cost more than the
+    // upload of the coordinates
+    pk_device_ctx *ctx = pk_ctx(m->device);
+    if (!ctx) return PK_E_NODEVICE;
+    pk_cands *cd = ctx->score_cands;
+    if (cd && ctx->score_cands_cap >= N) {
+        cd->N = N;
+        cd->prune = 0;
+        if (N > 0 && (hipMemcpyAsync(cd->x, x, (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                      hipMemcpyAsync(cd->y, y, (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) {
+            pk_set_error("pk_score: candidate upload failed");
+            return PK_E_HIP;
+        }
+    } else {
+        if (cd) pk_cands_destroy(cd);
+        ctx->score_cands = nullptr;
+        ctx->score_cands_cap = 0;
+        cd = pk_cands_create(m->device, N, x, y);
+        if (!cd) return PK_E_HIP;
+        ctx->score_cands = cd;
+        ctx->score_cands_cap = N;
+    }
     rc = pk_score_run(m, f, cd, w, thre, batch, n_out);
     if (!rc) rc = pk_score_fetch(cd, ox, oy, op, osignal);
-    pk_cands_destroy(cd);
     return rc;
 }
 

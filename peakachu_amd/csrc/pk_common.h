@@ -45,6 +45,8 @@ struct pk_device_ctx {
     size_t fea_tiles_bytes = 0;
     uint16_t *q_tiles = nullptr;  // [tile][F][128] rank codes of the current chunk (forest_q_kernel)
     size_t q_tiles_bytes = 0;
+    struct pk_cands *score_cands = nullptr;  // candidate list reused by pk_score (host-buffer calls)
+    int64_t score_cands_cap = 0;
     int64_t *scan_scratch = nullptr;  // block counts for the compaction scan
     size_t scan_scratch_bytes = 0;
     int cu_count = 0;
