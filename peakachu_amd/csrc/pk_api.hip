@@ -212,8 +212,6 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.extract_clean = value != 0;
     } else if (!strcmp(name, "extract_pair")) {
         g_opt.extract_pair = value != 0;
-    } else if (!strcmp(name, "extract_q")) {
-        g_opt.extract_q = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
         if (value < 0 || value == 1 || value > 16) return PK_E_INVALID;
         g_opt.forest_slots = value;
@@ -258,7 +256,6 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
     if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
     if (!strcmp(name, "extract_clean")) return g_opt.extract_clean;
-    if (!strcmp(name, "extract_q")) return g_opt.extract_q;
     if (!strcmp(name, "forest_warm")) return g_opt.forest_warm;
     if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
     if (!strcmp(name, "stat_extract_general")) return g_stat_extract_general;
@@ -1036,29 +1033,25 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
                         double prune_sum)
 {
     const int F = (2 * w + 1) * (2 * w + 1);
-    int blk = pk_forest_plan_blk(f);
+    const int blk = pk_forest_plan_blk(f);
     if (blk <= 0) {
         pk_set_error("w=%d: feature tile does not fit LDS", w);
         return PK_E_UNSUPPORTED;
     }
-    int rc;
+    int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
+    if (chunk > cd->N) chunk = (cd->N + blk - 1) / blk * blk;
+    const size_t tile_floats = (size_t)chunk * F;
+    const bool overlap = g_opt.overlap != 0;
+    int rc = pk_ctx_reserve_tiles(ctx, (overlap ? 2 : 1) * tile_floats * sizeof(float));
+    if (rc) return rc;
     if ((w == 5 || w == 6) && g_opt.extract_pair && g_opt.extract_clean) {
         rc = pk_matrix_prepare_norm(ctx, m);
         if (rc) return rc;
     }
-    // rank codes straight from the extractor (no float tile, no quantizer pass) when the
-    // forest is evaluated on rank codes and the matrix qualifies for the clean extractor
-    const bool overlap = g_opt.overlap != 0;
-    const bool codes = f->plan_kind == 2 && !overlap && pk_extract_codes_ok(m, f, w);
-    if (codes) blk = 128;
-    int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
-    if (chunk > cd->N) chunk = (cd->N + blk - 1) / blk * blk;
-    const size_t tile_floats = (size_t)chunk * F;
-    if (codes) rc = pk_ctx_reserve_qtiles(ctx, tile_floats * sizeof(unsigned short));
-    else rc = pk_ctx_reserve_tiles(ctx, (overlap ? 2 : 1) * tile_floats * sizeof(float));
-    if (rc) return rc;
-    // Two tile buffers: extract(k+1) runs on the low-priority stream beside forest(k)
-    // (option overlap, off: measured no gain).
+    // Two tile buffers: extract(k+1) runs on the low-priority stream beside forest(k).
+    // The forest kernel is LDS / latency bound and leaves ~40 % of the VALU issue slots
+    // and (at <= 72 VGPRs) room for one 216-register extractor wave per SIMD, which is
+    // FP64-VALU bound: the two kernels are complementary on a CU.
     hipStream_t st_ext = overlap ? ctx->stream2 : ctx->stream;
     if (overlap) {
         // whatever precedes on the main stream (uploads) must be visible to the extractor
@@ -1069,19 +1062,17 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     for (int64_t c0 = 0; c0 < cd->N; c0 += chunk, k++) {
         const int64_t cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
         const int buf = overlap ? (int)(k & 1) : 0;
-        float *tiles = codes ? reinterpret_cast<float *>(ctx->q_tiles)
-                             : ctx->fea_tiles + (size_t)buf * tile_floats;
+        float *tiles = ctx->fea_tiles + (size_t)buf * tile_floats;
         if (overlap && k >= 2)  // forest(k-2) must be done with this buffer
             PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[buf], 0));
         rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0, cn, tiles, blk, cd->status,
-                               nullptr, codes ? f : nullptr);
+                               nullptr);
         if (rc) return rc;
         if (overlap) {
             PK_HIP(hipEventRecord(ctx->ev_ext[buf], st_ext));
             PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[buf], 0));
         }
-        rc = pk_launch_forest(ctx, f, codes ? nullptr : tiles, blk, cd->status, c0, cn, cd->prob,
-                              prune_sum);
+        rc = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob, prune_sum);
         if (rc) return rc;
         if (overlap) PK_HIP(hipEventRecord(ctx->ev_for[buf], ctx->stream));
     }

@@ -68,8 +68,6 @@ struct pk_options {
                                 // the forest slows by what the extractor saves -- both are VALU-issue bound)
     int64_t extract_clean = 1;  // use the pre-divided band + shortcuts when the matrix qualifies
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
-    int64_t extract_q = 1;      // w = 5, clean matrix, rank-image forest: the extractor stores the rank
-                                // codes itself (no float tile, no quantizer pass)
     int64_t forest_warm = 1;    // last tree group: pull the tile of workgroup id + N into this XCD's L2
                                 // (0 = off, 1 = N = number of CUs: the workgroup that follows on this XCD)
     int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
@@ -262,11 +260,8 @@ int pk_q_fixed_slots(const pk_q_out &out, int slots, pk_q_layout *L);
 int pk_q_max_tree_bytes(const pk_q_out &out);  // largest tree image, a multiple of 16  // (re)group the trees of `out` for a layout
 int pk_forest_q_plan(pk_forest *f);   // PK_OK when the rank image applies (built and uploaded)
 void pk_forest_q_release(pk_forest *f);
-// tiles == nullptr: the rank codes of these candidates are in ctx->q_tiles already
-// (the extractor stored them); otherwise they are made from the float32 tiles first
 int pk_launch_forest_q(pk_device_ctx *, pk_forest *f, const float *tiles, const uint8_t *d_status,
                        int64_t c0, int64_t cn, double *d_prob, double prune_sum);
-int pk_ctx_reserve_qtiles(pk_device_ctx *, size_t bytes);
 
 // (re)build f->grp for this launch shape; returns PK_OK or an error code
 int pk_forest_groups(pk_forest *f, int tree_words, int slots);
@@ -329,13 +324,9 @@ int pk_launch_csr_info(pk_device_ctx *, const int32_t *d_indptr, const int32_t *
 // features of candidates [c0, c0+cn) -> tiles (tile width BLK) + status.
 // If fea64_rows != nullptr also writes row-major float64 features [cn][F].
 int pk_matrix_prepare_norm(pk_device_ctx *, pk_matrix *);
-// codes_of != nullptr: store that forest's 16-bit rank codes into `tiles` (a [tile][F][128]
-// uint16 buffer) instead of float32 features; only when pk_extract_codes_ok says so
 int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
-                      int blk, uint8_t *d_status, double *fea64_rows,
-                      const pk_forest *codes_of = nullptr);
-bool pk_extract_codes_ok(const pk_matrix *m, const pk_forest *f, int w);
+                      int blk, uint8_t *d_status, double *fea64_rows);
 
 // walk the forest over feature tiles of candidates [c0, c0+cn)
 // prune_sum: -inf (full evaluation) or thre*T: candidates whose sum provably cannot reach it

@@ -460,25 +460,12 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 // The arithmetic order is unchanged; tests compare this kernel bit for bit with the
 // general one and with the CPU restatement of the reference.
 // ------------------------------------------------------------------------
-// QCODES: instead of float32 features the kernel stores the forest's 16-bit RANK CODES
-// (pk_qimage.hip: code = number of the feature's distinct thresholds below the float32
-// value, << 5; NaN -> 0xFFFF) into [tile][F][128] uint16 tiles -- the quantizer's work
-// (pk_forest_q.hip, q_code) done where the value is still in a register: the lookup cell
-// and, for the few values that share their cell with a threshold, the threshold come from
-// the L2-resident tables.  The feature itself is computed exactly as before.
-struct pk_q_tables {
-    const float *thr;      // per feature sorted distinct thresholds, end to end (+1 pad)
-    const int32_t *off;    // F+1 offsets into thr
-    const unsigned *lut;   // [F][PK_Q_CELLS]: thresholds in lower cells | thresholds in the cell << 16
-    const float *par;      // [F][2]: lower end of the cells, cells per unit
-};
-
-template <int W, bool FEA64, bool QCODES>
+template <int W, bool FEA64>
 __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) void extract_pair_clean_kernel(
     const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
     const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
     float *__restrict__ tiles, int blk, uint8_t *__restrict__ status,
-    double *__restrict__ fea64_rows, const pk_q_tables qt)
+    double *__restrict__ fea64_rows)
 {
     constexpr int S = 2 * W + 1;
     constexpr int F = S * S;
@@ -646,38 +633,16 @@ __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) vo
     // floats for a grouped store cost 20 registers, the difference between one and two
     // waves per SIMD at w = 6); A stores the shared centre column.
     const int64_t first = wave0 / blk;  // the 32 candidates of a wave share a tile
-    constexpr int ESZ = QCODES ? 2 : 4;  // bytes of a tile element
-    char *tbase = reinterpret_cast<char *>(tiles) + (size_t)first * F * blk * ESZ;
+    char *tbase = reinterpret_cast<char *>(tiles + (size_t)first * F * blk);
     const int tl = (int)(wave0 - first * blk) + (threadIdx.x >> 1);
-    const int t0 = (tl + (role ? (F - 1) * blk : 0)) * ESZ;
-    const int sblk4 = sgn * blk * ESZ;
+    const int t0 = (tl + (role ? (F - 1) * blk : 0)) * 4;
+    const int sblk4 = sgn * blk * 4;
     double *rp = FEA64 ? fea64_rows + (size_t)local * F : nullptr;
-    // rank code of feature e (lane A) / F-1-e (lane B): the two features' table entries are
-    // scalar loads picked by role; the lookup cell and the threshold are per-lane loads
-    auto rank_code = [&](const int e, const float x) -> unsigned {
-        const int fa = e, fb = F - 1 - e;
-        const float lo = role ? qt.par[2 * fb] : qt.par[2 * fa];
-        const float inv = role ? qt.par[2 * fb + 1] : qt.par[2 * fa + 1];
-        const int o = role ? qt.off[fb] : qt.off[fa];
-        const unsigned ent = qt.lut[(role ? fb * PK_Q_CELLS : fa * PK_Q_CELLS) + pk_q_cell(x, lo, inv)];
-        unsigned r = ent & 0xFFFFu, k = ent >> 16;
-        const float *th = qt.thr + o;
-        const unsigned hit = (k != 0) & (th[r] < x);  // (th[r] is readable: the table is padded)
-        r += hit;
-        if (hit & (k > 1))
-            for (k--; k != 0 && th[r] < x; k--) r++;
-        return x != x ? 0xFFFFu : r << 5;
-    };
 #define PK_PUT(i_, q_, v_)                                                                      \
     do {                                                                                        \
         if (ok && ((q_) < W || role == 0)) {                                                    \
-            if (QCODES)                                                                         \
-                *reinterpret_cast<unsigned short *>(                                            \
-                    tbase + (unsigned)(t0 + __mul24((i_) * S + (q_), sblk4))) =                 \
-                    (unsigned short)rank_code((i_) * S + (q_), (float)(v_));                    \
-            else                                                                                \
-                *reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24((i_) * S + (q_), sblk4))) = \
-                    (float)(v_); /* sklearn's float32 cast (RNE) */                             \
+            *reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24((i_) * S + (q_), sblk4))) = \
+                (float)(v_); /* sklearn's float32 cast (RNE) */                                 \
             if (FEA64) rp[role ? F - 1 - ((i_) * S + (q_)) : (i_) * S + (q_)] = (v_);           \
         }                                                                                       \
     } while (0)
@@ -919,36 +884,12 @@ int pk_matrix_prepare_norm(pk_device_ctx *ctx, pk_matrix *m)
     return PK_OK;
 }
 
-// can the extractor store the rank codes of `f` itself (w = 5, a matrix that passes the
-// clean-kernel checks)?  Call after pk_matrix_prepare_norm.
-bool pk_extract_codes_ok(const pk_matrix *m, const pk_forest *f, int w)
-{
-    return g_opt.extract_q != 0 && w == 5 && g_opt.extract_pair && g_opt.extract_clean != 0 && f &&
-           f->q_state == 1 && f->F == 121 && m->norm != nullptr && m->clean && m->ld < (1 << 20);
-}
-
 int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
-                      int blk, uint8_t *d_status, double *fea64_rows, const pk_forest *codes_of)
+                      int blk, uint8_t *d_status, double *fea64_rows)
 {
     if (cn <= 0) return PK_OK;
     pk_prof_scope prof(ctx, PK_K_EXTRACT, st);
-    if (codes_of) {
-        // rank codes straight from the extractor: `tiles` is a [tile][F][128] uint16 buffer
-        if (!pk_extract_codes_ok(m, codes_of, w) || blk != 128 || fea64_rows) {
-            pk_set_error("pk_launch_extract: rank codes asked for a case that cannot give them (internal error)");
-            return PK_E_INVALID;
-        }
-        const unsigned grid = (unsigned)((cn + 31) / 32);
-        const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
-        pk_q_tables qt{codes_of->q_thr, codes_of->q_off, codes_of->q_lut, codes_of->q_par};
-        g_stat_extract_clean++;
-        hipLaunchKernelGGL((extract_pair_clean_kernel<5, false, true>), dim3((grid + 7u) & ~7u), dim3(64), 0,
-                           st, m->band, norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y,
-                           c0, cn, tiles, blk, d_status, nullptr, qt);
-        PK_HIP(hipGetLastError());
-        return PK_OK;
-    }
     if ((w == 5 || w == 6) && g_opt.extract_pair) {
         const unsigned grid = (unsigned)((cn + 31) / 32);
         const int F = (2 * w + 1) * (2 * w + 1);
@@ -960,9 +901,9 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
         if (clean) {
             const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
 #define PK_CLEAN(WW, FF)                                                                         \
-    hipLaunchKernelGGL((extract_pair_clean_kernel<WW, FF, false>), dim3((grid + 7u) & ~7u), dim3(64), 0, st, m->band, \
+    hipLaunchKernelGGL((extract_pair_clean_kernel<WW, FF>), dim3((grid + 7u) & ~7u), dim3(64), 0, st, m->band, \
                        norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,   \
-                       tiles, blk, d_status, fea64_rows, pk_q_tables{nullptr, nullptr, nullptr, nullptr})
+                       tiles, blk, d_status, fea64_rows)
             if (w == 5) {
                 if (fea64_rows) PK_CLEAN(5, true);
                 else PK_CLEAN(5, false);

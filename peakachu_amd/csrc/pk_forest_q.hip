@@ -37,7 +37,7 @@ typedef __attribute__((address_space(3))) u64 lds_u64;
 
 
 // ------------------------------------------------------------------------
-// float32 feature tiles [tile / 8][F][8 x 128] -> rank codes [tile][F][128] u16.
+// float32 feature tiles [tile / 8][F][8 x 128] -> rank codes [tile][F][64][2] u16.
 // (The extractor is asked for 1024-candidate float tiles: a feature's values of 8
 // consecutive 128-candidate tiles are then 4 KiB of contiguous HBM for the block that
 // converts this feature, instead of 8 pieces 60 KiB apart.)
@@ -93,14 +93,14 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
         for (int k = 0; k < 4; k++) {
             const int64_t ts = t + k < n_tiles ? t + k : t;
             const size_t row = ((size_t)(ts >> 3) * F + f) * (128 * PK_Q_FTILE) + (size_t)(ts & 7) * 128;
-            const float2 x2 = reinterpret_cast<const float2 *>(tiles + row)[lane];
-            xa[k] = x2.x;
-            xb[k] = x2.y;
+            xa[k] = tiles[row + lane];
+            xb[k] = tiles[row + 64 + lane];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (t + k >= n_tiles) break;
-            // (candidates 2 lane and 2 lane + 1; the forest kernel re-pairs them on its way to LDS)
+            // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
+            // half): the two walks of a lane read the same LDS bank, different lanes different banks
             const size_t row = ((size_t)(t + k) * F + f) * 128;
             const unsigned c0 = q_code(xa[k], thr, lut, lo, inv), c1 = q_code(xb[k], thr, lut, lo, inv);
             reinterpret_cast<unsigned *>(qtiles + row)[lane] = c0 | (c1 << 16);
@@ -228,24 +228,14 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     const int64_t wg = blockIdx.x;
     const int64_t cbase = wg * C;  // first candidate of this workgroup (relative to c0)
     {
-        // rank tiles of 128 candidates each ([F][128] u16, consecutive in memory); the second
-        // one exists only if it holds a candidate (the buffer ends with the last tile in use).
-        // In LDS dword j of a feature row holds the codes of candidates j (low half) and
-        // j + 64 (high half): the two walks of a lane then read one bank, and every lane its
-        // own.  A thread builds four such dwords from 8 bytes of each half row.
-        const unsigned short *src = qtiles + (size_t)cbase * F;
-        const int rows = ((CH == 4 && cbase + 128 < cn) ? 2 : 1) * F;
-        const int k = tid & 15;
-        for (int row = tid >> 4; row < rows; row += THREADS / 16) {
-            const uint2 a = *reinterpret_cast<const uint2 *>(src + (size_t)row * 128 + 4 * k);
-            const uint2 b = *reinterpret_cast<const uint2 *>(src + (size_t)row * 128 + 64 + 4 * k);
-            v4u o;
-            o.x = (a.x & 0xFFFFu) | (b.x << 16);
-            o.y = (a.x >> 16) | (b.x & 0xFFFF0000u);
-            o.z = (a.y & 0xFFFFu) | (b.y << 16);
-            o.w = (a.y >> 16) | (b.y & 0xFFFF0000u);
-            const int f = row < F ? row : row - F;
-            *LDS_AT(lds_u4, (row < F ? 0 : HALF1) + f * 256 + k * 16) = o;
+        // rank tiles of 128 candidates each, consecutive in memory; the second one exists
+        // only if it holds a candidate (the buffer ends with the last tile in use)
+        const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
+        const int halves = (CH == 4 && cbase + 128 < cn) ? 2 : 1;
+        const int nu = halves * (HB >> 4);
+        for (int i = tid; i < nu; i += THREADS) {
+            const int o = i << 4;
+            *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = src[i];
         }
     }
     // walk c of a lane = candidate lane + 64 (NCH * sub + c) of the workgroup
@@ -431,21 +421,6 @@ int q_upload(void **dst, const V &v)
 
 }  // namespace
 
-int pk_ctx_reserve_qtiles(pk_device_ctx *ctx, size_t bytes)
-{
-    if (bytes <= ctx->q_tiles_bytes) return PK_OK;
-    if (ctx->q_tiles) {
-        PK_HIP(hipStreamSynchronize(ctx->stream));
-        PK_HIP(hipStreamSynchronize(ctx->stream2));
-        PK_HIP(hipFree(ctx->q_tiles));
-        ctx->q_tiles = nullptr;
-        ctx->q_tiles_bytes = 0;
-    }
-    PK_HIP(hipMalloc((void **)&ctx->q_tiles, bytes));
-    ctx->q_tiles_bytes = bytes;
-    return PK_OK;
-}
-
 void pk_forest_q_release(pk_forest *f)
 {
     q_free(f);
@@ -611,13 +586,17 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
     const int F = f->F;
     const int64_t n_tiles = (cn + 127) / 128;
     const size_t qbytes = (size_t)n_tiles * F * 128 * sizeof(unsigned short);
-    if (!tiles && qbytes > ctx->q_tiles_bytes) {
-        pk_set_error("forest rank kernel: no rank codes staged for these candidates (internal error)");
-        return PK_E_INVALID;
+    if (qbytes > ctx->q_tiles_bytes) {
+        if (ctx->q_tiles) {
+            PK_HIP(hipStreamSynchronize(ctx->stream));
+            PK_HIP(hipFree(ctx->q_tiles));
+            ctx->q_tiles = nullptr;
+            ctx->q_tiles_bytes = 0;
+        }
+        PK_HIP(hipMalloc((void **)&ctx->q_tiles, qbytes));
+        ctx->q_tiles_bytes = qbytes;
     }
-    int rcq = pk_ctx_reserve_qtiles(ctx, qbytes);
-    if (rcq) return rcq;
-    if (tiles) {
+    {
         pk_prof_scope prof(ctx, PK_K_QUANT);
         // enough blocks per feature to fill the chip, few enough that the tables are
         // loaded for many tiles each
