@@ -238,8 +238,7 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         if (value < 0 || value > 2) return PK_E_INVALID;
         g_opt.forest_q_wpt = value;
     } else if (!strcmp(name, "forest_img")) {
-        if (value < 0 || value > 2) return PK_E_INVALID;
-        g_opt.forest_img = value;
+        g_opt.forest_img = value != 0;
     } else {
         pk_set_error("unknown option '%s'", name);
         return PK_E_INVALID;

@@ -158,7 +158,6 @@ struct pk_forest {
     // LDS image (forest_img_kernel): 0 = not tried, 1 = built, -1 = does not apply
     int img_state = 0;
     int img_slots = 0, img_n_grp = 0;
-    bool img_ilp2 = false;         // one wave per tree slot, two walks per lane
     int64_t img_opt_slots = -1;  // value of the forest_slots option the image was planned for
     struct pk_img_layout *img_layout = nullptr;
     uint4 *img = nullptr;          // device

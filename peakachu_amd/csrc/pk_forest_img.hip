@@ -214,178 +214,6 @@ __global__ __launch_bounds__(IMG_C *SLOTS) void forest_img_kernel(
 }
 
 
-// ------------------------------------------------------------------------
-// Two chains per lane: ONE wave per tree slot walks its tree for all 128
-// candidates of the workgroup (lane = candidates lane and lane + 64), the two
-// walks interleaved in one loop.  The walk is bound by the latency of the
-// dependent LDS round trip per level, not by issue slots or LDS bandwidth
-// (DESIGN.md), so what counts is the number of independent walks in flight
-// per CU = trees resident in LDS x 2; a wave per (tree, half) buys nothing
-// over two walks per wave, and a workgroup (<= 16 waves) can then keep up to
-// 16 trees walking.
-// ------------------------------------------------------------------------
-template <bool WITH_NAN, bool ALL_LEFT = false>
-__device__ __forceinline__ void walk_img2(uint2 curA, uint2 curB, int depth, unsigned lanekA,
-                                          unsigned lanekB, double *vA, double *vB)
-{
-    for (int d = 0; d < depth; d++) {
-        const unsigned xaA = __builtin_amdgcn_perm(curA.y, lanekA, 0x0c020700u);
-        const unsigned xaB = __builtin_amdgcn_perm(curB.y, lanekB, 0x0c020700u);
-        const float xA = *LDS_AT(const lds_f32, xaA);
-        const float xB = *LDS_AT(const lds_f32, xaB);
-        const unsigned caA = curA.y & 0x3fff8u, caB = curB.y & 0x3fff8u;
-        const u64 lwA = *LDS_AT(const volatile lds_u64, caA);
-        const u64 rwA = *LDS_AT(const volatile lds_u64, caA + 8);
-        const u64 lwB = *LDS_AT(const volatile lds_u64, caB);
-        const u64 rwB = *LDS_AT(const volatile lds_u64, caB + 8);
-        bool glA = xA <= __uint_as_float(curA.x);
-        bool glB = xB <= __uint_as_float(curB.x);
-        if (WITH_NAN) {
-            glA = glA | ((xA != xA) & ((curA.y & 1u) != 0));
-            glB = glB | ((xB != xB) & ((curB.y & 1u) != 0));
-        }
-        if (ALL_LEFT) {
-            glA = glA | (xA == xA);
-            glB = glB | (xB == xB);
-        }
-        curA.x = glA ? (unsigned)lwA : (unsigned)rwA;
-        curA.y = glA ? (unsigned)(lwA >> 32) : (unsigned)(rwA >> 32);
-        curB.x = glB ? (unsigned)lwB : (unsigned)rwB;
-        curB.y = glB ? (unsigned)(lwB >> 32) : (unsigned)(rwB >> 32);
-    }
-    *vA = *LDS_AT(const lds_f64, curA.x & 0x3ffffu);
-    *vB = *LDS_AT(const lds_f64, curB.x & 0x3ffffu);
-}
-
-#define IMG_PF16(X) IMG_PF12(X) X(12) X(13) X(14) X(15)
-
-template <int SLOTS, bool PRUNE>
-__global__ __launch_bounds__(64 * SLOTS) void forest_img2_kernel(
-    const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp,
-    const uint2 *__restrict__ troot, const int32_t *__restrict__ tdepth, int T, int F, int lenA,
-    int B0, const float *__restrict__ tiles, const uint8_t *__restrict__ status, int64_t c0,
-    int64_t cn, double *__restrict__ prob, double prune_sum, int warm_ahead, int dbg,
-    long long *__restrict__ stamps)
-{
-    constexpr int THREADS = 64 * SLOTS;
-    constexpr int PFN = 16;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);  // one wave per tree slot
-    const int HB = F * 256;
-    const int val_off = (int)HALF1 + HB;         // [SLOTS][128] float64
-    const int dec_off = val_off + SLOTS * 1024;  // 128 flags + 3 vote words
-    const unsigned lanekA = (unsigned)lane << 2, lanekB = lanekA | HALF1;
-    const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
-    if (!lds_at_zero && tid == 0 && stamps) stamps[65535] = 2;
-
-    if (PRUNE && tid < IMG_C + 3) *LDS_AT(lds_i32, dec_off + 4 * tid) = 0;
-    const int64_t tile = blockIdx.x;
-    {
-        const v4u *src = reinterpret_cast<const v4u *>(tiles + (size_t)tile * 2 * F * 64);
-        const int nu = (tile * IMG_C + 64 < cn ? 2 : 1) * (HB >> 4);
-        for (int i = tid; i < nu; i += THREADS) {
-            const int o = i << 4;
-            *LDS_AT(lds_u4, o < HB ? o : o - HB + (int)HALF1) = src[i];
-        }
-    }
-    // every wave looks at all 128 candidates (lane and lane + 64)
-    const int64_t locA = tile * IMG_C + lane, locB = locA + 64;
-    const unsigned stA = locA < cn ? status[c0 + locA] : 0;
-    const unsigned stB = locB < cn ? status[c0 + locB] : 0;
-    const bool actA = stA != 0 && lds_at_zero, actB = stB != 0 && lds_at_zero;
-    const bool wave_nan = __any(stA == 2 || stB == 2);
-    // threads 0..127 (waves 0 and 1) also own one candidate each for the ordered sum
-    const int64_t local = tile * IMG_C + tid;
-    const bool owner = tid < IMG_C;
-    const bool valid = owner && local < cn;
-    const unsigned st = valid ? status[c0 + local] : 0;
-    const bool active = st != 0 && lds_at_zero;
-
-    IMG_PF16(IMG_PF_DECL)
-    const v4u *pf_src;
-    int pf_nu;
-    int4 g_cur = gtab[0];
-    {
-        pf_src = img + g_cur.z;
-        pf_nu = g_cur.w;
-        IMG_PF16(IMG_PF_LOAD)
-        IMG_PF16(IMG_PF_STORE)
-    }
-    __syncthreads();
-
-#define IMG_STAMP(slot_)                                                                 \
-    do {                                                                                 \
-        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && g < 32)              \
-            stamps[((tid >> 6) * 32 + g) * 5 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
-    } while (0)
-    double acc = 0.0;
-    float warm_sink = 0.f;
-    for (int g = 0; g < n_grp; g++) {
-        const int t0 = g_cur.x, gt = g_cur.y;
-        const int4 g_nxt = gtab[g + 1];
-        IMG_STAMP(0);
-        if (g + 1 < n_grp) {
-            pf_src = img + g_nxt.z;
-            pf_nu = g_nxt.w;
-            IMG_PF16(IMG_PF_LOAD)
-        } else if (warm_ahead > 0) {
-            const int64_t ahead = tile + warm_ahead;
-            for (int line = tid; line < F * 4; line += THREADS)
-                if (ahead * IMG_C + 64 < cn)
-                    warm_sink += tiles[(size_t)ahead * 2 * F * 64 + (size_t)line * 32];
-        }
-        bool walkA = actA, walkB = actB;
-        if (PRUNE) {
-            walkA = walkA && *LDS_AT(lds_i32, dec_off + 4 * lane) == 0;
-            walkB = walkB && *LDS_AT(lds_i32, dec_off + 4 * (lane + 64)) == 0;
-        }
-        if (slot < gt && !(dbg & 2) && __any(walkA || walkB)) {
-            const int t = t0 + slot;
-            const uint2 r = troot[t];
-            const int depth = tdepth[t];
-            double vA, vB;
-            // lanes without a live candidate walk along (their results are not stored)
-            if (dbg & 8) walk_img2<false, true>(r, r, depth, lanekA, lanekB, &vA, &vB);
-            else if (wave_nan) walk_img2<true>(r, r, depth, lanekA, lanekB, &vA, &vB);
-            else walk_img2<false>(r, r, depth, lanekA, lanekB, &vA, &vB);
-            if (walkA) *LDS_AT(lds_f64, val_off + (slot * IMG_C + lane) * 8) = vA;
-            if (walkB) *LDS_AT(lds_f64, val_off + (slot * IMG_C + lane + 64) * 8) = vB;
-        }
-        IMG_STAMP(1);
-        __syncthreads();
-        IMG_STAMP(2);
-        if (g + 1 < n_grp) { IMG_PF16(IMG_PF_STORE) }
-        const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (IMG_C - 1))) == 0);
-        if (owner && active && undecided) {
-            for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * IMG_C + tid) * 8);  // tree order
-            if (PRUNE) {
-                const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < prune_sum;
-                if (out) {
-                    *LDS_AT(lds_i32, dec_off + 4 * tid) = 1;
-                    acc = 0.0;
-                } else {
-                    *LDS_AT(lds_i32, dec_off + 4 * (IMG_C + (g % 3))) = 1;
-                }
-            }
-        }
-        IMG_STAMP(3);
-        __syncthreads();
-        bool all_done = false;
-        if (PRUNE) {
-            all_done = *LDS_AT(lds_i32, dec_off + 4 * (IMG_C + (g % 3))) == 0;
-            if (tid == 0) *LDS_AT(lds_i32, dec_off + 4 * (IMG_C + ((g + 2) % 3))) = 0;
-        }
-        IMG_STAMP(4);
-        g_cur = g_nxt;
-        if (all_done) break;
-    }
-    if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
-    if (warm_sink == -__builtin_inff() && stamps) stamps[65534] = 1;
-#undef IMG_STAMP
-}
-
 template <typename KernelT>
 int img_set_max_lds(KernelT k, size_t bytes)
 {
@@ -427,13 +255,11 @@ static int img_plan(pk_forest *f)
     int best_slots = 0;
     double best_score = 0.0;
     const int forced = (int)g_opt.forest_slots;
-    const bool ilp2 = g_opt.forest_img == 2;  // one wave per tree, two walks per lane
-    for (int slots = 2; slots <= (ilp2 ? 16 : 8); slots++) {
-        if (slots == 3 && !ilp2) continue;  // not instantiated
+    for (int slots = 2; slots <= 8; slots++) {
+        if (slots == 3) continue;  // not instantiated
         if (forced && slots != forced) continue;
         pk_img_layout L;
-        if (!pk_img_make_layout(F, slots, ilp2 ? 16 * 64 * slots * 16 : pk_img_stage_bytes(slots), &L))
-            continue;
+        if (!pk_img_make_layout(F, slots, pk_img_stage_bytes(slots), &L)) continue;
         pk_img_out out;
         const int rc = pk_img_build(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(),
                                     f->h_feat.data(), f->h_thr.data(),
@@ -456,7 +282,6 @@ static int img_plan(pk_forest *f)
     img_free(f);
     f->img_layout = new pk_img_layout(bestL);
     f->img_slots = best_slots;
-    f->img_ilp2 = ilp2;
     f->img_n_grp = best.n_grp;
     PK_HIP(hipMalloc((void **)&f->img, best.words.size() * sizeof(uint2)));
     PK_HIP(hipMalloc((void **)&f->img_gtab, best.gtab.size() * sizeof(int32_t)));
@@ -481,8 +306,7 @@ int pk_forest_plan_blk(pk_forest *f)
         if (rc != PK_E_UNSUPPORTED) return 0;  // error already set
     }
     if (!g_opt.forest_img || g_opt.forest_lds <= 0) return pk_forest_tile_width(f->F);
-    if (f->img_state != 0 &&
-        (f->img_opt_slots != g_opt.forest_slots || f->img_ilp2 != (g_opt.forest_img == 2))) {
+    if (f->img_state != 0 && f->img_opt_slots != g_opt.forest_slots) {
         img_free(f);
         f->img_state = 0;
     }
@@ -515,23 +339,6 @@ int pk_forest_plan_blk(pk_forest *f)
         if (prune_sum > -1e300) IMG_LAUNCH_P(SLOTS, true);                                     \
         else IMG_LAUNCH_P(SLOTS, false);                                                       \
     } while (0)
-#define IMG2_LAUNCH_P(SLOTS, PRUNE)                                                            \
-    do {                                                                                       \
-        int rc__ = img_set_max_lds(forest_img2_kernel<SLOTS, PRUNE>, 163840);                  \
-        if (rc__) return rc__;                                                                 \
-        hipLaunchKernelGGL((forest_img2_kernel<SLOTS, PRUNE>), dim3(grid), dim3(64 * (SLOTS)), \
-                           163840, ctx->stream, reinterpret_cast<const v4u *>(f->img), reinterpret_cast<const int4 *>(f->img_gtab), \
-                           f->img_n_grp, f->img_troot, f->img_tdepth, f->T, f->F, L.lenA, L.B0, \
-                           tiles, d_status, c0, cn, d_prob, prune_sum,                         \
-                           g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
-                           (int)g_opt.forest_dbg, ctx->dbg_buf);                               \
-    } while (0)
-#define IMG2_LAUNCH(SLOTS)                                                                     \
-    case SLOTS:                                                                                \
-        if (prune_sum > -1e300) IMG2_LAUNCH_P(SLOTS, true);                                    \
-        else IMG2_LAUNCH_P(SLOTS, false);                                                      \
-        break;
-
 int pk_launch_forest_img(pk_device_ctx *ctx, pk_forest *f, const float *tiles,
                          const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob,
                          double prune_sum)
@@ -544,18 +351,6 @@ int pk_launch_forest_img(pk_device_ctx *ctx, pk_forest *f, const float *tiles,
     pk_prof_scope prof(ctx, PK_K_FOREST);
     const pk_img_layout &L = *f->img_layout;
     const unsigned grid = (unsigned)((cn + IMG_C - 1) / IMG_C);
-    if (f->img_ilp2) {
-        switch (f->img_slots) {
-            IMG2_LAUNCH(2) IMG2_LAUNCH(3) IMG2_LAUNCH(4) IMG2_LAUNCH(5) IMG2_LAUNCH(6) IMG2_LAUNCH(7)
-            IMG2_LAUNCH(8) IMG2_LAUNCH(9) IMG2_LAUNCH(10) IMG2_LAUNCH(11) IMG2_LAUNCH(12)
-            IMG2_LAUNCH(13) IMG2_LAUNCH(14) IMG2_LAUNCH(15) IMG2_LAUNCH(16)
-        default:
-            pk_set_error("forest image: %d slots not instantiated", f->img_slots);
-            return PK_E_INVALID;
-        }
-        PK_HIP(hipGetLastError());
-        return PK_OK;
-    }
     switch (f->img_slots) {
     case 2: IMG_LAUNCH(2); break;
     case 4: IMG_LAUNCH(4); break;

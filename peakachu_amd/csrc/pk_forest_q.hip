@@ -13,10 +13,11 @@
 //     rank codes once per candidate (a streaming pass, table lookups in LDS);
 //   * nodes are 4 bytes, sibling words adjacent; leaves lead back to themselves,
 //     so a tree is walked for a fixed number of levels with no termination test;
-//   * half the bytes per tree and per candidate tile put 9-13 whole trees and 256
-//     (or 128) candidates into the 160 KiB of LDS at once: one wave per tree,
-//     2 or 4 independent walks per lane, half as many tree groups (barriers, LDS
-//     commits, L2 -> LDS traffic) per candidate as the float kernels need.
+//   * half the bytes per tree and per candidate tile put 8 whole trees and 256
+//     candidates (F <= 192; else up to 16 trees and 128 candidates) into the
+//     160 KiB of LDS at once: half as many tree groups (barriers, LDS commits,
+//     L2 -> LDS traffic) per candidate as the float kernels need, and all 16
+//     waves walk (two per tree, one for each 128-candidate rank tile).
 // Per level and walk: v_perm_b32 (feature address), v_bfe_u32 + v_lshl_add_u32
 // (pair address), v_cmp_le_u32_sdwa (code against the word's upper half),
 // v_cndmask_b32; ds_read_u16 + ds_read_b64.  Leaf values are added in tree order
@@ -46,19 +47,40 @@ typedef __attribute__((address_space(3))) u64 lds_u64;
 // below x (exact: the lookup cell settles all thresholds but the few -- mostly
 // none or one -- that share the cell, which are compared), NaN -> 0xFFFF.
 // ------------------------------------------------------------------------
-__device__ __forceinline__ unsigned q_code(float x, const float *thr, const unsigned *lut, float lo, float inv)
+// Eight values at a time, in phases, so that the eight lookups are in flight together and
+// no branch stands between them (NaN takes cell 0 like any small value and is overridden
+// at the end; the rare lanes whose cell holds more than one threshold finish in a loop).
+template <int N>
+__device__ __forceinline__ void q_codes(const float (&x)[N], unsigned (&code)[N], const float *thr,
+                                        const unsigned *lut, float lo, float inv)
 {
-    if (x != x) return 0xFFFFu;
-    const unsigned e = lut[pk_q_cell(x, lo, inv)];
-    unsigned r = e & 0xFFFFu;  // thresholds in lower cells: all below x
-    unsigned k = e >> 16;      // thresholds of x's own cell (ascending): mostly none or one
-    // the first one without a branch (thr[] is padded, so thr[r] is always readable) ...
-    const unsigned first = (k != 0) & (thr[r] < x);
-    r += first;
-    // ... the rare others in a loop only lanes with a crowded cell enter
-    if (first & (k > 1))
-        for (k--; k != 0 && thr[r] < x; k--) r++;
-    return r << 5;
+    unsigned e[N], r[N];
+    float th[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) e[i] = lut[pk_q_cell(x[i], lo, inv)];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        r[i] = e[i] & 0xFFFFu;  // thresholds in lower cells: all below x
+        th[i] = thr[r[i]];      // (thr[] is padded: always readable)
+    }
+    bool more = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const unsigned k = e[i] >> 16;  // thresholds of x's own cell (ascending): mostly none or one
+        const bool first = (k != 0) & (th[i] < x[i]);
+        r[i] += first;
+        more = more | (first & (k > 1));
+    }
+    if (__any(more)) {
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            unsigned k = e[i] >> 16;
+            if (k > 1 && r[i] != (e[i] & 0xFFFFu))
+                for (k--; k != 0 && thr[r[i]] < x[i]; k--) r[i]++;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) code[i] = x[i] != x[i] ? 0xFFFFu : r[i] << 5;
 }
 
 // the cell of every threshold, computed where the quantizer computes the cells of the features
@@ -83,27 +105,31 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     for (int i = threadIdx.x; i < PK_Q_CELLS; i += 256) lut[i] = qlut[(size_t)f * PK_Q_CELLS + i];
     const float lo = qpar[2 * f], inv = qpar[2 * f + 1];
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // a wave converts four rows per trip: the loads of all four are in flight together
     // (one row per trip left the kernel waiting for HBM: 1.55 ms per 5.6 M candidates)
     // (a wave takes four consecutive tiles, the block sixteen: 8 KiB of this feature's values)
+    // (four consecutive tiles starting at a multiple of four lie in ONE group of eight: their
+    // rows are 512 B apart -- immediate offsets of one address; the float buffer is whole
+    // groups, so a tile past n_tiles is readable and merely not converted)
+    const size_t out_stride = (size_t)F * 64;  // dwords between the rows of consecutive tiles
     for (int64_t t = ((int64_t)blockIdx.y * 4 + wave) * 4; t < n_tiles; t += (int64_t)gridDim.y * 16) {
-        float xa[4], xb[4];
+        const float *src = tiles + ((size_t)(t >> 3) * F + f) * (128 * PK_Q_FTILE) + (size_t)(t & 7) * 128 + lane;
+        float x[8];
+        unsigned code[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int64_t ts = t + k < n_tiles ? t + k : t;
-            const size_t row = ((size_t)(ts >> 3) * F + f) * (128 * PK_Q_FTILE) + (size_t)(ts & 7) * 128;
-            xa[k] = tiles[row + lane];
-            xb[k] = tiles[row + 64 + lane];
+            x[2 * k] = src[k * 128];
+            x[2 * k + 1] = src[k * 128 + 64];
         }
+        q_codes<8>(x, code, thr, lut, lo, inv);
+        // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
+        // half): the two walks of a lane read the same LDS bank, different lanes different banks
+        unsigned *dst = reinterpret_cast<unsigned *>(qtiles) + ((size_t)t * F + f) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (t + k >= n_tiles) break;
-            // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
-            // half): the two walks of a lane read the same LDS bank, different lanes different banks
-            const size_t row = ((size_t)(t + k) * F + f) * 128;
-            const unsigned c0 = q_code(xa[k], thr, lut, lo, inv), c1 = q_code(xb[k], thr, lut, lo, inv);
-            reinterpret_cast<unsigned *>(qtiles + row)[lane] = c0 | (c1 << 16);
+            dst[k * out_stride] = code[2 * k] | (code[2 * k + 1] << 16);
         }
     }
 }

@@ -78,7 +78,7 @@ def test_config2_properties(config2):
     try:
         for opts in (dict(chunk=65536), dict(chunk=1000003), dict(forest_slots=12), dict(forest_q_ch=2),
                      dict(forest_q_ch=2, forest_slots=7),
-                     dict(forest_q=0), dict(forest_q=0, forest_slots=5), dict(forest_q=0, forest_img=2),
+                     dict(forest_q=0), dict(forest_q=0, forest_slots=5),
                      dict(forest_q=0, forest_img=0, forest_pipe=0),
                      dict(forest_q=0, forest_img=0, forest_pipe=0, forest_slots=4),
                      dict(forest_q=0, forest_img=0, forest_pipe=2),

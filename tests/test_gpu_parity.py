@@ -68,8 +68,6 @@ def _extract_golden(name):
     (4, 160, 0, 0, 1, 0), (4, 160, 2, 0, 1, 0), (4, 160, 4, 0, 1, 0),
     (4, 160, 5, 0, 1, 0), (4, 160, 6, 0, 1, 0), (4, 160, 7, 0, 1, 0),
     (4, 160, 8, 0, 1, 0),
-    (4, 160, 0, 0, 2, 0), (4, 160, 2, 0, 2, 0), (4, 160, 3, 0, 2, 0),
-    (4, 160, 7, 0, 2, 0), (4, 160, 12, 0, 2, 0), (4, 160, 16, 0, 2, 0),
     # q = walks per lane of the rank kernel + 1 (1 = automatic)
     (4, 160, 0, 0, 1, 1), (4, 160, 4, 0, 1, 5), (4, 160, 9, 0, 1, 5), (4, 160, 16, 0, 1, 5),
     (4, 160, 0, 0, 1, 3), (4, 160, 2, 0, 1, 3), (4, 160, 3, 0, 1, 3), (4, 160, 13, 0, 1, 3),
@@ -80,8 +78,7 @@ def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img, q):
     tree slots; a tree buffer so small (1-2 KiB) that some trees are walked
     from global memory; the barrier-free per-wave pipeline (pipe>0: number of
     waves, 1 = as many as fit); the LDS-image kernel (img=1: fixed-depth walks
-    over absolute LDS addresses; img=2: one wave per tree, two walks per lane)
-    with automatic and forced slot counts; the rank kernel (q>0: 16-bit rank
+    over absolute LDS addresses) with automatic and forced slot counts; the rank kernel (q>0: 16-bit rank
     codes, 4-byte nodes, 2 or 4 walks per lane) with automatic and forced shapes."""
     z = gio.load("g2_forest_%s.npz" % tag)
     X = gio.load("g2_forest_plain.npz")["X"]
