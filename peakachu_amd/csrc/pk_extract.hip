@@ -506,6 +506,37 @@ __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) vo
     const int sld8 = sgn * ld8, s8 = sgn * 8;
 #define PK_CELL(base_, i_, q_) \
     (*reinterpret_cast<const double *>(bbase + (unsigned)((base_) + (i_) * s8 + __mul24((q_) - (i_), sld8))))
+    // ---- utils.py:228-235 on the raw counts: top-left w x w mean (lane A's local block,
+    // sequential C order) and the centre cell.  At w = 6 read BEFORE the window is
+    // gathered: the w x w block is 2 w^2 registers that would otherwise be live on top of
+    // the window's (72 + 182: more than the 256 of two waves per SIMD -- 17 registers went
+    // to scratch, 2.90 vs 2.44 ms); at w = 5 both fit and the window's loads go first.
+    constexpr bool TL_FIRST = W >= 6;
+    double acc = 0.0;
+    double centre = 0.0;
+    auto raw_block = [&]() {
+        if (role == 0) {
+            double tl[W][W];
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+#pragma unroll
+                for (int q = 0; q < W; q++) {
+                    const int k = d + q - i;
+                    tl[i][q] = (k >= dlo && k <= dhi) ? PK_CELL(raw0, i, q) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+#pragma unroll
+                for (int q = 0; q < W; q++) acc += tl[i][q];
+            }
+        }
+        centre = (d >= dlo && d <= dhi)
+                     ? *reinterpret_cast<const double *>(
+                           bbase + (unsigned)(((int64_t)(d - dlo) * ld + xc) * 8))
+                     : 0.0;
+    };
+    if (TL_FIRST && normalise) raw_block();
     double win[S][H];
     if (__all(inside)) {
 #pragma unroll
@@ -537,32 +568,9 @@ __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) vo
     }
     nnz += lane_swap_i(nnz);
     ok = ok && !((double)nnz < (double)F * 0.1);
-    // ---- utils.py:228-235 on the raw counts: top-left w x w mean (lane A's local block,
-    // sequential C order) and the centre cell
-    double acc = 0.0;
-    double centre = win[W][W];
-    if (normalise) {
-        if (role == 0) {
-            double tl[W][W];
-#pragma unroll
-            for (int i = 0; i < W; i++) {
-#pragma unroll
-                for (int q = 0; q < W; q++) {
-                    const int k = d + q - i;
-                    tl[i][q] = (k >= dlo && k <= dhi) ? PK_CELL(raw0, i, q) : 0.0;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < W; i++) {
-#pragma unroll
-                for (int q = 0; q < W; q++) acc += tl[i][q];
-            }
-        }
-        centre = (d >= dlo && d <= dhi)
-                     ? *reinterpret_cast<const double *>(
-                           bbase + (unsigned)(((int64_t)(d - dlo) * ld + xc) * 8))
-                     : 0.0;
-    } else {
+    if (!TL_FIRST && normalise) raw_block();
+    if (!normalise) {  // the window holds the raw counts themselves
+        centre = win[W][W];
 #pragma unroll
         for (int i = 0; i < W; i++) {
 #pragma unroll
