@@ -45,3 +45,13 @@ print("  commit+accumulate   %8.0f" % commit.mean())
 print("  wait at barrier 2   %8.0f" % bar2.mean())
 print("  total per group     %8.0f ; whole workgroup %.0f cycles" % ((st[:, :, 4] - st[:, :, 0]).mean(), tot.mean()))
 print("per-wave walk means:", np.round(walk.mean(1)).astype(int).tolist())
+if os.environ.get("PK_STAMP_MATRIX"):
+    np.set_printoptions(linewidth=250)
+    print("walk cycles / 10 per group (rows) and wave (columns); * = slowest")
+    for g in range(ng):
+        row = walk[:, g]
+        print("g%02d" % g, " ".join(("%4d%s" % (v / 10, "*" if v == row.max() else " ")) for v in row),
+              " release-mean %5d" % (st[:, g, 2].mean() - st[:, g, 0].mean()))
+    nodes = np.diff(fo.tree_off)
+    print("nodes per tree:", nodes.tolist())
+    print("tree depth:", [int(d) for d in fo.tree_depths()] if hasattr(fo, "tree_depths") else "n/a")
