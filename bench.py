@@ -230,6 +230,8 @@ def main():
                     help="N > 1: fall back to a gloo gather when the RCCL communicator cannot be built "
                          "(otherwise the run fails)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive extra leg")
+    ap.add_argument("--side-leg", action="store_true",
+                    help="extra leg: option overlap=2 (the extractor resident beside the forest)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use device 0 and the RCCL gather is skipped "
                          "(RCCL refuses two ranks on one GPU); the result is not a valid measurement")
@@ -396,7 +398,7 @@ def main():
     # beside the forest of chunk k (option overlap = 2).  Faster per step, but the forest
     # kernel then shares its SIMDs, so its own duration (the roofline line) is longer.
     side = None
-    if world == 1 and not any(o.startswith("overlap=") for o in a.opt):
+    if world == 1 and a.side_leg and not any(o.startswith("overlap=") for o in a.opt):
         _lib.set_option("overlap", 2)
         step()
         sync()
