@@ -169,7 +169,11 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
     }
 }
 
-template <int CH, int X0, int HALF1, bool WITH_NAN, bool ALL_LEFT = false>
+// POS >= 0: the wave's issue priority rotates every two levels, starting from POS (its
+// position among the four waves of its SIMD).  At equal priority the SIMD issues oldest
+// first: the walks of a group then finish in wave order, the last quarter about 25 % after
+// the first, and everybody waits for them at the barrier.
+template <int CH, int X0, int HALF1, bool WITH_NAN, bool ALL_LEFT = false, int POS = -1>
 __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase, unsigned lk0,
                                        unsigned lk1, double (&v)[CH])
 {
@@ -177,11 +181,43 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
 #pragma unroll
     for (int c = 0; c < CH; c++) w[c] = root;
     int d = depth;
-    for (; d >= 2; d -= 2) {  // two levels per trip: a taken branch costs an instruction refetch
-        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+#define Q_TWO_LEVELS()                                                  \
+    do {                                                                \
+        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1); \
+        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1); \
+    } while (0)
+    if (POS >= 0) {
+        for (; d >= 8; d -= 8) {
+            __builtin_amdgcn_s_setprio((POS + 0) & 3);
+            Q_TWO_LEVELS();
+            __builtin_amdgcn_s_setprio((POS + 1) & 3);
+            Q_TWO_LEVELS();
+            __builtin_amdgcn_s_setprio((POS + 2) & 3);
+            Q_TWO_LEVELS();
+            __builtin_amdgcn_s_setprio((POS + 3) & 3);
+            Q_TWO_LEVELS();
+        }
+        if (d >= 2) {
+            __builtin_amdgcn_s_setprio((POS + 0) & 3);
+            Q_TWO_LEVELS();
+            d -= 2;
+        }
+        if (d >= 2) {
+            __builtin_amdgcn_s_setprio((POS + 1) & 3);
+            Q_TWO_LEVELS();
+            d -= 2;
+        }
+        if (d >= 2) {
+            __builtin_amdgcn_s_setprio((POS + 2) & 3);
+            Q_TWO_LEVELS();
+            d -= 2;
+        }
+    } else {
+        for (; d >= 2; d -= 2) Q_TWO_LEVELS();  // two levels per trip: a taken branch costs an instruction refetch
     }
+#undef Q_TWO_LEVELS
     if (d) q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+    if (POS >= 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int c = 0; c < CH; c++)  // the leaf's float64 value follows its pair
         v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index(w[c]) + 1) << 3));
@@ -346,14 +382,25 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             const unsigned tbase = (unsigned)(EARLY ? img_off + slots_at.off[min(slot, 15)] : img_off + tt.x);
             const unsigned root = (unsigned)tt.z;
             // lanes without a live candidate walk along (their values are not stored)
+#define Q_WALK_POS(X0_, NAN_, POS_) q_walk<NCH, X0_, HALF1, NAN_, false, POS_>(root, tt.y, tbase, lk0, lk1, v)
+#define Q_WALK(X0_, NAN_)                              \
+    do {                                               \
+        if (dbg & 32) Q_WALK_POS(X0_, NAN_, -1);       \
+        else if ((wave >> 2) == 0) Q_WALK_POS(X0_, NAN_, 0); \
+        else if ((wave >> 2) == 1) Q_WALK_POS(X0_, NAN_, 1); \
+        else if ((wave >> 2) == 2) Q_WALK_POS(X0_, NAN_, 2); \
+        else Q_WALK_POS(X0_, NAN_, 3);                 \
+    } while (0)
             if (WPT == 2 && sub) {  // the second rank tile (the tile index is an immediate offset)
-                if (wave_nan) q_walk<NCH, HALF1, HALF1, true>(root, tt.y, tbase, lk0, lk1, v);
-                else q_walk<NCH, HALF1, HALF1, false>(root, tt.y, tbase, lk0, lk1, v);
+                if (wave_nan) Q_WALK(HALF1, true);
+                else Q_WALK(HALF1, false);
             } else {
                 if (dbg & 8) q_walk<NCH, 0, HALF1, false, true>(root, tt.y, tbase, lk0, lk1, v);  // wrong results
-                else if (wave_nan) q_walk<NCH, 0, HALF1, true>(root, tt.y, tbase, lk0, lk1, v);
-                else q_walk<NCH, 0, HALF1, false>(root, tt.y, tbase, lk0, lk1, v);
+                else if (wave_nan) Q_WALK(0, true);
+                else Q_WALK(0, false);
             }
+#undef Q_WALK
+#undef Q_WALK_POS
 #pragma unroll
             for (int c = 0; c < NCH; c++)
                 if (walk[c])
@@ -592,7 +639,7 @@ int pk_forest_q_plan(pk_forest *f)
                            cn, d_prob,                                                         \
                            prune_sum,                                                          \
                            g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
-                           (int)g_opt.forest_dbg, ctx->dbg_buf);                               \
+                           (int)g_opt.forest_dbg | (g_opt.forest_q_prio ? 0 : 32), ctx->dbg_buf);  \
     } while (0)
 #define Q_LAUNCH(CH, WPT, HALF1, EARLY)                                                        \
     do {                                                                                       \
