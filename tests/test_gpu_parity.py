@@ -102,6 +102,26 @@ def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img, q):
     assert np.array_equal(gio.bits(p), gio.bits(z["p"]))
 
 
+@pytest.mark.parametrize("q", [1, 0])
+@pytest.mark.parametrize("tag,name", [("balanced", "old_sklearn_rf_balanced.xz.joblib"),
+                                      ("plain", "old_sklearn_rf_plain.xz.joblib")])
+def test_old_sklearn_pickle_on_device(hip_lib, tag, name, q):
+    """A model file written by scikit-learn 0.24.2 / joblib 1.1.0 (counts in tree_.value, no
+    missing_go_to_left; tools/make_old_sklearn_fixture.py) -> load_model -> HIP forest: that
+    scikit-learn's own predict_proba[:, 1], bit for bit (rank kernel and float kernels)."""
+    import os
+    from peakachu_amd.forest import load_model
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "old_sklearn_rf.npz"))
+    ff = load_model(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+    old = _lib.load().pk_get_option(b"forest_q")
+    _lib.set_option("forest_q", q)
+    try:
+        p = _lib.HipForest(ff).predict(z["X"])
+    finally:
+        _lib.set_option("forest_q", old)
+    assert np.array_equal(gio.bits(p), gio.bits(z["p_" + tag]))
+
+
 @pytest.mark.parametrize("name,opts", [("forest_w5_t100.npz", {}), ("forest_w5_t100.npz", {"forest_q_wpt": 1}),
                                        ("forest_w5_t100.npz", {"forest_q_ch": 2}),
                                        ("forest_w5_t100.npz", {"forest_q": 0}),

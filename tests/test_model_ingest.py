@@ -169,3 +169,27 @@ def test_rejects_non_forests(tmp_path):
     joblib.dump({"a": 1}, path)
     with pytest.raises(ValueError):
         load_model(path)
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+OLD_FILES = [("balanced", "old_sklearn_rf_balanced.xz.joblib"), ("plain", "old_sklearn_rf_plain.xz.joblib"),
+             ("plain", "old_sklearn_rf_plain.raw.joblib")]
+
+
+@pytest.mark.parametrize("tag,name", OLD_FILES)
+def test_genuine_old_sklearn_pickles(tag, name):
+    """Pickles written by scikit-learn 0.24.2 + joblib 1.1.0 themselves (tools/
+    make_old_sklearn_fixture.py, run with this image's Anaconda interpreter): the node records
+    have no `missing_go_to_left`, `tree_.value` holds (weighted) class COUNTS, the file is
+    `joblib.dump(model, path, compress=('xz', 3))` as peakachu/train_models.py:116 writes it.
+    The forest read here, walked by the oracle, must give THAT scikit-learn's own
+    predict_proba[:, 1] bit for bit."""
+    from oracle import oracle_np as onp
+    z = np.load(os.path.join(GOLDEN, "old_sklearn_rf.npz"))
+    assert list(z["versions"][:2]) == ["0.24.2", "1.1.0"]
+    arr = sk_pickle.forest_arrays(os.path.join(GOLDEN, name))
+    assert arr["version"] == "0.24.2" and arr["F"] == 121 and len(arr["trees"]) == 12
+    assert arr["trees"][0]["value"].max() > 1.0  # counts
+    ff = load_model(os.path.join(GOLDEN, name))
+    p = onp.predict({k: getattr(ff, k) for k in FlatForest.FIELDS}, z["X"])
+    assert np.array_equal(p.view(np.uint64), z["p_" + tag].view(np.uint64))
