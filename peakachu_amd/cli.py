@@ -12,7 +12,7 @@ from . import call_loops, score_chromosome, score_genome
 
 # (flags, keyword arguments) per option group; a group is attached to the listed commands
 _COMMON_SCORING = [
-    (("-p", "--path"), dict(help="contact map: a cooler URI (needs `cooler`) or a .pkmap.npz container")),
+    (("-p", "--path"), dict(help="contact map: .cool, .mcool::/resolutions/<binsize> or a .pkmap.npz container")),
     (("--clr-weight-name",), dict(default="weight",
                                   help="bin-weight column used for balancing; 'raw' scores the raw counts")),
     (("-m", "--model"), dict(type=str, help="model: pickled sklearn forest or flat-forest .npz")),

@@ -4,7 +4,9 @@ The reference reads `.cool` through `cooler` and `.hic` through `straw`
 (peakachu/score_genome.py:26-35,55-57; peakachu/utils.py:17-58).  Neither
 package (nor a contact map) is available in the build environment, so the
 drivers accept
-  * a `.cool` URI when `cooler` is importable (same calls as the reference),
+  * a `.cool` / `.mcool::/resolutions/N` URI -- through `cooler` when it is importable (same
+    calls as the reference), otherwise through `cool.CoolFile`, which reads the HDF5
+    container itself (`h5lite`),
   * a `.pkmap.npz` container written by `write_pkmap` -- per chromosome the
     symmetric raw-count CSR and, optionally, balancing weights -- which is
     what the synthetic configurations use.
@@ -107,12 +109,17 @@ def chrom_bins(lib, chrom):
 
 
 def open_map(path):
-    """`-p/--path`: .pkmap.npz, or anything cooler.Cooler accepts."""
+    """`-p/--path`: a .pkmap.npz container, or a .cool / .mcool::/resolutions/N URI -- through
+    `cooler` when it is installed (the reference's own reader), else through the built-in
+    reader (`cool.CoolFile`: pure Python, no h5py)."""
     if str(path).endswith(".npz"):
         return PkMap(path)
     try:
         import cooler
-    except ImportError as e:
-        raise ImportError("reading %s needs the `cooler` package (not installed); "
-                          "use a .pkmap.npz container instead" % path) from e
+    except ImportError:
+        from . import cool
+        if str(path).partition("::")[0].endswith(".hic"):
+            raise ImportError("reading %s needs `hic-straw` (not installed); convert it with "
+                              "`hic2cool` and pass the .cool / .mcool" % path)
+        return cool.CoolFile(path)
     return cooler.Cooler(path)

@@ -1,0 +1,98 @@
+"""`.cool` / `.mcool` ingestion without cooler or h5py (SURVEY.md section 8f row 4;
+peakachu/score_genome.py:26-35,55-57).
+
+The fixtures are genuine HDF5 files -- written by h5py 3.3.0 / libhdf5 1.10.6 (this image's
+Anaconda interpreter, tools/make_cool_fixture.py) in the layout cooler gives its files: chunked
+datasets with gzip 6 + shuffle, an enum-typed bins/chrom, fixed-length names, variable-length
+string attributes.  `cool_small_expected.npz` holds what
+`cooler.Cooler(path).matrix(balance=..., sparse=True).fetch(chrom)` returns for such a file,
+computed by the generator from the same arrays; `h5lite_types.h5` exercises the rest of the
+reader (n-D chunks, big-endian, fletcher32, deep and large groups, attributes)."""
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from peakachu_amd import cool, h5lite, io
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_h5lite_reads_what_libhdf5_wrote():
+    z = np.load(os.path.join(G, "h5lite_types_expected.npz"))
+    with h5lite.File(os.path.join(G, "h5lite_types.h5")) as f:
+        assert len(z.files) == 82
+        for k in z.files:
+            d = f[k.replace("|", "/")]
+            a, e = np.asarray(d.read()), z[k]
+            assert a.shape == e.shape and np.array_equal(a, e), k
+            assert a.dtype.kind == e.dtype.kind and a.dtype.itemsize == e.dtype.itemsize, k
+        assert len(f["many"].keys()) == 70 and f["a/b/c"].keys() == ["deep"]
+        assert f.attrs["float"] == 1.5 and f.attrs["fixed"] == "fixed-length"
+        assert f.attrs["text"] == "variable length é" and list(f.attrs["ints"]) == [1, 2, 3]
+        assert f["f32"].attrs == {"unit": "m"}
+        # ranged reads touch only the chunks they need and agree with the whole
+        assert np.array_equal(f["checksummed"][100:1030], z["checksummed"][100:1030])
+        assert np.array_equal(f["u64"][3:9], z["u64"][3:9]) and f["u64"][5:5].size == 0
+        assert np.array_equal(f["contiguous_f64"][10:20], z["contiguous_f64"][10:20])
+        with pytest.raises(KeyError):
+            f["nothing/here"]
+
+
+@pytest.mark.parametrize("uri", ["cool_small.cool", "cool_small.mcool::/resolutions/10000",
+                                 "cool_small.mcool::resolutions/10000"])
+def test_coolfile_serves_what_cooler_serves(uri):
+    z = np.load(os.path.join(G, "cool_small_expected.npz"))
+    c = cool.CoolFile(os.path.join(G, uri))
+    assert c.chromnames == [str(s) for s in z["chromnames"]] and c.binsize == int(z["binsize"])
+    assert [c.chromsizes[k] for k in c.chromnames] == [int(v) for v in z["chromsizes"]]
+    for name in c.chromnames:
+        n = int(z[name + "/n"])
+        assert c.chrom_bins(name) == n == io.chrom_bins(c, name)
+        for tag, bal in (("raw", False), ("weight", "weight"), ("KR", "KR"), ("weight", True)):
+            M = c.matrix(balance=bal, sparse=True).fetch(name)
+            assert M.shape == (n, n) and sparse.isspmatrix_coo(M)
+            assert M.data.dtype == (np.int32 if bal is False else np.float64)  # counts stay integers, as in cooler
+            A = sparse.csr_matrix((M.data.astype(np.float64), (M.row, M.col)), shape=M.shape)
+            A.sort_indices()
+            assert np.array_equal(A.indptr, z["%s/%s/indptr" % (name, tag)])
+            assert np.array_equal(A.indices, z["%s/%s/indices" % (name, tag)])
+            assert np.array_equal(A.data.view(np.uint64), z["%s/%s/data" % (name, tag)].view(np.uint64))
+            if bal is not False:  # the two weights are multiplied first: exactly symmetric, NaN where a weight is
+                assert (abs(A - A.T) > 0).nnz == 0 or np.isnan(A.data).any()
+        for col in ("weight", "KR"):
+            assert np.array_equal(c.bins().fetch(name)[col].values, z[name + "/" + col], equal_nan=True)
+    with pytest.raises(ValueError, match="Unknown sequence label"):
+        c.matrix(balance=False, sparse=True).fetch("chr9")
+    with pytest.raises(ValueError, match="No column 'bins/VC'"):
+        c.matrix(balance="VC", sparse=True).fetch("chr1")
+    c.close()
+
+
+def test_open_map_and_errors(tmp_path):
+    lib = io.open_map(os.path.join(G, "cool_small.cool"))
+    assert type(lib).__name__ in ("CoolFile", "Cooler") and lib.chromnames[0] == "chr1"
+    with pytest.raises(ValueError, match="resolutions/<binsize>"):
+        cool.CoolFile(os.path.join(G, "cool_small.mcool"))
+    with pytest.raises(KeyError):
+        cool.CoolFile(os.path.join(G, "cool_small.mcool") + "::/resolutions/5000")
+    bad = tmp_path / "not.cool"
+    bad.write_bytes(b"PK\x03\x04" + b"\x00" * 4000)
+    with pytest.raises(h5lite.H5FormatError, match="not an HDF5 file"):
+        cool.CoolFile(str(bad))
+    assert cool.is_cool(os.path.join(G, "cool_small.mcool") + "::/resolutions/10000") and not cool.is_cool(str(bad))
+
+
+def test_libver_latest_file_reads_or_says_why():
+    """A file written with libver='latest' (version-2 object headers, compact links, fixed-array
+    chunk indexes): what the reader supports is read correctly, and the resizable pixel tables
+    (extensible-array index) are refused with a message, not misread."""
+    ref = cool.CoolFile(os.path.join(G, "cool_small.cool"))
+    f = h5lite.File(os.path.join(G, "cool_small_latest.cool"))
+    for k in ("bins/start", "bins/end", "bins/weight", "bins/chrom", "chroms/name", "indexes/bin1_offset"):
+        assert np.array_equal(f[k].read(), ref._g[k].read(), equal_nan=f[k].dtype.kind == "f"), k
+    with pytest.raises(h5lite.H5Unsupported, match="extensible array"):
+        f["pixels/count"].read()
+    f.close()
+    ref.close()

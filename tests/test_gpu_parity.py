@@ -357,6 +357,46 @@ def test_score_genome_cli_matches_reference(hip_lib, tmp_path, tag, wname, chrom
     assert out.read_text() == str(z["genome_" + tag])
 
 
+@pytest.mark.parametrize("uri", ["cool_small.cool", "cool_small.mcool::/resolutions/10000"])
+@pytest.mark.parametrize("wname", ["raw", "weight", "KR"])
+def test_score_genome_on_a_cool_file(hip_lib, tmp_path, uri, wname):
+    """`score_genome -p map.cool` with no cooler / h5py installed (the built-in reader): the
+    bedpe equals what the same chromosomes give when the matrices cooler would return
+    (tests/golden/cool_small_expected.npz, see tests/test_cool.py) are handed to `Chromosome`
+    directly, i.e. peakachu/score_genome.py:53-67 with the file access taken out."""
+    import os
+    from scipy import sparse
+    from peakachu_amd import cli, scoreUtils
+    from peakachu_amd.forest import load_model
+    z = np.load(os.path.join(gio.GOLD, "cool_small_expected.npz"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = os.path.join(root, "peakachu_amd", "data", "forest_w5_t100.npz")
+    out = tmp_path / "cool.bedpe"
+    cli.run(["score_genome", "-p", os.path.join(gio.GOLD, uri), "-m", model, "-O", str(out),
+             "--clr-weight-name", wname, "-r", "10000", "-l", "6", "-u", "50", "--minimum-prob", "0.05"])
+    got = out.read_text()
+    ref = tmp_path / "ref.bedpe"
+    mdl = load_model(model)
+
+    def csr(name, tag):
+        n = int(z[name + "/n"])
+        return sparse.csr_matrix((z["%s/%s/data" % (name, tag)], z["%s/%s/indices" % (name, tag)],
+                                  z["%s/%s/indptr" % (name, tag)]), shape=(n, n))
+    for name in [str(c) for c in z["chromnames"]]:
+        raw = csr(name, "raw")
+        if wname == "raw":
+            X = scoreUtils.Chromosome(raw, model=mdl, raw_M=raw, weights=None, cname=name, lower=6, upper=50,
+                                      res=10000, width=5)
+        else:
+            X = scoreUtils.Chromosome(csr(name, wname), model=mdl, raw_M=raw, weights=z[name + "/" + wname],
+                                      cname=name, lower=6, upper=50, res=10000, width=5)
+        result, R = X.score(thre=0.05)
+        X.writeBed(str(ref), result, R)
+    want = ref.read_text() if ref.exists() else ""
+    assert got == want
+    assert len(got.splitlines()) > 20  # the comparison is not vacuous
+
+
 def test_score_chromosome_cli_matches_reference(hip_lib, tmp_path):
     import os
     from peakachu_amd import cli
