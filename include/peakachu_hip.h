@@ -171,6 +171,16 @@ pk_cands *pk_candidates_create(pk_matrix *raw, int lower, int upper, const int64
 /* copy the candidate coordinates of a pk_cands back to the host (N entries each) */
 int pk_cands_fetch(pk_cands *, int32_t *x, int32_t *y);
 
+/* ---- the Gaussian taps ----------------------------------------------------- */
+/* The window blur of getwindow is scipy.ndimage.gaussian_filter(sigma=1) (peakachu/utils.py:
+ * 211-237), whose 9 taps are exp(-x*x/2)/sum evaluated by the caller's numpy; two of them
+ * differ in the last bit between numpy releases (1.26 vs 2.2).  taps5 = centre tap and the
+ * four on one side, as the HOST's numpy computes them: the kernels then reproduce the
+ * reference of that very environment.  Default: the values numpy 2.2 / scipy 1.15 give.
+ * Applies to every device, now and later; must be finite, positive and decreasing. */
+int pk_set_gauss_taps(const double *taps5);
+int pk_get_gauss_taps(double *taps5);
+
 /* ---- tuning / measurement ------------------------------------------------ */
 /* named integer knobs ("chunk", "forest_ilp", "forest_lds", ...); returns
  * PK_E_INVALID for an unknown name */

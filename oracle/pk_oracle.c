@@ -56,7 +56,7 @@ double pko_csr_get(const int32_t *indptr, const int32_t *indices,
  * = exp(-0.5 x^2) / sum, x = -4..4 (gaussian_filter truncate=4.0 ->
  * radius = int(4.0*1 + 0.5) = 4).  Hex constants so no libm exp() rounding
  * can creep in; tests/test_oracle_golden.py checks them against scipy. */
-static const double GK[5] = {
+static double GK[5] = {
     0x1.9884a307594fbp-2,  /* k0 (centre) */
     0x1.ef8eb9ad499bap-3,  /* k1 */
     0x1.ba4b99d1799abp-5,  /* k2 */
@@ -65,6 +65,8 @@ static const double GK[5] = {
 };
 
 const double *pko_gauss_taps(void) { return GK; }
+/* tests only: the taps of another numpy (see tests/test_oracle_golden.py) */
+void pko_set_gauss_taps(const double *k) { for (int i = 0; i < 5; i++) GK[i] = k[i]; }
 
 /* scipy 'reflect' boundary: (d c b a | a b c d | d c b a). */
 static inline int reflect_idx(int i, int n)

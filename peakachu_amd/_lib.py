@@ -61,6 +61,8 @@ SIGNATURES = {
     "pk_candidates_create": (_vp, [_vp, C.c_int, C.c_int, _vp, _f64p, _vp, _vp, C.c_int64,
                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pk_cands_fetch": (C.c_int, [_vp, _i32p, _i32p]),
+    "pk_set_gauss_taps": (C.c_int, [_f64p]),
+    "pk_get_gauss_taps": (C.c_int, [_f64p]),
     "pk_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "pk_get_option": (C.c_int64, [C.c_char_p]),
     "pk_prof_enable": (C.c_int, [C.c_int]),
@@ -105,8 +107,25 @@ def load():
         fn.argtypes = args
     if L.pk_abi_version() != 1:
         raise PeakachuHipError("ABI version mismatch: %d" % L.pk_abi_version())
+    # the blur's taps as THIS interpreter's numpy evaluates them (the reference gets them from
+    # scipy.ndimage's _gaussian_kernel1d, same expression): their last bits vary with numpy
+    rc = L.pk_set_gauss_taps(gauss_taps())
+    if rc != 0:
+        raise PeakachuHipError("pk_set_gauss_taps failed: %s" % L.pk_last_error().decode("utf-8", "replace"))
     _LIB = L
     return L
+
+
+def gauss_taps(sigma=1.0, radius=4):
+    """Centre tap and the taps of one side of scipy.ndimage's Gaussian kernel (sigma 1, truncate
+    4): `phi = exp(-0.5 / sigma**2 * x**2); phi /= phi.sum()` -- _gaussian_kernel1d, unchanged
+    between scipy 1.7 and 1.15 -- evaluated by the numpy at hand."""
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    phi = phi / phi.sum()
+    if not np.array_equal(phi, phi[::-1]):
+        raise PeakachuHipError("numpy's exp gave an asymmetric Gaussian kernel")  # the kernels pair the taps
+    return np.ascontiguousarray(phi[radius:], np.float64)
 
 
 def last_error():

@@ -32,6 +32,9 @@ static std::mutex g_mu;
 std::recursive_mutex g_api_mu;
 #define PK_API_LOCK std::lock_guard<std::recursive_mutex> api_lock__(g_api_mu)
 static std::map<int, pk_device_ctx *> g_ctx;
+// Gaussian taps of the window blur (see pk_set_gauss_taps); defaults = numpy 2.2 / scipy 1.15
+static double g_taps[5] = {0x1.9884a307594fbp-2, 0x1.ef8eb9ad499bap-3, 0x1.ba4b99d1799abp-5,
+                           0x1.22724cb7eb269p-8, 0x1.18a9c4fd536c6p-13};
 
 // --------------------------------------------------------------- profiling
 struct prof_rec {
@@ -123,6 +126,7 @@ pk_device_ctx *pk_ctx(int device)
     }
     PK_HIP_NULL(hipMalloc((void **)&c->dbg_buf, 65536 * sizeof(long long)));
     PK_HIP_NULL(hipMemset(c->dbg_buf, 0, 65536 * sizeof(long long)));
+    if (pk_extract_upload_taps(g_taps) != PK_OK) return nullptr;
     g_ctx[device] = c;
     return c;
 }
@@ -188,6 +192,40 @@ extern "C" int pk_device_synchronize(int device)
     PK_HIP(hipStreamSynchronize(c->stream2));
     PK_HIP(hipStreamSynchronize(c->stream));
     PK_HIP(hipDeviceSynchronize());
+    return PK_OK;
+}
+
+extern "C" int pk_set_gauss_taps(const double *taps5)
+{
+    PK_API_LOCK;
+    if (!taps5) {
+        pk_set_error("pk_set_gauss_taps: null pointer");
+        return PK_E_INVALID;
+    }
+    for (int i = 0; i < 5; i++)
+        if (!(taps5[i] > 0.0) || !(taps5[i] < 1.0) || (i && !(taps5[i] < taps5[i - 1]))) {
+            pk_set_error("pk_set_gauss_taps: taps must be finite, in (0, 1) and decreasing from the centre");
+            return PK_E_INVALID;
+        }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        memcpy(g_taps, taps5, sizeof(g_taps));
+        for (auto &kv : g_ctx) {  // devices that are already in use
+            PK_HIP(hipSetDevice(kv.first));
+            PK_HIP(hipStreamSynchronize(kv.second->stream));
+            PK_HIP(hipStreamSynchronize(kv.second->stream2));
+            const int rc = pk_extract_upload_taps(g_taps);
+            if (rc) return rc;
+        }
+    }
+    return PK_OK;
+}
+
+extern "C" int pk_get_gauss_taps(double *taps5)
+{
+    if (!taps5) return PK_E_INVALID;
+    std::lock_guard<std::mutex> lk(g_mu);
+    memcpy(taps5, g_taps, sizeof(g_taps));
     return PK_OK;
 }
 

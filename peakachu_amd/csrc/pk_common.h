@@ -330,6 +330,7 @@ int pk_launch_csr_info(pk_device_ctx *, const int32_t *d_indptr, const int32_t *
 // features of candidates [c0, c0+cn) -> tiles (tile width BLK) + status.
 // If fea64_rows != nullptr also writes row-major float64 features [cn][F].
 int pk_matrix_prepare_norm(pk_device_ctx *, pk_matrix *);
+int pk_extract_upload_taps(const double *taps5);  // into the current device's constant memory
 int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
                       int blk, uint8_t *d_status, double *fea64_rows);

@@ -38,13 +38,19 @@
 
 namespace {
 
-// scipy.ndimage._filters._gaussian_kernel1d(sigma=1, order=0, radius=4):
-// exp(-x^2/2)/sum, as hex literals (no device exp()).
-__device__ constexpr double GK0 = 0x1.9884a307594fbp-2;
-__device__ constexpr double GK1 = 0x1.ef8eb9ad499bap-3;
-__device__ constexpr double GK2 = 0x1.ba4b99d1799abp-5;
-__device__ constexpr double GK3 = 0x1.22724cb7eb269p-8;
-__device__ constexpr double GK4 = 0x1.18a9c4fd536c6p-13;
+// scipy.ndimage._filters._gaussian_kernel1d(sigma=1, order=0, radius=4) = exp(-x^2/2)/sum:
+// centre tap and the four on one side.  The defaults are what numpy 2.2 / scipy 1.15 give
+// (the environment of the golden fixtures); the last bit of two of them depends on the
+// numpy that evaluates exp() -- numpy 1.26 differs by one ulp -- so the host passes the taps
+// of ITS numpy at load time (pk_set_gauss_taps) and the kernels read them from constant
+// memory (scalar loads; a 64-bit literal would be materialised in registers as well).
+__constant__ double pk_gk[5] = {0x1.9884a307594fbp-2, 0x1.ef8eb9ad499bap-3, 0x1.ba4b99d1799abp-5,
+                                0x1.22724cb7eb269p-8, 0x1.18a9c4fd536c6p-13};
+#define GK0 pk_gk[0]
+#define GK1 pk_gk[1]
+#define GK2 pk_gk[2]
+#define GK3 pk_gk[3]
+#define GK4 pk_gk[4]
 
 // scipy 'reflect' line extension: (d c b a | a b c d | d c b a)
 __host__ __device__ constexpr int reflect_idx(int i, int n)
@@ -930,6 +936,13 @@ int pk_matrix_prepare_norm(pk_device_ctx *ctx, pk_matrix *m)
         return PK_E_HIP;
     }
     m->clean = (h_flags == 0);
+    return PK_OK;
+}
+
+// copies the host's Gaussian taps into the current device's constant memory
+int pk_extract_upload_taps(const double *taps5)
+{
+    PK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pk_gk), taps5, 5 * sizeof(double), 0, hipMemcpyHostToDevice));
     return PK_OK;
 }
 

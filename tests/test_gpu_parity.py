@@ -102,6 +102,40 @@ def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img, q):
     assert np.array_equal(gio.bits(p), gio.bits(z["p"]))
 
 
+@pytest.mark.parametrize("w", [5, 6, 11, 3])
+def test_extract_with_the_taps_of_another_numpy(hip_lib, w):
+    """pk_set_gauss_taps: with the Gaussian taps numpy 1.26.4 computes (two of five differ by
+    one ulp from numpy 2.2's; tests/golden/gauss_scipy171.npz) every extractor kernel gives
+    the float64 features the CPU restatement gives with the same taps -- i.e. the reference
+    of THAT environment -- and they differ from the default ones."""
+    L = _lib.load()
+    k171 = gio.load("gauss_scipy171.npz")["taps"][4:].copy()
+    k0 = _lib.gauss_taps()
+    M, _ = synth.synth_band(900, 120, seed=w)
+    upper = 100
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    x, y = x[::7], y[::7]
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -2 * w + 1, upper + 2 * w - 1)
+    fea0, _, keep0 = hm.extract(w, x, y)
+    try:
+        _lib.check(L.pk_set_gauss_taps(k171), "taps")
+        onp.set_gauss_taps(k171)
+        fea1, _, keep1 = hm.extract(w, x, y)
+        ref, rkeep = onp.extract(Mf, e, w, x, y)
+    finally:
+        _lib.check(L.pk_set_gauss_taps(k0), "taps")
+        onp.set_gauss_taps(k0)
+    assert np.array_equal(keep1, rkeep) and np.array_equal(gio.bits(fea1), gio.bits(ref))
+    assert np.array_equal(keep0, keep1) and not np.array_equal(gio.bits(fea0), gio.bits(fea1))
+    assert np.abs(fea0 - fea1).max() < 1e-14
+    fea2 = hm.extract(w, x, y)[0]  # the defaults are back
+    assert np.array_equal(gio.bits(fea2), gio.bits(fea0))
+    bad = np.array([0.4, 0.5, 0.1, 0.01, 0.001])
+    assert L.pk_set_gauss_taps(bad) != 0  # not decreasing
+
+
 @pytest.mark.parametrize("q", [1, 0])
 @pytest.mark.parametrize("tag,name", [("balanced", "old_sklearn_rf_balanced.xz.joblib"),
                                       ("plain", "old_sklearn_rf_plain.xz.joblib")])
