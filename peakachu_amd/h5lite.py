@@ -10,7 +10,7 @@ container itself, in pure Python + numpy, after the HDF5 File Format Specificati
     h5py writes by default and therefore what cooler's files are -- and as compact link
     messages (libver='latest'); dense link storage (fractal heaps) is refused;
   * datasets: compact, contiguous and chunked (v1 B-tree chunk index, layout message v3;
-    of the v4 layouts of libver='latest': single chunk, implicit, fixed array);
+    the v4 layouts of libver='latest': single chunk, implicit, fixed array, extensible array);
     filters deflate and shuffle (cooler: gzip 6 + shuffle);
   * datatypes: fixed-point, IEEE float, fixed-length string, enum (returned as its integer
     base), variable-length string (attributes; global heap);
@@ -472,28 +472,139 @@ class Dataset:
             dblk = r.uint(hd, 8 + r.L, r.O)
             if r.undefined(dblk):
                 return [], cdims
-            if nent > (1 << page_bits):
-                raise H5Unsupported("paged fixed-array chunk index (very many chunks, libver='latest')")
+            def fa_elem(buf, q, k):
+                a = r.uint(buf, q, r.O)
+                if client == 1:  # filtered chunks: address, size (esize - O - 4 bytes), mask
+                    ssz = esize - r.O - 4
+                    size = r.uint(buf, q + r.O, ssz)
+                    mask = struct.unpack_from("<I", buf, q + r.O + ssz)[0]
+                else:
+                    size, mask = cbytes, 0
+                return None if r.undefined(a) else (offsets(k), a, size, mask)
+
+            out = []
+            if nent > (1 << page_bits):  # paged: bitmap of initialised pages, a checksum behind every page
+                pg = 1 << page_bits
+                npages = -(-nent // pg)
+                bm = (npages + 7) // 8
+                hdr = r.at(dblk, 6 + r.O + bm)
+                if hdr[:4] != b"FADB":
+                    raise H5FormatError("fixed array data block missing")
+                bitmap = hdr[6 + r.O:]
+                base = dblk + 6 + r.O + bm + 4
+                for pi in range(npages):
+                    if not (bitmap[pi >> 3] >> (7 - (pi & 7))) & 1:
+                        continue
+                    n = min(pg, nent - pi * pg)
+                    buf = r.at(base + pi * (pg * esize + 4), n * esize)
+                    out += [e for e in (fa_elem(buf, k * esize, pi * pg + k) for k in range(n)) if e]
+                return out, cdims
             db = r.at(dblk, 6 + r.O + nent * esize)
             if db[:4] != b"FADB":
                 raise H5FormatError("fixed array data block missing")
-            q = 6 + r.O
-            out = []
-            for k in range(nent):
-                a = r.uint(db, q, r.O)
-                if client == 1:  # filtered chunks: address, size (esize - O - 4 bytes), mask
-                    ssz = esize - r.O - 4
-                    size = r.uint(db, q + r.O, ssz)
-                    mask = struct.unpack_from("<I", db, q + r.O + ssz)[0]
-                else:
-                    size, mask = cbytes, 0
-                q += esize
-                if not r.undefined(a):
-                    out.append((offsets(k), a, size, mask))
+            out = [e for e in (fa_elem(db, 6 + r.O + k * esize, k) for k in range(nent)) if e]
             return out, cdims
+        if itype == 4:  # extensible array (a dataset with one unlimited dimension)
+            p += 5  # max bits, index elements, min pointers, min elements, page bits (repeated in the header)
+            addr = r.uint(lay, p, r.O)
+            if r.undefined(addr):
+                return [], cdims
+            elems = self._extensible_array(addr, cbytes)
+            return [(offsets(k), a, size, mask) for k, (a, size, mask) in enumerate(elems)
+                    if a is not None], cdims
         raise H5Unsupported("chunk index type %d (%s) of libver='latest'; rewrite the file with "
                             "`h5repack in out` or `cooler cp`" %
-                            (itype, {4: "extensible array", 5: "v2 B-tree"}.get(itype, "?")))
+                            (itype, {5: "v2 B-tree"}.get(itype, "?")))
+
+    def _extensible_array(self, addr, cbytes):
+        """All elements of an extensible-array chunk index, in order: [(address | None, bytes, mask)]."""
+        r = self._f._r
+        hd = r.at(addr, 12 + 6 * r.L + r.O)
+        if hd[:4] != b"EAHD":
+            raise H5FormatError("extensible array header missing")
+        client, esize, max_bits, idx_elmts, dblk_min, sblk_min_ptrs, page_bits = hd[5:12]
+        max_idx_set = r.uint(hd, 12 + 4 * r.L, r.L)
+        iblk = r.uint(hd, 12 + 6 * r.L, r.O)
+        if r.undefined(iblk):
+            return []
+        off_size = (max_bits + 7) // 8
+
+        def elem(buf, q):
+            a = r.uint(buf, q, r.O)
+            if client == 1:  # filtered chunks: address, chunk size, filter mask
+                ssz = esize - r.O - 4
+                size = r.uint(buf, q + r.O, ssz)
+                mask = struct.unpack_from("<I", buf, q + r.O + ssz)[0]
+            else:
+                size, mask = cbytes, 0
+            return (None if r.undefined(a) else a, size, mask)
+
+        def log2(v):
+            return v.bit_length() - 1
+
+        # super block s: 2^(s//2) data blocks of dblk_min * 2^((s+1)//2) elements each
+        nsblks = 1 + (max_bits - log2(dblk_min))
+        iblock_nsblks = 2 * log2(sblk_min_ptrs)
+        sb_ndblks = [1 << (s // 2) for s in range(nsblks)]
+        sb_nelmts = [dblk_min << ((s + 1) // 2) for s in range(nsblks)]
+        ndblk_addrs = 2 * (sblk_min_ptrs - 1)
+        nsblk_addrs = nsblks - iblock_nsblks
+        ib = r.at(iblk, 6 + r.O + idx_elmts * esize + (ndblk_addrs + nsblk_addrs) * r.O)
+        if ib[:4] != b"EAIB":
+            raise H5FormatError("extensible array index block missing")
+        q = 6 + r.O
+        out = [elem(ib, q + k * esize) for k in range(idx_elmts)]
+        q += idx_elmts * esize
+        dblk_addrs = [r.uint(ib, q + k * r.O, r.O) for k in range(ndblk_addrs)]
+        q += ndblk_addrs * r.O
+        sblk_addrs = [r.uint(ib, q + k * r.O, r.O) for k in range(nsblk_addrs)]
+
+        def data_block(a, nel):
+            if r.undefined(a):
+                return [(None, 0, 0)] * nel
+            if nel > (1 << page_bits):  # paged: a checksum behind every page
+                pg = 1 << page_bits
+                base = a + 6 + r.O + off_size
+                res = []
+                for p0 in range(0, nel, pg):
+                    n = min(pg, nel - p0)
+                    buf = r.at(base + (p0 // pg) * (pg * esize + 4), n * esize)
+                    res += [elem(buf, k * esize) for k in range(n)]
+                return res
+            buf = r.at(a, 6 + r.O + off_size + nel * esize)
+            if buf[:4] != b"EADB":
+                raise H5FormatError("extensible array data block missing")
+            return [elem(buf, 6 + r.O + off_size + k * esize) for k in range(nel)]
+
+        k = 0
+        for s in range(iblock_nsblks):  # data blocks addressed from the index block
+            for _ in range(sb_ndblks[s]):
+                if len(out) >= max_idx_set or k >= len(dblk_addrs):
+                    return out[:max_idx_set]
+                out += data_block(dblk_addrs[k], sb_nelmts[s])
+                k += 1
+        for j, sa in enumerate(sblk_addrs):  # the rest through super blocks
+            s = iblock_nsblks + j
+            if len(out) >= max_idx_set:
+                break
+            nd, nel = sb_ndblks[s], sb_nelmts[s]
+            if r.undefined(sa):
+                out += [(None, 0, 0)] * (nd * nel)
+                continue
+            paged = nel > (1 << page_bits)
+            bitmask = 0
+            if paged:
+                npages = nel >> page_bits
+                bitmask = nd * ((npages + 7) // 8)
+            sb = r.at(sa, 6 + r.O + off_size + bitmask + nd * r.O)
+            if sb[:4] != b"EASB":
+                raise H5FormatError("extensible array super block missing")
+            q = 6 + r.O + off_size + bitmask
+            for d in range(nd):
+                if len(out) >= max_idx_set:
+                    break
+                out += data_block(r.uint(sb, q + d * r.O, r.O), nel)
+        return out[:max_idx_set]
 
 
 class Group:

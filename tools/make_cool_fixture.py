@@ -153,3 +153,18 @@ with h5py.File(os.path.join(out, "h5lite_types.h5"), "w") as f:
     f["f32"].attrs["unit"] = "m"
 np.savez_compressed(os.path.join(out, "h5lite_types_expected.npz"), **{k.replace("/", "|"): v for k, v in exp2.items()})
 print("h5lite_types.h5", os.path.getsize(os.path.join(out, "h5lite_types.h5")))
+
+# ---- libver='latest' with MANY chunks: deep extensible arrays (super blocks, paged data blocks)
+with h5py.File(os.path.join(out, "h5lite_latest_many.h5"), "w", libver="latest") as f:
+    def ramp(n):
+        return (np.arange(n, dtype=np.int64) * 7919 % 30011).astype(np.int16)
+    f.create_dataset("ea_3000_chunks", data=ramp(3000 * 4 + 3), chunks=(4,), maxshape=(None,))
+    f.create_dataset("ea_20000_chunks", data=ramp(20000 * 2), chunks=(2,), maxshape=(None,))
+    f.create_dataset("ea_filtered_5000_chunks", data=ramp(5000 * 16 + 1), chunks=(16,), maxshape=(None,),
+                     compression="gzip", compression_opts=1, shuffle=True)
+    f.create_dataset("fa_5000_chunks", data=ramp(5000 * 4), chunks=(4,))  # fixed array, paged
+    f.create_dataset("fa_filtered_3000_chunks", data=ramp(3000 * 16), chunks=(16,), compression="gzip",
+                     compression_opts=1)
+    d = f.create_dataset("ea_sparse", shape=(64 * 300,), dtype="i2", chunks=(64,), maxshape=(None,))
+    d[64 * 250:64 * 251] = ramp(64)  # only one chunk, far into the array, was ever written
+print("h5lite_latest_many.h5", os.path.getsize(os.path.join(out, "h5lite_latest_many.h5")))

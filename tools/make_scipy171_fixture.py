@@ -12,7 +12,7 @@ rng = np.random.RandomState(99)
 out = {}
 for w in (5, 6, 11, 2):
     S = 2 * w + 1
-    wins = rng.rand(40, S, S) * rng.choice([1.0, 1e-3, 1e4], (40, 1, 1))
+    wins = rng.rand(12, S, S) * rng.choice([1.0, 1e-3, 1e4], (12, 1, 1))
     wins[::5] *= rng.rand(*wins[::5].shape) < 0.3  # sparse windows
     out["in_w%d" % w] = wins
     out["out_w%d" % w] = np.stack([gaussian_filter(a, sigma=1, order=0) for a in wins])
