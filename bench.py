@@ -223,6 +223,9 @@ def main():
                     help="flat-forest .npz, or random:T[:depth] for untrained random trees "
                          "(default: the committed forest for -w)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="time budget of the CPU baseline; large enough for the whole workload it also "
+                         "compares every scored pixel with the GPU's (cpu_baseline.pixels_equal)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = every rank its own chromosome (default); strong = one chromosome, "
                          "the candidate list cut into batch-aligned blocks")
@@ -552,7 +555,8 @@ def main():
         if side is not None:
             out["extract_beside_forest"] = side
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(Mf, exp_arr, w, fo, a.thre, x, y, a.batch, gpu_pixels)
+            out["cpu_baseline"] = cpu_baseline(Mf, exp_arr, w, fo, a.thre, x, y, a.batch, gpu_pixels,
+                                               target_s=a.cpu_seconds)
         print(json.dumps(out))
         sys.stdout.flush()
 
