@@ -274,6 +274,9 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_q_ch")) {
         if (value != 0 && value != 2 && value != 4) return PK_E_INVALID;
         g_opt.forest_q_ch = value;
+    } else if (!strcmp(name, "forest_q_persist")) {
+        if (value < -4096 || value > 8) return PK_E_INVALID;
+        g_opt.forest_q_persist = value;
     } else if (!strcmp(name, "forest_q_prio")) {
         g_opt.forest_q_prio = value != 0;
     } else if (!strcmp(name, "forest_q_early")) {
@@ -312,6 +315,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_q")) return g_opt.forest_q;
     if (!strcmp(name, "forest_q_ch")) return g_opt.forest_q_ch;
     if (!strcmp(name, "forest_q_wpt")) return g_opt.forest_q_wpt;
+    if (!strcmp(name, "forest_q_persist")) return g_opt.forest_q_persist;
     if (!strcmp(name, "forest_q_prio")) return g_opt.forest_q_prio;
     if (!strcmp(name, "forest_dbg")) return g_opt.forest_dbg;
     if (!strcmp(name, "forest_q_early")) return g_opt.forest_q_early;

@@ -85,6 +85,8 @@ struct pk_options {
     int64_t forest_q = 1;       // rank-quantised tiles + 4-byte nodes (forest_q_kernel) when the forest fits
     int64_t forest_q_ch = 0;    // walks per lane of forest_q_kernel: 0 = auto (4 when F <= 128), 2, 4
     int64_t forest_q_wpt = 0;   // waves per tree with 4 walks per lane: 0 = auto (2), 1, 2
+    int64_t forest_q_persist = 1; // rank kernel: persistent launch, this many workgroups per CU, each looping over
+                                  // tiles with the next tile prefetched (3.97 -> 3.81 ms); 0 = one workgroup per tile
     int64_t forest_q_prio = 1;  // rank kernel: rotate the waves' issue priorities during the walk (4.05 -> 3.89 ms)
     int64_t forest_q_early = 0; // two waves per tree: stage the slot's next tree as soon as both are done with it
                                 // (measured SLOWER, 4.51 vs 4.09 ms: two waves storing alone get half the LDS

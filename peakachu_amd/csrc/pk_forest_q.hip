@@ -276,21 +276,34 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     static_assert(!EARLY || WPT == 2, "early staging is written for two waves per tree");
     const int done_off = dec_off + 4 * (C + 4);  // EARLY: per tree slot, waves done with it (counts up)
     extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
-    const int tid = threadIdx.x;
+    const int HB = F * 256;
+    const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
+    if (!lds_at_zero && threadIdx.x == 0 && stamps) stamps[65535] = 2;
+
+    // Persistent launch (gridDim.x < tiles): a workgroup takes tiles blockIdx.x, blockIdx.x +
+    // gridDim.x, ...  While it walks the LAST tree group of a tile -- the staging registers are
+    // idle then -- it fetches the next tile's rank codes and status bytes into registers and
+    // commits them to LDS right after the group: a tile change then costs about what a
+    // group change costs, not a cold start (two dependent memory latencies).
+    const int64_t n_wg = (cn + C - 1) / C;
+    unsigned stc_n[NCH] = {}, st_n = 0;
+    bool tile_ready = false;  // (uniform) the tile of this trip is in LDS already
+    for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+    // (the thread index is opaque per trip: otherwise every address derived from it that the
+    // prologue and the epilogue of a tile use is hoisted out of this loop and stays in a
+    // register through all the walks -- 28 more VGPRs, and the tile prefetch then spills)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = wave / WPT, sub = wave % WPT;  // tree slot; which part of the candidates
-    const int HB = F * 256;
     const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
-    const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
-    if (!lds_at_zero && tid == 0 && stamps) stamps[65535] = 2;
-
+    if (wg != (int64_t)blockIdx.x) __syncthreads();  // nobody reads the previous trip's flags any more
     if (PRUNE)
         for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
     if (EARLY && tid < 8) *LDS_AT(lds_i32, done_off + 4 * tid) = 0;
-    const int64_t wg = blockIdx.x;
     const int64_t cbase = wg * C;  // first candidate of this workgroup (relative to c0)
-    {
+    if (!tile_ready) {
         // rank tiles of 128 candidates each, consecutive in memory; the second one exists
         // only if it holds a candidate (the buffer ends with the last tile in use)
         const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const int64_t loc = cbase + lane + 64 * (NCH * sub + c);
-        stc[c] = loc < cn ? status[c0 + loc] : 0;
+        stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[c0 + loc] : 0);
         act[c] = stc[c] != 0 && lds_at_zero;
         any_nan = any_nan || stc[c] == 2;
     }
@@ -317,8 +330,10 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     const bool owner = tid < C;
     const int64_t local = cbase + tid;
     const bool valid = owner && local < cn;
-    const unsigned st = valid ? status[c0 + local] : 0;
+    const unsigned st = tile_ready ? st_n : (valid ? status[c0 + local] : 0);
     const bool active = st != 0 && lds_at_zero;
+    const int64_t wg_next = wg + gridDim.x;
+    bool fetched = false;  // (uniform) tile_u / stc_n / st_n hold the next tile
 
     Q_PF16(Q_PF_DECL)
     const v4u *pf_src;
@@ -362,7 +377,28 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         if (g + 1 < n_grp) {  // loads fly while this group is walked
             stage_of(g_nxt, tt_nxt);
             Q_PF16(Q_PF_LOAD)
-        } else if (warm_ahead > 0) {
+        } else if (wg_next < n_wg) {
+            // last group of this tile: the next tile travels global -> VGPR during the walk
+            const int64_t cb = wg_next * C;
+            // (into the staging registers, which carry nothing during the last group: registers
+            // 0-2 the first rank tile, 3-5 the second; <= 3 x 1024 units of 16 B per tile)
+            const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cb * F);
+            const int upt = HB >> 4;
+            const bool two = CH == 4 && cb + 128 < cn;
+#define Q_TILE_LOAD(q, half, j)                                                   \
+    if ((j) * THREADS < upt && ((half) == 0 || two))                              \
+        pf##q = src[(half) * upt + min(tid + (j) * THREADS, upt - 1)];
+            Q_TILE_LOAD(0, 0, 0) Q_TILE_LOAD(1, 0, 1) Q_TILE_LOAD(2, 0, 2)
+            Q_TILE_LOAD(3, 1, 0) Q_TILE_LOAD(4, 1, 1) Q_TILE_LOAD(5, 1, 2)
+#undef Q_TILE_LOAD
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int64_t loc = cb + lane + 64 * (NCH * sub + c);
+                stc_n[c] = loc < cn ? status[c0 + loc] : 0;
+            }
+            st_n = (owner && cb + tid < cn) ? status[c0 + cb + tid] : 0;
+            fetched = true;
+        } else if (warm_ahead > 0 && gridDim.x >= n_wg) {
             // last group: pull the tiles of the workgroup that follows this one on this XCD
             // into its L2, one dword per 128-byte line; the value is never used
             const int64_t ahead = wg + warm_ahead;
@@ -461,6 +497,19 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     }
     if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
     if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-ahead loads alive
+    tile_ready = fetched;
+    if (fetched) {  // every walk of this tile is behind the last barrier: its rank tiles can go
+        const int64_t cb = wg_next * C;
+        const int upt = HB >> 4;
+        const bool two = CH == 4 && cb + 128 < cn;
+#define Q_TILE_STORE(q, half, j)                                                                        \
+    if ((j) * THREADS < upt && tid + (j) * THREADS < upt && ((half) == 0 || two))                       \
+        *LDS_AT(lds_u4, (half) * HALF1 + ((tid + (j) * THREADS) << 4)) = pf##q;
+        Q_TILE_STORE(0, 0, 0) Q_TILE_STORE(1, 0, 1) Q_TILE_STORE(2, 0, 2)
+        Q_TILE_STORE(3, 1, 0) Q_TILE_STORE(4, 1, 1) Q_TILE_STORE(5, 1, 2)
+#undef Q_TILE_STORE
+    }
+    }
 #undef Q_STAMP
 }
 
@@ -639,7 +688,7 @@ int pk_forest_q_plan(pk_forest *f)
                            L.val_off, L.img_off, slots_at, ctx->q_tiles, d_status, c0,         \
                            cn, d_prob,                                                         \
                            prune_sum,                                                          \
-                           g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
+                           persist ? (int)grid : g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm, \
                            (int)g_opt.forest_dbg | (g_opt.forest_q_prio ? 0 : 32), ctx->dbg_buf);  \
     } while (0)
 #define Q_LAUNCH(CH, WPT, HALF1, EARLY)                                                        \
@@ -685,7 +734,13 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
     }
     pk_prof_scope prof(ctx, PK_K_FOREST);
     const int C = 64 * L.ch;
-    const unsigned grid = (unsigned)((cn + C - 1) / C);
+    unsigned grid = (unsigned)((cn + C - 1) / C);
+    // persistent launch: forest_q_persist workgroups per CU, each looping over tiles (a negative
+    // value = exactly that many workgroups in all: tests)
+    const unsigned want = g_opt.forest_q_persist > 0 ? (unsigned)(ctx->cu_count * g_opt.forest_q_persist)
+                                                     : (unsigned)(-g_opt.forest_q_persist);
+    const bool persist = g_opt.forest_q_persist != 0 && grid > want;
+    if (persist) grid = want;
     // two waves per tree when the groups leave half the waves without one
     const bool wpt2 = L.ch == 4 && f->q_slots <= 8 && g_opt.forest_q_wpt != 1;
     const bool early = wpt2 && f->q_slot_bytes > 0;

@@ -74,10 +74,12 @@ def test_config2_properties(config2):
     # invariance to chunking and kernel variant
     old = {k: _lib.load().pk_get_option(k.encode())
            for k in ("chunk", "forest_slots", "forest_lds", "forest_pipe", "forest_pipe_slots",
-                     "extract_pair", "overlap", "extract_resident", "forest_img", "forest_q", "forest_q_ch")}
+                     "extract_pair", "overlap", "extract_resident", "forest_img", "forest_q", "forest_q_ch",
+                     "forest_q_persist")}
     try:
         for opts in (dict(chunk=65536), dict(chunk=1000003), dict(forest_slots=12), dict(forest_q_ch=2),
-                     dict(forest_q_ch=2, forest_slots=7),
+                     dict(forest_q_ch=2, forest_slots=7), dict(forest_q_persist=0), dict(forest_q_persist=2),
+                     dict(forest_q_persist=-7), dict(forest_q_persist=1, chunk=65536),
                      dict(forest_q=0), dict(forest_q=0, forest_slots=5),
                      dict(forest_q=0, forest_img=0, forest_pipe=0),
                      dict(forest_q=0, forest_img=0, forest_pipe=0, forest_slots=4),

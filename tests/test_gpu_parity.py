@@ -201,7 +201,9 @@ def test_forest_threshold_edges(hip_lib, name, opts):
 
 
 @pytest.mark.parametrize("opts", [{}, {"forest_q_early": 1}, {"forest_q_wpt": 1}, {"forest_q_ch": 2},
-                                  {"forest_q_prio": 0},
+                                  {"forest_q_prio": 0}, {"forest_q_persist": 0}, {"forest_q_persist": -1},
+                                  {"forest_q_persist": -5},
+                                  {"forest_q_persist": -3, "forest_q_ch": 2},
                                   {"forest_slots": 5}, {"forest_slots": 5, "forest_q_early": 1},
                                   {"forest_slots": 3, "forest_q_early": 1}])
 @pytest.mark.parametrize("name", ["forest_w5_t100.npz", "forest_w6_t100.npz"])
