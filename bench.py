@@ -233,8 +233,6 @@ def main():
                     help="N > 1: fall back to a gloo gather when the RCCL communicator cannot be built "
                          "(otherwise the run fails)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive extra leg")
-    ap.add_argument("--side-leg", action="store_true",
-                    help="extra leg: option overlap=2 (the extractor resident beside the forest)")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use device 0 and the RCCL gather is skipped "
                          "(RCCL refuses two ranks on one GPU); the result is not a valid measurement")
@@ -397,25 +395,6 @@ def main():
                  "scored_pixels": int(n_early), "same_pixels_as_full_evaluation": bool(n_early == n_out),
                  "note": "opt-in exact pruning at threshold %g; NOT the headline value" % a.thre}
 
-    # extra, not the headline: the extractor of chunk k+1 as one resident workgroup per CU
-    # beside the forest of chunk k (option overlap = 2).  Faster per step, but the forest
-    # kernel then shares its SIMDs, so its own duration (the roofline line) is longer.
-    side = None
-    if world == 1 and a.side_leg and not any(o.startswith("overlap=") for o in a.opt):
-        _lib.set_option("overlap", 2)
-        step()
-        sync()
-        s_steps = min(a.steps, 20)
-        t0 = time.perf_counter()
-        for _ in range(s_steps):
-            n_side = step()
-        sync()
-        s_el = time.perf_counter() - t0
-        _lib.set_option("overlap", 0)
-        side = {"value": int(x.size) * s_steps / s_el, "ms_per_step": s_el / s_steps * 1e3, "steps": s_steps,
-                "scored_pixels": int(n_side), "same_pixels": bool(n_side == n_out),
-                "note": "option overlap=2: extract(k+1) resident beside forest(k); NOT the headline value"}
-
     # extra, not the headline: SURVEY.md 8d's literal metric -- the same steps through
     # pk_score with HOST coordinate / result buffers (H2D of the candidates and D2H of the
     # scored pixels inside the timed region; matrix and forest stay resident)
@@ -552,8 +531,6 @@ def main():
             out["strong_check"] = strong_check
         if early is not None:
             out["early_exit"] = early
-        if side is not None:
-            out["extract_beside_forest"] = side
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Mf, exp_arr, w, fo, a.thre, x, y, a.batch, gpu_pixels,
                                                target_s=a.cpu_seconds)

@@ -122,7 +122,6 @@ pk_device_ctx *pk_ctx(int device)
             PK_HIP_NULL(hipEventCreateWithFlags(&c->ev_ext[i], hipEventDisableTiming));
             PK_HIP_NULL(hipEventCreateWithFlags(&c->ev_for[i], hipEventDisableTiming));
         }
-        PK_HIP_NULL(hipEventCreateWithFlags(&c->ev_quant, hipEventDisableTiming));
     }
     PK_HIP_NULL(hipMalloc((void **)&c->dbg_buf, 65536 * sizeof(long long)));
     PK_HIP_NULL(hipMemset(c->dbg_buf, 0, 65536 * sizeof(long long)));
@@ -242,11 +241,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_lds")) {
         if (value < 0) return PK_E_INVALID;
         g_opt.forest_lds = value;
-    } else if (!strcmp(name, "extract_resident")) {
-        g_opt.extract_resident = value != 0;
     } else if (!strcmp(name, "overlap")) {
-        if (value < 0 || value > 2) return PK_E_INVALID;
-        g_opt.overlap = value;
+        g_opt.overlap = value != 0;
     } else if (!strcmp(name, "forest_warm")) {
         if (value < 0) return PK_E_INVALID;
         g_opt.forest_warm = value;
@@ -306,7 +302,6 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
     if (!strcmp(name, "stat_extract_general")) return g_stat_extract_general;
     if (!strcmp(name, "overlap")) return g_opt.overlap;
-    if (!strcmp(name, "extract_resident")) return g_opt.extract_resident;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
     if (!strcmp(name, "forest_l2_tile")) return g_opt.forest_l2_tile;
     if (!strcmp(name, "early_exit")) return g_opt.early_exit;
@@ -1091,44 +1086,12 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
     if (chunk > cd->N) chunk = (cd->N + blk - 1) / blk * blk;
     const size_t tile_floats = (size_t)chunk * F;
-    // overlap = 2 (rank path only): extract(k+1) beside forest(k).  The quantizer has turned
-    // the float tiles of chunk k into rank codes before forest(k) starts, so ONE float
-    // buffer serves: extract(k+1) waits for quantize(k), quantize(k+1) for extract(k+1).
-    const bool side = g_opt.overlap == 2 && f->plan_kind == 2 && f->q_state == 1;
-    const bool overlap = g_opt.overlap == 1 || (g_opt.overlap == 2 && !side);
+    const bool overlap = g_opt.overlap != 0;
     int rc = pk_ctx_reserve_tiles(ctx, (overlap ? 2 : 1) * tile_floats * sizeof(float));
     if (rc) return rc;
     if ((w == 5 || w == 6) && g_opt.extract_pair && g_opt.extract_clean) {
         rc = pk_matrix_prepare_norm(ctx, m);
         if (rc) return rc;
-    }
-    if (side) {
-        auto run = [&]() -> int {
-            float *tiles = ctx->fea_tiles;
-            int64_t cn = cd->N < chunk ? cd->N : chunk;
-            int r = pk_launch_extract(ctx, ctx->stream, m, w, cd->x, cd->y, 0, cn, tiles, blk, cd->status,
-                                      nullptr);
-            for (int64_t c0 = 0; !r && c0 < cd->N; c0 += chunk) {
-                cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
-                r = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob, prune_sum);
-                const int64_t c1 = c0 + chunk;
-                if (r || c1 >= cd->N) continue;
-                const int64_t cn1 = cd->N - c1 < chunk ? cd->N - c1 : chunk;
-                PK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_quant, 0));
-                ctx->extract_resident = g_opt.extract_resident != 0;
-                r = pk_launch_extract(ctx, ctx->stream2, m, w, cd->x, cd->y, c1, cn1, tiles, blk, cd->status,
-                                      nullptr);
-                ctx->extract_resident = false;
-                if (r) continue;
-                PK_HIP(hipEventRecord(ctx->ev_ext[0], ctx->stream2));
-                PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[0], 0));
-            }
-            return r;
-        };
-        ctx->want_ev_quant = true;
-        rc = run();
-        ctx->want_ev_quant = false;
-        return rc;
     }
     // Two tile buffers: extract(k+1) runs on the low-priority stream beside forest(k).
     // The forest kernel is LDS / latency bound and leaves ~40 % of the VALU issue slots

@@ -41,9 +41,6 @@ struct pk_device_ctx {
     hipStream_t stream2 = nullptr;  // extractor of the NEXT chunk (low priority), see run_pipeline
     hipEvent_t ev_ext[2] = {nullptr, nullptr};  // extract(k) done, per tile buffer
     hipEvent_t ev_for[2] = {nullptr, nullptr};  // forest(k) done with its tile buffer
-    hipEvent_t ev_quant = nullptr;   // rank path: the quantizer is done with the float tiles
-    bool want_ev_quant = false;      // pk_launch_forest_q records ev_quant behind its quantizer
-    bool extract_resident = false;   // pk_launch_extract: one resident workgroup per CU (beside the forest)
     float *fea_tiles = nullptr;   // [tile][F][BLK] float32 feature tiles (two chunk buffers)
     size_t fea_tiles_bytes = 0;
     uint16_t *q_tiles = nullptr;  // [tile][F][128] rank codes of the current chunk (forest_q_kernel)
@@ -67,11 +64,8 @@ struct pk_options {
     int64_t forest_slots = 0;   // LDS kernel: tree slots (wave pairs) per workgroup; 0 = as many as
                                 // average trees fit beside the tile (8 at w=5, 7 at w=6)
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
-    int64_t overlap = 0;        // 1: extract(k+1) on a second stream as soon as its tile buffer is free;
-                                // 2 (rank path): extract(k+1) beside forest(k), see run_pipeline.  Measured on
-                                // config 2: 6.40 -> 6.34 (1) / 6.23 ms (2): the forest slows by most of what the
-                                // extractor saves (4.05 -> 4.69 ms), and its roofline fraction with it
-    int64_t extract_resident = 1; // overlap = 2: the side extractor is one resident workgroup per CU
+    int64_t overlap = 0;        // 1: extract(k+1) on a second stream as soon as its tile buffer is free
+                                // (measured: no gain -- kernels that share the chip slow each other down)
     int64_t extract_clean = 1;  // use the pre-divided band + shortcuts when the matrix qualifies
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
     int64_t forest_warm = 1;    // last tree group: pull the tile of workgroup id + N into this XCD's L2

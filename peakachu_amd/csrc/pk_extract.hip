@@ -466,8 +466,7 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 // The arithmetic order is unchanged; tests compare this kernel bit for bit with the
 // general one and with the CPU restatement of the reference.
 // ------------------------------------------------------------------------
-// (the body of the kernel: wave `vblock` of `vgrid`, so that the same code serves the
-// one-wave-per-block launch and the resident variant below)
+// (the body of the kernel, for wave `vblock` of `vgrid`)
 template <int W, bool FEA64, bool TL_FIRST = (W >= 6)>
 __device__ __forceinline__ void extract_pair_clean_body(
     const unsigned vblock, const unsigned vgrid, const unsigned lane_id,
@@ -698,33 +697,6 @@ __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) vo
 {
     extract_pair_clean_body<W, FEA64>(blockIdx.x, gridDim.x, threadIdx.x, band, norm_off, ld, dlo, dhi, n,
                                       exp_len, xs, ys, c0, cn, tiles, blk, status, fea64_rows);
-}
-
-// Resident variant for running BESIDE the forest kernel (run_pipeline, option overlap = 2):
-// one workgroup of four waves per CU -- one wave per SIMD -- loops over the chunk.  The
-// forest's workgroup (16 waves x 80 registers) and one 184-register extractor wave share a
-// SIMD's 512 registers; a second extractor wave would keep the next forest workgroup off
-// the CU until it ends (measured with the plain kernel on a second stream: the forest loses
-// what the extractor gains), and with exactly one workgroup per CU none is ever pending.
-// Wave j of XCD x (= blockIdx.x % 8) takes the virtual blocks 8 j + x, as the plain launch
-// places them.
-// (w = 5 only: the w = 6 window needs 243 registers, more than the forest leaves)
-__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(192))) void extract_pair_clean_side_kernel(
-    const unsigned vgrid, const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n,
-    int exp_len, const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
-    float *__restrict__ tiles, int blk, uint8_t *__restrict__ status)
-{
-    const unsigned xcd = blockIdx.x & 7u;
-    const unsigned per_iter = (gridDim.x >> 3) * 4u;  // waves of one XCD
-    for (unsigned j = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6); 8u * j + xcd < vgrid; j += per_iter) {
-        // (opaque per trip: otherwise the 66 cell offsets of a lane are hoisted out of the
-        // loop into 60 more registers, and the wave no longer fits beside the forest)
-        unsigned lane = threadIdx.x & 63u;
-        int ld_ = ld;
-        asm volatile("" : "+v"(lane), "+s"(ld_));
-        extract_pair_clean_body<5, false, true>(8u * j + xcd, vgrid, lane, band, norm_off, ld_, dlo, dhi, n, exp_len, xs,
-                                          ys, c0, cn, tiles, blk, status, nullptr);
-    }
 }
 
 // ------------------------------------------------------------------------
@@ -960,13 +932,7 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
                            ((size_t)((cn + blk - 1) / blk) * blk * F * sizeof(float) < (1ull << 31)) &&
                            (blk % 32 == 0) && m->ld < (1 << 20);
         (clean ? g_stat_extract_clean : g_stat_extract_general)++;
-        if (clean && w == 5 && ctx->extract_resident && !fea64_rows && (ctx->cu_count % 8) == 0) {
-            const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
-            const unsigned vgrid = (grid + 7u) & ~7u;
-            hipLaunchKernelGGL(extract_pair_clean_side_kernel, dim3((unsigned)ctx->cu_count), dim3(256), 0, st,
-                               vgrid, m->band, norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y,
-                               c0, cn, tiles, blk, d_status);
-        } else if (clean) {
+        if (clean) {
             const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
 #define PK_CLEAN(WW, FF)                                                                         \
     hipLaunchKernelGGL((extract_pair_clean_kernel<WW, FF>), dim3((grid + 7u) & ~7u), dim3(64), 0, st, m->band, \

@@ -730,7 +730,6 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
                            ctx->stream, tiles, n_tiles, F, f->q_thr, f->q_off, f->q_lut, f->q_par,
                            ctx->q_tiles);
         PK_HIP(hipGetLastError());
-        if (ctx->want_ev_quant) PK_HIP(hipEventRecord(ctx->ev_quant, ctx->stream));
     }
     pk_prof_scope prof(ctx, PK_K_FOREST);
     const int C = 64 * L.ch;
