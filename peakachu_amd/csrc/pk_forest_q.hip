@@ -289,136 +289,136 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     unsigned stc_n[NCH] = {}, st_n = 0;
     bool tile_ready = false;  // (uniform) the tile of this trip is in LDS already
     for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
-    // (the thread index is opaque per trip: otherwise every address derived from it that the
-    // prologue and the epilogue of a tile use is hoisted out of this loop and stays in a
-    // register through all the walks -- 28 more VGPRs, and the tile prefetch then spills)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = wave / WPT, sub = wave % WPT;  // tree slot; which part of the candidates
-    const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
-    if (wg != (int64_t)blockIdx.x) __syncthreads();  // nobody reads the previous trip's flags any more
-    if (PRUNE)
-        for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
-    if (EARLY && tid < 8) *LDS_AT(lds_i32, done_off + 4 * tid) = 0;
-    const int64_t cbase = wg * C;  // first candidate of this workgroup (relative to c0)
-    if (!tile_ready) {
-        // rank tiles of 128 candidates each, consecutive in memory; the second one exists
-        // only if it holds a candidate (the buffer ends with the last tile in use)
-        const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
-        const int halves = (CH == 4 && cbase + 128 < cn) ? 2 : 1;
-        const int nu = halves * (HB >> 4);
-        for (int i = tid; i < nu; i += THREADS) {
-            const int o = i << 4;
-            *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = src[i];
+        // (the thread index is opaque per trip: otherwise every address derived from it that the
+        // prologue and the epilogue of a tile use is hoisted out of this loop and stays in a
+        // register through all the walks -- 28 more VGPRs, and the tile prefetch then spills)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int slot = wave / WPT, sub = wave % WPT;  // tree slot; which part of the candidates
+        const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
+        if (wg != (int64_t)blockIdx.x) __syncthreads();  // nobody reads the previous trip's flags any more
+        if (PRUNE)
+            for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
+        if (EARLY && tid < 8) *LDS_AT(lds_i32, done_off + 4 * tid) = 0;
+        const int64_t cbase = wg * C;  // first candidate of this workgroup (relative to c0)
+        if (!tile_ready) {
+            // rank tiles of 128 candidates each, consecutive in memory; the second one exists
+            // only if it holds a candidate (the buffer ends with the last tile in use)
+            const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
+            const int halves = (CH == 4 && cbase + 128 < cn) ? 2 : 1;
+            const int nu = halves * (HB >> 4);
+            for (int i = tid; i < nu; i += THREADS) {
+                const int o = i << 4;
+                *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = src[i];
+            }
         }
-    }
-    // walk c of a lane = candidate lane + 64 (NCH * sub + c) of the workgroup
-    unsigned stc[NCH];
-    bool act[NCH];
-    bool any_nan = false;
+        // walk c of a lane = candidate lane + 64 (NCH * sub + c) of the workgroup
+        unsigned stc[NCH];
+        bool act[NCH];
+        bool any_nan = false;
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const int64_t loc = cbase + lane + 64 * (NCH * sub + c);
-        stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[c0 + loc] : 0);
-        act[c] = stc[c] != 0 && lds_at_zero;
-        any_nan = any_nan || stc[c] == 2;
-    }
-    const bool wave_nan = __any(any_nan);  // a wave holding NaN features takes the slow walk
-    // threads 0 .. C-1 also own one candidate each for the ordered sum
-    const bool owner = tid < C;
-    const int64_t local = cbase + tid;
-    const bool valid = owner && local < cn;
-    const unsigned st = tile_ready ? st_n : (valid ? status[c0 + local] : 0);
-    const bool active = st != 0 && lds_at_zero;
-    const int64_t wg_next = wg + gridDim.x;
-    bool fetched = false;  // (uniform) tile_u / stc_n / st_n hold the next tile
-
-    Q_PF16(Q_PF_DECL)
-    const v4u *pf_src;
-    int pf_nu, pf_dst;
-    const int pf_i0 = EARLY ? lane : tid, pf_stride = EARLY ? 64 : THREADS;
-    int4 g_cur = gtab[0];
-    int4 tt = ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree of the group: offset, units, depth, root
-    // what this thread stages of group `gi`: the whole group (all threads together), or,
-    // EARLY, this wave's half of the tree of its slot
-    auto stage_of = [&](const int4 gi, const int4 ti) {
-        if (EARLY) {
-            const int tu = ti.w, half = (tu + 1) >> 1, u0 = sub * half;
-            pf_src = img + gi.z + (ti.x >> 4) + u0;
-            pf_nu = slot < gi.y ? max(0, min(tu, u0 + half) - u0) : 0;
-            pf_dst = img_off + slots_at.off[min(slot, 15)] + (u0 << 4);
-        } else {
-            pf_src = img + gi.z;
-            pf_nu = gi.w;
-            pf_dst = img_off;
+        for (int c = 0; c < NCH; c++) {
+            const int64_t loc = cbase + lane + 64 * (NCH * sub + c);
+            stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[c0 + loc] : 0);
+            act[c] = stc[c] != 0 && lds_at_zero;
+            any_nan = any_nan || stc[c] == 2;
         }
-    };
-    {
-        stage_of(g_cur, tt);
-        Q_PF16(Q_PF_LOAD)
-        Q_PF16(Q_PF_STORE)
-    }
-    __syncthreads();  // rank tiles and first group are in LDS
+        const bool wave_nan = __any(any_nan);  // a wave holding NaN features takes the slow walk
+        // threads 0 .. C-1 also own one candidate each for the ordered sum
+        const bool owner = tid < C;
+        const int64_t local = cbase + tid;
+        const bool valid = owner && local < cn;
+        const unsigned st = tile_ready ? st_n : (valid ? status[c0 + local] : 0);
+        const bool active = st != 0 && lds_at_zero;
+        const int64_t wg_next = wg + gridDim.x;
+        bool fetched = false;  // (uniform) tile_u / stc_n / st_n hold the next tile
+
+        Q_PF16(Q_PF_DECL)
+        const v4u *pf_src;
+        int pf_nu, pf_dst;
+        const int pf_i0 = EARLY ? lane : tid, pf_stride = EARLY ? 64 : THREADS;
+        int4 g_cur = gtab[0];
+        int4 tt = ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree of the group: offset, units, depth, root
+        // what this thread stages of group `gi`: the whole group (all threads together), or,
+        // EARLY, this wave's half of the tree of its slot
+        auto stage_of = [&](const int4 gi, const int4 ti) {
+            if (EARLY) {
+                const int tu = ti.w, half = (tu + 1) >> 1, u0 = sub * half;
+                pf_src = img + gi.z + (ti.x >> 4) + u0;
+                pf_nu = slot < gi.y ? max(0, min(tu, u0 + half) - u0) : 0;
+                pf_dst = img_off + slots_at.off[min(slot, 15)] + (u0 << 4);
+            } else {
+                pf_src = img + gi.z;
+                pf_nu = gi.w;
+                pf_dst = img_off;
+            }
+        };
+        {
+            stage_of(g_cur, tt);
+            Q_PF16(Q_PF_LOAD)
+            Q_PF16(Q_PF_STORE)
+        }
+        __syncthreads();  // rank tiles and first group are in LDS
 
 #define Q_STAMP(slot_)                                                                   \
     do {                                                                                 \
         if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && g < 32)              \
             stamps[((tid >> 6) * 32 + g) * 5 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
-    double acc = 0.0;
-    unsigned warm_sink = 0;
-    for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
-        const int t0 = g_cur.x, gt = g_cur.y;
-        const int4 g_nxt = gtab[g + 1];
-        const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];  // (scalar loads: in flight during the walk)
-        Q_STAMP(0);
-        if (g + 1 < n_grp) {  // loads fly while this group is walked
-            stage_of(g_nxt, tt_nxt);
-            Q_PF16(Q_PF_LOAD)
-        } else if (wg_next < n_wg) {
-            // last group of this tile: the next tile travels global -> VGPR during the walk
-            const int64_t cb = wg_next * C;
-            // (into the staging registers, which carry nothing during the last group: registers
-            // 0-2 the first rank tile, 3-5 the second; <= 3 x 1024 units of 16 B per tile)
-            const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cb * F);
-            const int upt = HB >> 4;
-            const bool two = CH == 4 && cb + 128 < cn;
+        double acc = 0.0;
+        unsigned warm_sink = 0;
+        for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
+            const int t0 = g_cur.x, gt = g_cur.y;
+            const int4 g_nxt = gtab[g + 1];
+            const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];  // (scalar loads: in flight during the walk)
+            Q_STAMP(0);
+            if (g + 1 < n_grp) {  // loads fly while this group is walked
+                stage_of(g_nxt, tt_nxt);
+                Q_PF16(Q_PF_LOAD)
+            } else if (wg_next < n_wg) {
+                // last group of this tile: the next tile travels global -> VGPR during the walk
+                const int64_t cb = wg_next * C;
+                // (into the staging registers, which carry nothing during the last group: registers
+                // 0-2 the first rank tile, 3-5 the second; <= 3 x 1024 units of 16 B per tile)
+                const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cb * F);
+                const int upt = HB >> 4;
+                const bool two = CH == 4 && cb + 128 < cn;
 #define Q_TILE_LOAD(q, half, j)                                                   \
     if ((j) * THREADS < upt && ((half) == 0 || two))                              \
         pf##q = src[(half) * upt + min(tid + (j) * THREADS, upt - 1)];
-            Q_TILE_LOAD(0, 0, 0) Q_TILE_LOAD(1, 0, 1) Q_TILE_LOAD(2, 0, 2)
-            Q_TILE_LOAD(3, 1, 0) Q_TILE_LOAD(4, 1, 1) Q_TILE_LOAD(5, 1, 2)
+                Q_TILE_LOAD(0, 0, 0) Q_TILE_LOAD(1, 0, 1) Q_TILE_LOAD(2, 0, 2)
+                Q_TILE_LOAD(3, 1, 0) Q_TILE_LOAD(4, 1, 1) Q_TILE_LOAD(5, 1, 2)
 #undef Q_TILE_LOAD
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const int64_t loc = cb + lane + 64 * (NCH * sub + c);
-                stc_n[c] = loc < cn ? status[c0 + loc] : 0;
+                for (int c = 0; c < NCH; c++) {
+                    const int64_t loc = cb + lane + 64 * (NCH * sub + c);
+                    stc_n[c] = loc < cn ? status[c0 + loc] : 0;
+                }
+                st_n = (owner && cb + tid < cn) ? status[c0 + cb + tid] : 0;
+                fetched = true;
+            } else if (warm_ahead > 0 && gridDim.x >= n_wg) {
+                // last group: pull the tiles of the workgroup that follows this one on this XCD
+                // into its L2, one dword per 128-byte line; the value is never used
+                const int64_t ahead = wg + warm_ahead;
+                if ((ahead + 1) * C <= cn)
+                    for (int line = tid; line < F * CH; line += THREADS)
+                        warm_sink += reinterpret_cast<const unsigned *>(qtiles + (size_t)ahead * C * F)[line * 32];
             }
-            st_n = (owner && cb + tid < cn) ? status[c0 + cb + tid] : 0;
-            fetched = true;
-        } else if (warm_ahead > 0 && gridDim.x >= n_wg) {
-            // last group: pull the tiles of the workgroup that follows this one on this XCD
-            // into its L2, one dword per 128-byte line; the value is never used
-            const int64_t ahead = wg + warm_ahead;
-            if ((ahead + 1) * C <= cn)
-                for (int line = tid; line < F * CH; line += THREADS)
-                    warm_sink += reinterpret_cast<const unsigned *>(qtiles + (size_t)ahead * C * F)[line * 32];
-        }
-        bool walk[NCH];
-        bool any_walk = false;
+            bool walk[NCH];
+            bool any_walk = false;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            walk[c] = act[c] &&
-                      (!PRUNE || *LDS_AT(lds_i32, dec_off + 4 * (lane + 64 * (NCH * sub + c))) == 0);
-            any_walk = any_walk || walk[c];
-        }
-        if (slot < gt && !(dbg & 2) && __any(any_walk)) {
-            double v[NCH];
-            const unsigned tbase = (unsigned)(EARLY ? img_off + slots_at.off[min(slot, 15)] : img_off + tt.x);
-            const unsigned root = (unsigned)tt.z;
-            // lanes without a live candidate walk along (their values are not stored)
+            for (int c = 0; c < NCH; c++) {
+                walk[c] = act[c] &&
+                          (!PRUNE || *LDS_AT(lds_i32, dec_off + 4 * (lane + 64 * (NCH * sub + c))) == 0);
+                any_walk = any_walk || walk[c];
+            }
+            if (slot < gt && !(dbg & 2) && __any(any_walk)) {
+                double v[NCH];
+                const unsigned tbase = (unsigned)(EARLY ? img_off + slots_at.off[min(slot, 15)] : img_off + tt.x);
+                const unsigned root = (unsigned)tt.z;
+                // lanes without a live candidate walk along (their values are not stored)
 #define Q_WALK_POS(X0_, NAN_, POS_) q_walk<NCH, X0_, HALF1, NAN_, false, POS_>(root, tt.y, tbase, lk0, lk1, v)
 #define Q_WALK(X0_, NAN_)                              \
     do {                                               \
@@ -428,87 +428,87 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         else if ((wave >> 2) == 2) Q_WALK_POS(X0_, NAN_, 2); \
         else Q_WALK_POS(X0_, NAN_, 3);                 \
     } while (0)
-            if (WPT == 2 && sub) {  // the second rank tile (the tile index is an immediate offset)
-                if (wave_nan) Q_WALK(HALF1, true);
-                else Q_WALK(HALF1, false);
-            } else {
-                if (dbg & 8) q_walk<NCH, 0, HALF1, false, true>(root, tt.y, tbase, lk0, lk1, v);  // wrong results
-                else if (wave_nan) Q_WALK(0, true);
-                else Q_WALK(0, false);
-            }
+                if (WPT == 2 && sub) {  // the second rank tile (the tile index is an immediate offset)
+                    if (wave_nan) Q_WALK(HALF1, true);
+                    else Q_WALK(HALF1, false);
+                } else {
+                    if (dbg & 8) q_walk<NCH, 0, HALF1, false, true>(root, tt.y, tbase, lk0, lk1, v);  // wrong results
+                    else if (wave_nan) Q_WALK(0, true);
+                    else Q_WALK(0, false);
+                }
 #undef Q_WALK
 #undef Q_WALK_POS
 #pragma unroll
-            for (int c = 0; c < NCH; c++)
-                if (walk[c])
-                    *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * (NCH * sub + c)) * 8) = v[c];
-        }
-        Q_STAMP(1);
-        if (EARLY) {
-            // this wave no longer reads the tree of its slot; when its partner does not
-            // either, each stages its half of the slot's next tree.  The partner waits for
-            // nothing before it counts itself in, so the wait is bounded by its walk.
-            if (lane == 0)
-                __hip_atomic_fetch_add(LDS_AT(lds_i32, done_off + 4 * slot), 1, __ATOMIC_RELEASE,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (g + 1 < n_grp && pf_nu > 0 && !(dbg & 4)) {
-                bool both = false;
-                for (int spin = 0; spin < (1 << 22) && !both; spin++) {
-                    both = __hip_atomic_load(LDS_AT(lds_i32, done_off + 4 * slot), __ATOMIC_ACQUIRE,
-                                             __HIP_MEMORY_SCOPE_WORKGROUP) >= 2 * (g + 1);
-                    if (!both) __builtin_amdgcn_s_sleep(2);
-                }
-                if (!both && lane == 0 && stamps) stamps[65535] = 1;  // reported by the host as an error
-                Q_PF16(Q_PF_STORE)
+                for (int c = 0; c < NCH; c++)
+                    if (walk[c])
+                        *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * (NCH * sub + c)) * 8) = v[c];
             }
-        }
-        __syncthreads();  // every walk of the group is done (EARLY: and the next group staged)
-        Q_STAMP(2);
-        if (!EARLY && g + 1 < n_grp && !(dbg & 4)) { Q_PF16(Q_PF_STORE) }  // (dbg 4: timing ablation, wrong results)
-        const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
-        if (owner && active && undecided) {
-            for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
+            Q_STAMP(1);
+            if (EARLY) {
+                // this wave no longer reads the tree of its slot; when its partner does not
+                // either, each stages its half of the slot's next tree.  The partner waits for
+                // nothing before it counts itself in, so the wait is bounded by its walk.
+                if (lane == 0)
+                    __hip_atomic_fetch_add(LDS_AT(lds_i32, done_off + 4 * slot), 1, __ATOMIC_RELEASE,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (g + 1 < n_grp && pf_nu > 0 && !(dbg & 4)) {
+                    bool both = false;
+                    for (int spin = 0; spin < (1 << 22) && !both; spin++) {
+                        both = __hip_atomic_load(LDS_AT(lds_i32, done_off + 4 * slot), __ATOMIC_ACQUIRE,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP) >= 2 * (g + 1);
+                        if (!both) __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (!both && lane == 0 && stamps) stamps[65535] = 1;  // reported by the host as an error
+                    Q_PF16(Q_PF_STORE)
+                }
+            }
+            __syncthreads();  // every walk of the group is done (EARLY: and the next group staged)
+            Q_STAMP(2);
+            if (!EARLY && g + 1 < n_grp && !(dbg & 4)) { Q_PF16(Q_PF_STORE) }  // (dbg 4: timing ablation, wrong results)
+            const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
+            if (owner && active && undecided) {
+                for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
+                if (PRUNE) {
+                    // every remaining tree adds at most 1.0: if even that cannot lift the sum to
+                    // thre*T (1e-12 covers the rounding of at most T additions) the final p is
+                    // <= thre and the pixel is not reported -- stop walking it
+                    const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < prune_sum;
+                    if (out) {
+                        *LDS_AT(lds_i32, dec_off + 4 * tid) = 1;
+                        acc = 0.0;  // reported probability of a pruned candidate: 0
+                    } else {
+                        *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) = 1;  // still an open candidate
+                    }
+                }
+            }
+            Q_STAMP(3);
+            __syncthreads();  // next group staged; values consumed; votes cast
+            bool all_done = false;
             if (PRUNE) {
-                // every remaining tree adds at most 1.0: if even that cannot lift the sum to
-                // thre*T (1e-12 covers the rounding of at most T additions) the final p is
-                // <= thre and the pixel is not reported -- stop walking it
-                const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < prune_sum;
-                if (out) {
-                    *LDS_AT(lds_i32, dec_off + 4 * tid) = 1;
-                    acc = 0.0;  // reported probability of a pruned candidate: 0
-                } else {
-                    *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) = 1;  // still an open candidate
-                }
+                // a vote word is set before this barrier, read after it and cleared two groups
+                // ahead, so a clear and a set of the same word are always a barrier apart
+                all_done = *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) == 0;
+                if (tid == 0) *LDS_AT(lds_i32, dec_off + 4 * (C + ((g + 2) % 3))) = 0;
             }
+            Q_STAMP(4);
+            g_cur = g_nxt;
+            tt = tt_nxt;
+            if (all_done) break;
         }
-        Q_STAMP(3);
-        __syncthreads();  // next group staged; values consumed; votes cast
-        bool all_done = false;
-        if (PRUNE) {
-            // a vote word is set before this barrier, read after it and cleared two groups
-            // ahead, so a clear and a set of the same word are always a barrier apart
-            all_done = *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) == 0;
-            if (tid == 0) *LDS_AT(lds_i32, dec_off + 4 * (C + ((g + 2) % 3))) = 0;
-        }
-        Q_STAMP(4);
-        g_cur = g_nxt;
-        tt = tt_nxt;
-        if (all_done) break;
-    }
-    if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
-    if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-ahead loads alive
-    tile_ready = fetched;
-    if (fetched) {  // every walk of this tile is behind the last barrier: its rank tiles can go
-        const int64_t cb = wg_next * C;
-        const int upt = HB >> 4;
-        const bool two = CH == 4 && cb + 128 < cn;
+        if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
+        if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-ahead loads alive
+        tile_ready = fetched;
+        if (fetched) {  // every walk of this tile is behind the last barrier: its rank tiles can go
+            const int64_t cb = wg_next * C;
+            const int upt = HB >> 4;
+            const bool two = CH == 4 && cb + 128 < cn;
 #define Q_TILE_STORE(q, half, j)                                                                        \
     if ((j) * THREADS < upt && tid + (j) * THREADS < upt && ((half) == 0 || two))                       \
         *LDS_AT(lds_u4, (half) * HALF1 + ((tid + (j) * THREADS) << 4)) = pf##q;
-        Q_TILE_STORE(0, 0, 0) Q_TILE_STORE(1, 0, 1) Q_TILE_STORE(2, 0, 2)
-        Q_TILE_STORE(3, 1, 0) Q_TILE_STORE(4, 1, 1) Q_TILE_STORE(5, 1, 2)
+            Q_TILE_STORE(0, 0, 0) Q_TILE_STORE(1, 0, 1) Q_TILE_STORE(2, 0, 2)
+            Q_TILE_STORE(3, 1, 0) Q_TILE_STORE(4, 1, 1) Q_TILE_STORE(5, 1, 2)
 #undef Q_TILE_STORE
-    }
+        }
     }
 #undef Q_STAMP
 }
