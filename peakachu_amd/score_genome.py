@@ -22,16 +22,41 @@ def select_chromosomes(chromnames, chroms):
     return queue
 
 
-def build_chromosome(Lib, key, cname, model, correct, args, width, device):
-    """peakachu/score_genome.py:53-67 (the .cool branch)."""
+def fetch_inputs(Lib, key, correct):
+    """The reads of peakachu/score_genome.py:55-57 (balanced) / :63 (raw) for one chromosome."""
     if correct:
-        M = utils.tocsr(Lib.matrix(balance=correct, sparse=True).fetch(key))
-        raw_M = utils.tocsr(Lib.matrix(balance=False, sparse=True).fetch(key))
-        weights = Lib.bins().fetch(key)[correct].values
+        return (Lib.matrix(balance=correct, sparse=True).fetch(key),
+                Lib.matrix(balance=False, sparse=True).fetch(key),
+                Lib.bins().fetch(key)[correct].values)
+    return Lib.matrix(balance=False, sparse=True).fetch(key), None, None
+
+
+def prefetched(Lib, keys, correct):
+    """(key, inputs) for every key, in order; the NEXT chromosome is read on a background thread
+    while the caller prepares and scores the current one.  Reading and inflating a chromosome
+    costs more host time than scoring it on the GPU; zlib and numpy release the GIL.  All file
+    access happens on that one thread, in the reference's order."""
+    from concurrent.futures import ThreadPoolExecutor
+    keys = list(keys)
+    if not keys:
+        return
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(fetch_inputs, Lib, keys[0], correct)
+        for i, key in enumerate(keys):
+            cur = nxt.result()
+            nxt = pool.submit(fetch_inputs, Lib, keys[i + 1], correct) if i + 1 < len(keys) else None
+            yield key, cur
+
+
+def build_chromosome(Lib, key, cname, model, correct, args, width, device, inputs=None):
+    """peakachu/score_genome.py:53-67 (the .cool branch)."""
+    M, raw_M, weights = inputs if inputs is not None else fetch_inputs(Lib, key, correct)
+    if correct:
+        M, raw_M = utils.tocsr(M), utils.tocsr(raw_M)
         return scoreUtils.Chromosome(M, model=model, raw_M=raw_M, weights=weights, cname=cname,
                                      lower=args.lower, upper=args.upper, res=args.resolution,
                                      width=width, device=device)
-    M = utils.tocsr(Lib.matrix(balance=False, sparse=True).fetch(key))
+    M = utils.tocsr(M)
     return scoreUtils.Chromosome(M, model=model, raw_M=M, weights=None, cname=cname,
                                  lower=args.lower, upper=args.upper, res=args.resolution,
                                  width=width, device=device)
@@ -51,9 +76,9 @@ def main(args):
 
     # PK_FORCE_DIST=1 sends a single rank down the multi-rank branch (tests)
     if world == 1 and os.environ.get("PK_FORCE_DIST") != "1":
-        for key in queue:
+        for key, inputs in prefetched(Lib, queue, correct):
             cname = key if key.startswith('chr') else 'chr' + key
-            X = build_chromosome(Lib, key, cname, model, correct, args, width, local_rank)
+            X = build_chromosome(Lib, key, cname, model, correct, args, width, local_rank, inputs)
             result, R = X.score(thre=args.minimum_prob)
             X.writeBed(args.output, result, R)
         return
@@ -69,10 +94,9 @@ def main(args):
     try:
         recs, failure = [], None
         try:
-            for qi in mine:
-                key = queue[qi]
+            for qi, (key, inputs) in zip(mine, prefetched(Lib, [queue[q] for q in mine], correct)):
                 cname = key if key.startswith('chr') else 'chr' + key
-                X = build_chromosome(Lib, key, cname, model, correct, args, width, local_rank)
+                X = build_chromosome(Lib, key, cname, model, correct, args, width, local_rank, inputs)
                 result, R = X.score(thre=args.minimum_prob)
                 r, c = result.nonzero()
                 p = np.asarray(result[r, c]).ravel() if r.size else np.zeros(0)
