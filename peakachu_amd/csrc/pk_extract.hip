@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 // general one and with the CPU restatement of the reference.
 // ------------------------------------------------------------------------
 // (the body of the kernel, for wave `vblock` of `vgrid`)
-template <int W, bool FEA64, bool TL_FIRST = (W >= 6)>
+template <int W, bool FEA64>
 __device__ __forceinline__ void extract_pair_clean_body(
     const unsigned vblock, const unsigned vgrid, const unsigned lane_id,
     const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
@@ -515,13 +515,10 @@ __device__ __forceinline__ void extract_pair_clean_body(
 #define PK_CELL(base_, i_, q_) \
     (*reinterpret_cast<const double *>(bbase + (unsigned)((base_) + (i_) * s8 + __mul24((q_) - (i_), sld8))))
     // ---- utils.py:228-235 on the raw counts: top-left w x w mean (lane A's local block,
-    // sequential C order) and the centre cell.  At w = 6 read BEFORE the window is
-    // gathered: the w x w block is 2 w^2 registers that would otherwise be live on top of
-    // the window's (72 + 182: more than the 256 of two waves per SIMD -- 17 registers went
-    // to scratch, 2.90 vs 2.44 ms); at w = 5 both fit and the window's loads go first.
+    // sequential C order) and the centre cell.
     double acc = 0.0;
     double centre = 0.0;
-    auto raw_block = [&]() {
+    auto raw_block = [&]() {  // (general path: every cell tested against the band)
         if (role == 0) {
             double tl[W][W];
 #pragma unroll
@@ -543,15 +540,48 @@ __device__ __forceinline__ void extract_pair_clean_body(
                            bbase + (unsigned)(((int64_t)(d - dlo) * ld + xc) * 8))
                      : 0.0;
     };
-    if (TL_FIRST && normalise) raw_block();
     double win[S][H];
-    if (__all(inside)) {
+    const bool fast = __all(inside);  // every window of the wave lies inside the band
+    if (fast) {
+        // Overlapped memory phases (no cell needs a range test here): the raw top-left block,
+        // the centre cell and the first half of the window are requested together; the block
+        // is summed while that half is in flight (its registers are needed for the second
+        // half: block + window = 254 registers at w = 6), then the second half is requested.
+        // The window goes column by column, the order in which the column blur consumes it,
+        // so the blur starts on column 0 while later columns are still in flight.  (Before:
+        // window -> wait -> count -> block -> wait -> sum at w = 5, block -> wait -> sum ->
+        // window -> wait at w = 6: two full latencies with nothing to do.)
+        double tl[W][W];
+        const bool want_tl = normalise && role == 0;
+        if (want_tl) {
 #pragma unroll
-        for (int i = 0; i < S; i++) {
+            for (int i = 0; i < W; i++) {
 #pragma unroll
-            for (int q = 0; q < H; q++) win[i][q] = PK_CELL(row0, i, q);
+                for (int q = 0; q < W; q++) tl[i][q] = PK_CELL(raw0, i, q);
+            }
+        }
+        if (normalise)
+            centre = *reinterpret_cast<const double *>(bbase + (unsigned)(((int64_t)(d - dlo) * ld + xc) * 8));
+        constexpr int H1 = H / 2;  // the block is summed (its registers freed) before the second half
+#pragma unroll
+        for (int q = 0; q < H1; q++) {
+#pragma unroll
+            for (int i = 0; i < S; i++) win[i][q] = PK_CELL(row0, i, q);
+        }
+        if (want_tl) {
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+#pragma unroll
+                for (int q = 0; q < W; q++) acc += tl[i][q];
+            }
+        }
+#pragma unroll
+        for (int q = H1; q < H; q++) {
+#pragma unroll
+            for (int i = 0; i < S; i++) win[i][q] = PK_CELL(row0, i, q);
         }
     } else {
+        if (normalise) raw_block();
 #pragma unroll
         for (int i = 0; i < S; i++) {
 #pragma unroll
@@ -563,19 +593,6 @@ __device__ __forceinline__ void extract_pair_clean_body(
             }
         }
     }
-    // ---- utils.py:221-225 sparsity filter (quotient != 0 <=> count != 0)
-    int nnz = 0;
-#pragma unroll
-    for (int i = 0; i < S; i++) {
-#pragma unroll
-        for (int q = 0; q < H; q++) {
-            const bool mine = (q < W) || (role == 0);
-            nnz += (mine && win[i][q] != 0.0) ? 1 : 0;
-        }
-    }
-    nnz += lane_swap_i(nnz);
-    ok = ok && !((double)nnz < (double)F * 0.1);
-    if (!TL_FIRST && normalise) raw_block();
     if (!normalise) {  // the window holds the raw counts themselves
         centre = win[W][W];
 #pragma unroll
@@ -592,12 +609,18 @@ __device__ __forceinline__ void extract_pair_clean_body(
     const double p2ll = centre / ll_mean;
     ok = ok && (p2ll > 0.1);
 
-    // ---- scipy gaussian_filter(sigma=1), axis 0: down each local column
+    // ---- utils.py:221-225 sparsity filter (quotient != 0 <=> count != 0), counted column by
+    // column on the way, and scipy gaussian_filter(sigma=1), axis 0: down each local column
+    int nnz = 0;
 #pragma unroll
     for (int q = 0; q < H; q++) {
         double col[S];
+        const bool mine = (q < W) || (role == 0);
 #pragma unroll
-        for (int i = 0; i < S; i++) col[i] = win[i][q];
+        for (int i = 0; i < S; i++) {
+            col[i] = win[i][q];
+            nnz += (mine && col[i] != 0.0) ? 1 : 0;
+        }
 #pragma unroll
         for (int i = 0; i < S; i++) {
             win[i][q] = PK_BLUR9(col[i], col[reflect_idx(i - 4, S)], col[reflect_idx(i + 4, S)],
@@ -606,6 +629,8 @@ __device__ __forceinline__ void extract_pair_clean_body(
                                  col[reflect_idx(i - 1, S)], col[reflect_idx(i + 1, S)]);
         }
     }
+    nnz += lane_swap_i(nnz);
+    ok = ok && !((double)nnz < (double)F * 0.1);
     // ---- axis 1 (see extract_pair_kernel)
 #pragma unroll
     for (int ip = 0; ip <= W; ip++) {
