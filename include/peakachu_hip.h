@@ -13,8 +13,9 @@
  *  - functions returning a handle: NULL = error, message in pk_last_error().
  *  - host pointers are BORROWED for the duration of the call; outputs are
  *    caller-allocated; device memory lives in the opaque handles.
- *  - one HIP stream per handle family on the given device; calls on handles
- *    of one device are serialised by the library.
+ *  - one HIP stream pair per device; every entry point takes one process-wide
+ *    lock, so calls are serialised (across devices too: the intended
+ *    deployment is one process per GPU, see peakachu_amd/dist.py).
  *  - there is no CPU fallback: without a gfx950 device every compute call
  *    fails with PK_E_NODEVICE.
  */

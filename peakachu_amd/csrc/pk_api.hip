@@ -1273,9 +1273,20 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
     if (!rc && (w == 5 || w == 6) && g_opt.extract_pair && g_opt.extract_clean)
         rc = pk_matrix_prepare_norm(ctx, m);
-    if (!rc && hipMalloc((void **)&d_rows, (size_t)chunk * F * sizeof(double)) != hipSuccess) {
-        pk_set_error("pk_extract: staging allocation failed");
-        rc = PK_E_NOMEM;
+    if (!rc) {  // the staging rows live in the context and only ever grow: no allocation per call
+        const size_t need = (size_t)chunk * F * sizeof(double);
+        if (need > ctx->rows64_bytes) {
+            if (ctx->rows64) hipFree(ctx->rows64);
+            ctx->rows64 = nullptr;
+            ctx->rows64_bytes = 0;
+            if (hipMalloc((void **)&ctx->rows64, need) != hipSuccess) {
+                pk_set_error("pk_extract: staging allocation failed");
+                rc = PK_E_NOMEM;
+            } else {
+                ctx->rows64_bytes = need;
+            }
+        }
+        d_rows = ctx->rows64;
     }
     int64_t nk = 0;
     for (int64_t c0 = 0; !rc && c0 < N; c0 += chunk) {
@@ -1301,7 +1312,6 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
             keep[nk++] = c0 + i;
         }
     }
-    if (d_rows) hipFree(d_rows);
     pk_cands_destroy(cd);
     if (!rc) *n_keep = nk;
     return rc;

@@ -43,6 +43,8 @@ struct pk_device_ctx {
     hipEvent_t ev_for[2] = {nullptr, nullptr};  // forest(k) done with its tile buffer
     float *fea_tiles = nullptr;   // [tile][F][BLK] float32 feature tiles (two chunk buffers)
     size_t fea_tiles_bytes = 0;
+    double *rows64 = nullptr;        // pk_extract: float64 feature rows of one chunk (grow-only)
+    size_t rows64_bytes = 0;
     uint16_t *q_tiles = nullptr;  // [tile][F][128] rank codes of the current chunk (forest_q_kernel)
     size_t q_tiles_bytes = 0;
     struct pk_cands *score_cands = nullptr;  // candidate list reused by pk_score (host-buffer calls)
