@@ -268,7 +268,7 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_q")) {
         g_opt.forest_q = value != 0;
     } else if (!strcmp(name, "forest_q_ch")) {
-        if (value != 0 && value != 2 && value != 4) return PK_E_INVALID;
+        if (value != 0 && value != 1 && value != 2 && value != 4) return PK_E_INVALID;
         g_opt.forest_q_ch = value;
     } else if (!strcmp(name, "forest_q_persist")) {
         if (value < -4096 || value > 8) return PK_E_INVALID;

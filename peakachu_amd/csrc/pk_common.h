@@ -220,8 +220,9 @@ int pk_launch_forest_img(pk_device_ctx *, pk_forest *f, const float *tiles, cons
 #define PK_Q_CELLS 4096
 #define PK_Q_FTILE 8   // 128-candidate tiles per float32 tile handed to the quantizer
 struct pk_q_layout {
-    int F, slots, ch;   // ch = walks per lane: 2 (128 candidates per workgroup) or 4 (256)
-    int HB;             // bytes of a half tile: [F][128] u16
+    int F, slots, ch;   // ch = 64-candidate blocks per workgroup: 2 (128 candidates), 4 (256), or 1 (64
+                        // candidates, 64-candidate rank tiles and the wide node word: up to 1023 features)
+    int HB;             // bytes of a rank tile: [F][128] u16 (ch = 1: [F][64] u16)
     int half1;          // LDS offset of the second half tile (ch == 4), 0 otherwise
     int dec_off;        // early-termination flags
     int val_off;        // [slots][64*ch] float64 leaf values parked for the ordered sum

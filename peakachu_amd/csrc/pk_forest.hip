@@ -721,7 +721,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
 {
     if (cn <= 0) return PK_OK;
     // pk_forest_plan_blk decided how this forest is evaluated (and which tile width that needs)
-    if (f->plan_kind == 2 && blk == 128 * PK_Q_FTILE && f->q_state == 1)
+    if (f->plan_kind == 2 && blk == (f->q_ch == 1 ? 128 : 128 * PK_Q_FTILE) && f->q_state == 1)
         return pk_launch_forest_q(ctx, f, tiles, d_status, c0, cn, d_prob, prune_sum);
     if (f->plan_kind == 1 && blk == 64 && f->img_state == 1)
         return pk_launch_forest_img(ctx, f, tiles, d_status, c0, cn, d_prob, prune_sum);

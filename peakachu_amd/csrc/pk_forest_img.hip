@@ -301,7 +301,7 @@ int pk_forest_plan_blk(pk_forest *f)
         const int rc = pk_forest_q_plan(f);
         if (rc == PK_OK) {
             f->plan_kind = 2;
-            return 128 * PK_Q_FTILE;
+            return f->q_ch == 1 ? 128 : 128 * PK_Q_FTILE;  // (wide forests: plain 128-candidate float tiles)
         }
         if (rc != PK_E_UNSUPPORTED) return 0;  // error already set
     }

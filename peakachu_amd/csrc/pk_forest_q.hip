@@ -95,7 +95,7 @@ __global__ void q_cells_kernel(const float *__restrict__ qthr, const int32_t *__
 __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     const float *__restrict__ tiles, int64_t n_tiles, int F, const float *__restrict__ qthr,
     const int32_t *__restrict__ qoff, const unsigned *__restrict__ qlut,
-    const float *__restrict__ qpar, unsigned short *__restrict__ qtiles)
+    const float *__restrict__ qpar, unsigned short *__restrict__ qtiles, int tile64)
 {
     __shared__ float thr[2048];  // n <= 2047 entries + padding
     __shared__ unsigned lut[PK_Q_CELLS];
@@ -114,17 +114,34 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     // groups, so a tile past n_tiles is readable and merely not converted)
     const size_t out_stride = (size_t)F * 64;  // dwords between the rows of consecutive tiles
     for (int64_t t = ((int64_t)blockIdx.y * 4 + wave) * 4; t < n_tiles; t += (int64_t)gridDim.y * 16) {
-        const float *src = tiles + ((size_t)(t >> 3) * F + f) * (128 * PK_Q_FTILE) + (size_t)(t & 7) * 128 + lane;
+        // float tiles: groups of 8 (1024 candidates per feature row) or, tile64 (wide forests,
+        // whose one-window-per-wave extractor stores a feature at a time), single 128-tiles
+        const float *src = tile64 ? tiles + ((size_t)t * F + f) * 128 + lane
+                                  : tiles + ((size_t)(t >> 3) * F + f) * (128 * PK_Q_FTILE) + (size_t)(t & 7) * 128 + lane;
+        const int kstride = tile64 ? F * 128 : 128;  // floats between consecutive tiles of this feature
         float x[8];
         unsigned code[8];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            x[2 * k] = src[k * 128];
-            x[2 * k + 1] = src[k * 128 + 64];
+            const int kk = (tile64 && t + k >= n_tiles) ? 0 : k;  // (single tiles: nothing behind the last one)
+            x[2 * k] = src[(size_t)kk * kstride];
+            x[2 * k + 1] = src[(size_t)kk * kstride + 64];
         }
         q_codes<8>(x, code, thr, lut, lo, inv);
         // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
         // half): the two walks of a lane read the same LDS bank, different lanes different banks
+        if (tile64) {
+            // 64-candidate tiles [tile][F][64] u16 (wide forests): candidates lane and lane + 64
+            // of a 128-tile go to two consecutive 64-tiles
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (t + k >= n_tiles) break;
+                unsigned short *d16 = qtiles + ((size_t)(t + k) * 2 * F + f) * 64 + lane;
+                d16[0] = (unsigned short)code[2 * k];
+                d16[(size_t)F * 64] = (unsigned short)code[2 * k + 1];
+            }
+            continue;
+        }
         unsigned *dst = reinterpret_cast<unsigned *>(qtiles) + ((size_t)t * F + f) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -137,10 +154,12 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
 // ------------------------------------------------------------------------
 // the walk
 // ------------------------------------------------------------------------
+template <bool WIDE = false>
 __device__ __forceinline__ unsigned q_pair_index(unsigned w)
 {
     unsigned t;  // (the compiler turns a C bit-field extract into shift + and + add: 3 VALU, not 2)
-    asm("v_bfe_u32 %0, %1, 8, 12" : "=v"(t) : "v"(w));
+    if (WIDE) asm("v_bfe_u32 %0, %1, 10, 11" : "=v"(t) : "v"(w));
+    else asm("v_bfe_u32 %0, %1, 8, 12" : "=v"(t) : "v"(w));
     return t;
 }
 
@@ -153,17 +172,21 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
 {
     unsigned xv[CH];
     u64 pr[CH];
+    // one walk per lane = the 64-candidate tile [F][64] u16 and the wide node word (10-bit
+    // feature, 11-bit pair index, no NaN-goes-left bit: a NaN code is above every rank)
+    constexpr bool WIDE = CH == 1;
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         // byte 0 <- lane constant, byte 1 <- the word's feature byte
-        const unsigned xa = __builtin_amdgcn_perm(w[c], (c & 1) ? lk1 : lk0, 0x0c0c0400u);
+        const unsigned xa = WIDE ? ((w[c] & 0x3FFu) << 7) + lk0
+                                 : __builtin_amdgcn_perm(w[c], (c & 1) ? lk1 : lk0, 0x0c0c0400u);
         xv[c] = *LDS_AT(const lds_u16, xa + X0 + (c >> 1) * HALF1);
-        pr[c] = *LDS_AT(const lds_u64, tbase + (q_pair_index(w[c]) << 3));
+        pr[c] = *LDS_AT(const lds_u64, tbase + (q_pair_index<WIDE>(w[c]) << 3));
     }
 #pragma unroll
     for (int c = 0; c < CH; c++) {
-        bool gl = xv[c] <= (w[c] >> 16);  // rank(x) <= rank(threshold); bits 20..16 cannot flip it
-        if (WITH_NAN) gl = gl | ((xv[c] == 0xFFFFu) & ((w[c] & (1u << 20)) != 0));
+        bool gl = xv[c] <= (w[c] >> 16);  // rank(x) <= rank(threshold); the bits below cannot flip it
+        if (WITH_NAN && !WIDE) gl = gl | ((xv[c] == 0xFFFFu) & ((w[c] & (1u << 20)) != 0));
         if (ALL_LEFT) gl = gl | (xv[c] < 0x10000u);  // timing ablation: every lane takes the same path
         w[c] = gl ? (unsigned)pr[c] : (unsigned)(pr[c] >> 32);
     }
@@ -221,7 +244,7 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
     if (POS >= 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int c = 0; c < CH; c++)  // the leaf's float64 value follows its pair
-        v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index(w[c]) + 1) << 3));
+        v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index<CH == 1>(w[c]) + 1) << 3));
 }
 
 #define Q_PF16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
@@ -273,10 +296,11 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     constexpr int NCH = CH / WPT;  // walks per lane of one wave
     static_assert(THREADS >= C, "one thread per candidate owns the ordered sum");
     static_assert(WPT == 1 || (WPT == 2 && CH == 4), "two waves per tree = one per rank tile");
+    static_assert(CH == 1 || CH == 2 || CH == 4, "64, 128 or 256 candidates per workgroup");
     static_assert(!EARLY || WPT == 2, "early staging is written for two waves per tree");
     const int done_off = dec_off + 4 * (C + 4);  // EARLY: per tree slot, waves done with it (counts up)
     extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
-    const int HB = F * 256;
+    const int HB = CH == 1 ? F * 128 : F * 256;  // bytes of a rank tile ([F][64] u16 when CH = 1)
     const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
     if (!lds_at_zero && threadIdx.x == 0 && stamps) stamps[65535] = 2;
 
@@ -297,7 +321,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int slot = wave / WPT, sub = wave % WPT;  // tree slot; which part of the candidates
-        const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
+        const unsigned lk0 = (unsigned)lane << (CH == 1 ? 1 : 2), lk1 = lk0 + 2u;
         if (wg != (int64_t)blockIdx.x) __syncthreads();  // nobody reads the previous trip's flags any more
         if (PRUNE)
             for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
@@ -377,7 +401,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             if (g + 1 < n_grp) {  // loads fly while this group is walked
                 stage_of(g_nxt, tt_nxt);
                 Q_PF16(Q_PF_LOAD)
-            } else if (wg_next < n_wg) {
+            } else if (wg_next < n_wg && (HB >> 4) <= (CH == 4 ? 3 : 6) * THREADS) {
                 // last group of this tile: the next tile travels global -> VGPR during the walk
                 const int64_t cb = wg_next * C;
                 // (into the staging registers, which carry nothing during the last group: registers
@@ -388,8 +412,13 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #define Q_TILE_LOAD(q, half, j)                                                   \
     if ((j) * THREADS < upt && ((half) == 0 || two))                              \
         pf##q = src[(half) * upt + min(tid + (j) * THREADS, upt - 1)];
-                Q_TILE_LOAD(0, 0, 0) Q_TILE_LOAD(1, 0, 1) Q_TILE_LOAD(2, 0, 2)
-                Q_TILE_LOAD(3, 1, 0) Q_TILE_LOAD(4, 1, 1) Q_TILE_LOAD(5, 1, 2)
+                if (CH == 4) {  // two tiles of <= 3 x 1024 units
+                    Q_TILE_LOAD(0, 0, 0) Q_TILE_LOAD(1, 0, 1) Q_TILE_LOAD(2, 0, 2)
+                    Q_TILE_LOAD(3, 1, 0) Q_TILE_LOAD(4, 1, 1) Q_TILE_LOAD(5, 1, 2)
+                } else {  // one tile of <= 6 x 1024 units
+                    Q_TILE_LOAD(0, 0, 0) Q_TILE_LOAD(1, 0, 1) Q_TILE_LOAD(2, 0, 2)
+                    Q_TILE_LOAD(3, 0, 3) Q_TILE_LOAD(4, 0, 4) Q_TILE_LOAD(5, 0, 5)
+                }
 #undef Q_TILE_LOAD
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
@@ -505,8 +534,13 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #define Q_TILE_STORE(q, half, j)                                                                        \
     if ((j) * THREADS < upt && tid + (j) * THREADS < upt && ((half) == 0 || two))                       \
         *LDS_AT(lds_u4, (half) * HALF1 + ((tid + (j) * THREADS) << 4)) = pf##q;
-            Q_TILE_STORE(0, 0, 0) Q_TILE_STORE(1, 0, 1) Q_TILE_STORE(2, 0, 2)
-            Q_TILE_STORE(3, 1, 0) Q_TILE_STORE(4, 1, 1) Q_TILE_STORE(5, 1, 2)
+            if (CH == 4) {
+                Q_TILE_STORE(0, 0, 0) Q_TILE_STORE(1, 0, 1) Q_TILE_STORE(2, 0, 2)
+                Q_TILE_STORE(3, 1, 0) Q_TILE_STORE(4, 1, 1) Q_TILE_STORE(5, 1, 2)
+            } else {
+                Q_TILE_STORE(0, 0, 0) Q_TILE_STORE(1, 0, 1) Q_TILE_STORE(2, 0, 2)
+                Q_TILE_STORE(3, 0, 3) Q_TILE_STORE(4, 0, 4) Q_TILE_STORE(5, 0, 5)
+            }
 #undef Q_TILE_STORE
         }
     }
@@ -554,10 +588,13 @@ void pk_forest_q_release(pk_forest *f)
 static int q_plan_build(pk_forest *f)
 {
     const int F = f->F, T = f->T;
-    if (F > 255 || f->h_tree_off.empty()) return PK_E_UNSUPPORTED;
+    if (F > 1023 || f->h_tree_off.empty()) return PK_E_UNSUPPORTED;
     int ch = (int)g_opt.forest_q_ch;
-    if (ch == 0) ch = F <= 192 ? 4 : 2;  // two rank tiles of 256 B per feature fit 64 KiB of offsets
-    if (ch == 4 && F > 192) return PK_E_UNSUPPORTED;
+    // 256 candidates per workgroup while two rank tiles of 256 B per feature fit 64 KiB of
+    // offsets, 128 up to 255 features (the narrow word's feature byte), 64 candidates and the
+    // wide word beyond (w = 11: 529 features)
+    if (ch == 0) ch = F <= 192 ? 4 : F <= 255 ? 2 : 1;
+    if ((ch == 4 && F > 192) || (ch == 2 && F > 255)) return PK_E_UNSUPPORTED;
     // tables and trees once (they do not depend on the layout), then only the grouping
     // is tried for every slot count
     pk_q_out best;
@@ -728,7 +765,7 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
         if (split < 1) split = 1;
         hipLaunchKernelGGL(quantize_tiles_kernel, dim3((unsigned)F, (unsigned)split), dim3(256), 0,
                            ctx->stream, tiles, n_tiles, F, f->q_thr, f->q_off, f->q_lut, f->q_par,
-                           ctx->q_tiles);
+                           ctx->q_tiles, L.ch == 1 ? 1 : 0);
         PK_HIP(hipGetLastError());
     }
     pk_prof_scope prof(ctx, PK_K_FOREST);
@@ -755,6 +792,8 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
         else Q_LAUNCH(4, 1, 49152, false);
     } else if (L.ch == 2) {
         Q_LAUNCH(2, 1, 32768, false);
+    } else if (L.ch == 1) {
+        Q_LAUNCH(1, 1, 32768, false);
     } else {
         pk_set_error("forest rank kernel: layout not instantiated");
         return PK_E_INVALID;

@@ -66,10 +66,16 @@ struct q_tree {
 };
 
 // lays one tree out; pairs are appended to `out` (nullptr: only count).  Returns the
-// number of pairs, or -1 (malformed) / -2 (does not fit the 12-bit pair field).
+// number of pairs, or -1 (malformed) / -2 (does not fit the pair field).
+// Word formats (rank in bits 31..21 either way, so `code <= word >> 16` decides a split):
+//   narrow (<= 255 features): [20] NaN goes left | [19:8] pair index | [7:0] feature
+//   wide   (<= 1023 features): [20:10] pair index (trees of <= 2047 pairs) | [9:0] feature;
+//          no NaN bit -- a forest with missing_go_to_left nodes does not fit it
 int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> *out, uint32_t *root,
-                int *depth, std::string *err)
+                int *depth, std::string *err, bool wide)
 {
+    const int pair_shift = wide ? 10 : 8;
+    const int max_pairs = wide ? 2048 : 4096;
     const int nn = t.nn;
     std::vector<int> order, dep((size_t)nn, 0), stack;
     std::vector<uint8_t> seen((size_t)nn, 0);
@@ -137,16 +143,18 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
     for (int v = 0; v < nn; v++)
         if (seen[(size_t)v] && t.left[v] == -1) lblock[(size_t)v] = leaf_block(v);
     if (next & 1) next++;  // whole 16-byte units
-    if (next > 4096) return -2;
-    auto leaf_word = [](int block) { return Q_LEAF | ((uint32_t)block << 8); };
+    if (next > max_pairs) return -2;
+    auto leaf_word = [&](int block) {
+        return (wide ? (0x7FFu << 21) : Q_LEAF) | ((uint32_t)block << pair_shift);
+    };
     auto word_of = [&](int v) -> uint32_t {
         if (t.left[v] == -1) return leaf_word(lblock[(size_t)v]);
         const int f = t.feat[v];
         const float t32 = q_floor32(t.thr[v]);
         const float *b = tab.qthr.data() + tab.qoff[(size_t)f], *e = tab.qthr.data() + tab.qoff[(size_t)f + 1];
         const int k = (int)(std::lower_bound(b, e, t32) - b);  // t32 is in the table by construction
-        uint32_t w = ((uint32_t)k << 21) | ((uint32_t)pairi[(size_t)v] << 8) | (uint32_t)f;
-        if (t.miss && t.miss[v]) w |= 1u << 20;
+        uint32_t w = ((uint32_t)k << 21) | ((uint32_t)pairi[(size_t)v] << pair_shift) | (uint32_t)f;
+        if (!wide && t.miss && t.miss[v]) w |= 1u << 20;
         return w;
     };
     *root = word_of(0);
@@ -157,7 +165,8 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
     auto put_block = [&](int p, double v) {
         uint64_t b;
         memcpy(&b, &v, 8);
-        P[p] = make_uint2(leaf_word(p), 0);
+        // (wide word: no NaN-goes-left bit keeps a NaN code at the leaf, so both ways lead back to it)
+        P[p] = make_uint2(leaf_word(p), wide ? leaf_word(p) : 0);
         P[p + 1] = make_uint2((uint32_t)(b & 0xffffffffu), (uint32_t)(b >> 32));
     };
     put_block(0, 0.0);
@@ -184,13 +193,15 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
 //   [img_off, 163840)        the group's trees
 bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L)
 {
-    if (F < 1 || F > 255 || slots < 2 || slots > 16 || (ch != 2 && ch != 4)) return false;
+    if (F < 1 || slots < 2 || slots > 16 || (ch != 1 && ch != 2 && ch != 4)) return false;
+    if (F > (ch == 1 ? 1023 : 255)) return false;
     L->F = F;
     L->slots = slots;
     L->ch = ch;
     L->slot_bytes = 0;
     memset(L->slot_off, 0, sizeof(L->slot_off));
-    L->HB = F * 256;
+    // ch = 1: one 64-candidate tile [F][64] u16 (the wide node word, up to 1023 features)
+    L->HB = ch == 1 ? F * 128 : F * 256;
     const int C = 64 * ch;
     int top;
     L->half1 = 0;
@@ -262,7 +273,11 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
                const pk_q_layout &L, pk_q_out *out)
 {
     *out = pk_q_out();
-    if (T <= 0 || F < 1 || F > 255) return PK_E_UNSUPPORTED;
+    const bool wide = L.ch == 1;  // 64-candidate tiles: the 10-bit feature field
+    if (T <= 0 || F < 1 || F > (wide ? 1023 : 255)) return PK_E_UNSUPPORTED;
+    if (wide && miss)
+        for (int32_t v = tree_off[0]; v < tree_off[T]; v++)
+            if (miss[v] && left[v] != -1) return PK_E_UNSUPPORTED;  // no NaN-goes-left bit in the wide word
     // rank tables
     std::vector<std::vector<float>> per((size_t)F);
     for (int t = 0; t < T; t++)
@@ -319,7 +334,7 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
         }
         std::string err;
         const int np = q_emit_tree(tv, F, *out, &out->pairs, &out->troot[(size_t)t],
-                                   &out->tdepth[(size_t)t], &err);
+                                   &out->tdepth[(size_t)t], &err, wide);
         if (np == -1) {
             pk_set_error("forest rank image: tree %d: %s", t, err.c_str());
             return PK_E_INVALID;

@@ -93,6 +93,11 @@ def walk_qimage(img, codes, T):
     HB, ch_half1, dec_off, val_off, img_off, cap, slots, F, slot_bytes = [int(v) for v in img["lay"][:9]]
     slot_off = [int(v) for v in img["lay"][9:26]]   # slot_bytes > 0: fixed tree slots (early staging)
     ch, half1 = ch_half1 & 0xFF, ch_half1 >> 8
+    # ch = 1: 64-candidate tiles and the WIDE node word -- [20:10] pair index, [9:0] feature, no
+    # NaN-goes-left bit (a NaN code 0xFFFF is above every rank: it always goes right)
+    wide = ch == 1
+    fmask, pshift, pmask = (0x3FF, 10, 0x7FF) if wide else (0xFF, 8, 0xFFF)
+    assert HB == (F * 128 if wide else F * 256)
     N = codes.shape[0]
     acc = np.zeros(N, np.float64)
     assert img_off % 16 == 0 and img_off + cap <= LDS_BYTES
@@ -121,15 +126,17 @@ def walk_qimage(img, codes, T):
                     lds[tbase // 8 + 2 * u0: tbase // 8 + 2 * u1] = img["pairs"][src: src + 2 * (u1 - u0)]
             w = np.full(N, np.uint32(root & 0xFFFFFFFF), np.uint32)
             for _ in range(depth):
-                f = (w & 0xFF).astype(np.int64)
+                f = (w & fmask).astype(np.int64)
                 assert f.max() < F
                 xv = codes[np.arange(N), f].astype(np.uint32)
-                ca = tbase + ((w >> 8) & 0xFFF).astype(np.int64) * 8
+                ca = tbase + ((w >> pshift) & pmask).astype(np.int64) * 8
                 assert (ca + 8 <= (img_off + slot_off[t - t0 + 1] if slot_bytes else img_off + nu * 16)).all()
                 pr = lds[ca // 8]
-                gl = (xv <= (w >> 16)) | ((xv == 0xFFFF) & ((w >> 20) & 1 != 0))
+                gl = xv <= (w >> 16)
+                if not wide:
+                    gl = gl | ((xv == 0xFFFF) & ((w >> 20) & 1 != 0))
                 w = np.where(gl, pr & np.uint64(0xFFFFFFFF), pr >> np.uint64(32)).astype(np.uint32)
-            va = tbase + (((w >> 8) & 0xFFF).astype(np.int64) + 1) * 8
+            va = tbase + (((w >> pshift) & pmask).astype(np.int64) + 1) * 8
             acc += lds[va // 8].view(np.float64)  # tree order: sklearn's sequential sum
     return acc / float(T)
 
@@ -241,3 +248,58 @@ def test_rank_image_limits():
                miss_left=np.zeros(3, np.uint8), p1=np.zeros(3))
     rc, msg = build_qimage(bad, 4, 4, 2)
     assert rc != 0 and "malformed" in msg
+
+
+def _random_forest(F, T, nodes, depth, seed):
+    """Untrained random trees (bench.py's `random:T:depth` recipe in small)."""
+    rng = np.random.default_rng(seed)
+    offs, cols = [0], {k: [] for k in ("left", "right", "feat", "thr", "miss_left", "p1")}
+    for _ in range(T):
+        left, right, feat, thr, p1, dep = [-1], [-1], [-2], [-2.0], [0.0], [0]
+        frontier = [0]
+        while frontier and len(left) < nodes:
+            i = frontier.pop(int(rng.integers(0, len(frontier))))
+            if dep[i] >= depth:
+                continue
+            feat[i] = int(rng.integers(0, F))
+            thr[i] = float(rng.random())
+            for side in (left, right):
+                side[i] = len(left)
+                left.append(-1); right.append(-1); feat.append(-2); thr.append(-2.0)
+                p1.append(float(rng.integers(0, 2)) if rng.random() < 0.9 else float(rng.random()))
+                dep.append(dep[i] + 1)
+                frontier.append(len(left) - 1)
+        cols["left"].append(np.array(left, np.int32)); cols["right"].append(np.array(right, np.int32))
+        cols["feat"].append(np.array(feat, np.int32)); cols["thr"].append(np.array(thr, np.float64))
+        cols["miss_left"].append(np.zeros(len(left), np.uint8)); cols["p1"].append(np.array(p1, np.float64))
+        offs.append(offs[-1] + len(left))
+    fo = {k: np.concatenate(v) for k, v in cols.items()}
+    fo["tree_off"] = np.array(offs, np.int32)
+    return fo
+
+
+@pytest.mark.parametrize("F,slots", [(529, 7), (529, 16), (300, 5), (1023, 2)])
+def test_wide_word_forests(F, slots):
+    """More than 255 features (w = 11: 529): 64-candidate tiles and the wide node word."""
+    fo = _random_forest(F, 12, 900, 14, seed=F)
+    rc, img = build_qimage(fo, F, slots, 1)
+    assert rc == 0, img
+    rng = np.random.default_rng(F + 1)
+    X = rng.random((130, F)).astype(np.float32)
+    X[::9] = (X[::9] > 0.5).astype(np.float32)
+    thr32 = fo["thr"][fo["left"] != -1].astype(np.float32)
+    feats = fo["feat"][fo["left"] != -1]
+    for k in range(100):   # values exactly on thresholds and one ulp beside them
+        t = thr32[k * 7 % thr32.size]
+        X[20 + k, feats[k * 7 % thr32.size]] = [t, np.nextafter(t, np.float32(-np.inf)), np.nextafter(t, np.float32(np.inf))][k % 3]
+    X[3, 5] = np.nan
+    X[4, :] = np.nan
+    codes, _ = quantize(img, X)
+    p = walk_qimage(img, codes, 12)
+    assert np.array_equal(gio.bits(p), gio.bits(onp.predict(fo, X)))
+    # the narrow word cannot hold these features; missing_go_to_left does not fit the wide one
+    assert build_qimage(fo, F, 4, 2)[0] != 0
+    fo2 = dict(fo)
+    fo2["miss_left"] = fo["miss_left"].copy()
+    fo2["miss_left"][0] = 1
+    assert build_qimage(fo2, F, slots, 1)[0] != 0

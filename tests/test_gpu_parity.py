@@ -237,6 +237,49 @@ def test_forest_q_modes(hip_lib, name, opts):
     assert np.array_equal(gio.bits(p), gio.bits(ref))
 
 
+@pytest.mark.parametrize("opts", [{}, {"forest_slots": 5}, {"forest_q_persist": -2}, {"forest_q_prio": 0},
+                                  {"forest_q": 0}])
+@pytest.mark.parametrize("F,with_miss", [(529, False), (300, False), (529, True)])
+def test_forest_wide_format(hip_lib, F, with_miss, opts):
+    """More than 255 features (w = 11: 529): the rank kernel on 64-candidate tiles with the wide
+    node word (10-bit feature, 11-bit pair index) -- forests without missing_go_to_left nodes;
+    one with such nodes does not fit the word and takes the float kernels.  Rows with exact 0 / 1,
+    values on thresholds, NaN cells and all-NaN rows; bit-exact against the oracle."""
+    from test_forest_qimage import _random_forest
+    fo = _random_forest(F, 40, 1500, 16, seed=F + (7 if with_miss else 0))
+    if with_miss:
+        fo["miss_left"][::3] = 1
+    ff = FlatForest(F, *(fo[k] for k in FlatForest.FIELDS))
+    rng = np.random.default_rng(F)
+    X = rng.random((1301, F)).astype(np.float32)
+    X[::5] = (X[::5] > 0.5).astype(np.float32)
+    inner = np.flatnonzero(fo["left"] != -1)
+    for k in range(400):
+        j = inner[k * 13 % inner.size]
+        t = np.float32(fo["thr"][j])
+        X[100 + k, fo["feat"][j]] = (t, np.nextafter(t, np.float32(-np.inf)), np.nextafter(t, np.float32(np.inf)))[k % 3]
+    X[7, 3] = np.nan
+    X[300, :] = np.nan
+    X[1300, F - 1] = np.nan
+    ref = onp.predict(fo, X)
+    old = {k: _lib.load().pk_get_option(k.encode()) for k in opts}
+    try:
+        for k, v in opts.items():
+            _lib.set_option(k, v)
+        L = _lib.load()
+        L.pk_prof_enable(1)
+        L.pk_prof_reset()
+        p = _lib.HipForest(ff).predict(X)
+        quant_launches = _lib.prof_get("quant")[1]
+        L.pk_prof_enable(0)
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
+    assert np.array_equal(gio.bits(p), gio.bits(ref))
+    # the rank path (its quantizer) ran exactly when the forest fits the wide word
+    assert (quant_launches > 0) == (not with_miss and opts.get("forest_q", 1) != 0)
+
+
 def _g3_matrix(z):
     raw = gio.sym_matrix(z, "R")
     mode = str(z["mode"])
