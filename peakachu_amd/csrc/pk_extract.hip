@@ -886,6 +886,18 @@ __global__ void norm_band_kernel(const double *__restrict__ band, double *__rest
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int kk = blockIdx.y;
+    if (blockIdx.x == 0 && kk == 0) {
+        // EVERY expected value, not only those of the band's diagonals: a window cell beyond
+        // the band (the corner of a candidate at the largest distance reaches |k| = dhi + 1)
+        // is 0 / expected in the reference -- NaN if that expected value is 0 or NaN, -0 if it
+        // is negative -- where the clean extractor takes a plain +0
+        int bad_e = 0;
+        for (int i = threadIdx.x; i < exp_len; i += blockDim.x) {
+            const double e = exp_arr[i];
+            if (!(e > 0.0) || !(e < 1e300)) bad_e = 1;
+        }
+        if (__any(bad_e) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+    }
     if (r >= ld || kk >= ndiag) return;
     const int k = kk + dlo;
     const double raw = band[(int64_t)kk * ld + r];

@@ -647,6 +647,37 @@ def test_randomised_score_vs_oracle(hip_lib, seed):
     assert np.array_equal(gio.bits(osig), gio.bits(rs))
 
 
+@pytest.mark.parametrize("w", [5, 6])
+@pytest.mark.parametrize("bad", [0.0, float("nan"), -1.0])
+def test_expected_value_beyond_the_band(hip_lib, w, bad):
+    """Found by tools/fuzz_score.py: the corner cell of a candidate at the largest distance lies
+    at |col - row| = upper + 2w, one diagonal beyond the band (scoreUtils.py:30 filters with a
+    strict <).  The reference divides that (zero) cell by the expected value all the same:
+    0 / 0 = NaN, 0 / -1 = -0.  The pre-divided-band extractor takes a plain +0 there, so a
+    matrix whose LAST expected value is not positive and finite must go to the general
+    extractor, although no stored diagonal uses that value."""
+    n, band, upper = 400, 60, 40
+    M, _ = synth.synth_band(n, band, seed=3, loops=6)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True).copy()
+    e[-1] = bad
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, upper - 1, upper)   # the two largest distances
+    fo = random_forest_arrays((2 * w + 1) ** 2, 9, 5, depth=6)
+    hm = hip_matrix(Mf, e, w, upper)
+    hf = _lib.HipForest(flat(fo))
+    ox, oy, op, osig = hm.score(hf, w, 0.0, x, y)
+    rx, ry, rp, rs = onp.score(Mf, e, w, fo, 0.0, x, y)
+    assert np.array_equal(ox, rx) and np.array_equal(oy, ry) and rx.size > 100
+    assert np.array_equal(gio.bits(op), gio.bits(rp))
+    f64, _, keep = hm.extract(w, x, y)
+    ref, rkeep = onp.extract(Mf, e, w, x, y)
+    assert np.array_equal(keep, rkeep)
+    same = (gio.bits(f64) == gio.bits(ref)) | (np.isnan(f64) & np.isnan(ref))
+    assert same.all()
+    if bad != bad or bad == 0.0:
+        assert np.isnan(ref[(y - x)[rkeep] == upper]).all()   # every d = upper window turns NaN
+
+
 @pytest.mark.parametrize("mode", ["raw", "weights", "separate_raw"])
 def test_candidates_on_device_match_scipy(hip_lib, mode):
     """get_candidate on the device (tables made with scipy) against the host
