@@ -34,8 +34,8 @@ def main():
     npix = ncand = 0
     for seed in range(first, first + n_cases):
         rng = np.random.default_rng(seed)
-        w = int(rng.choice([5, 5, 6, 3, 4]))
-        n = int(rng.integers(12 * w + 60, 420))
+        w = int(rng.choice([5, 5, 6, 3, 4, 7, 11]))
+        n = int(rng.integers(12 * w + 60, 12 * w + 360))
         band = int(rng.integers(4 * w + 12, min(90, n // 2)))
         upper = int(rng.choice([band - 2 * w - 1, band, band + 30, n]))
         lower = int(rng.choice([1, 6, w + 3]))
@@ -84,11 +84,30 @@ def main():
         o = np.lexsort((oy, ox))
         ok_s = (np.array_equal(ox[o], ref["ri"]) and np.array_equal(oy[o], ref["ci"])
                 and np.array_equal(bits(op[o]), bits(ref["prob"])) and np.array_equal(bits(osig[o]), bits(ref["signal"])))
+        # ---- getwindow itself on arbitrary upper-triangle coordinates (not only candidates):
+        # float64 features and the list of coordinates that survive the filters
+        k = 300
+        gx = rng.integers(0, n - 1, k)
+        gy = np.minimum(gx + rng.integers(0, up + 3, k), n - 1)
+        ch2 = mg.make_chrom(M, rf, w, lower=lower, upper=upper, weights=weights,
+                            raw_M=(raw if mode != "raw" else None), cname="chr1")
+        fea_ref, clist = ch2.getwindow(list(zip(gx.tolist(), gy.tolist())))
+        fea_ref = np.asarray(fea_ref, np.float64).reshape(-1, F)
+        fea_o, keep = onp.extract(Mf, e, w, gx, gy)
+        clist = np.asarray(clist, np.int64).reshape(-1, 2)
+        ok_g = (np.array_equal(clist[:, 0], gx[keep]) and np.array_equal(clist[:, 1], gy[keep])
+                and fea_ref.shape == fea_o.shape
+                and bool(((bits(fea_ref) == bits(fea_o)) | (np.isnan(fea_ref) & np.isnan(fea_o))).all()))
+        if not ok_g:
+            print("   getwindow MISMATCH: kept", clist.shape[0], keep.size)
+            sys.exit(1)
+        nwin = clist.shape[0]
         npix += int(ref["ri"].size)
         ncand += int(len(cx))
         print("seed %4d w=%d n=%3d band=%2d lower=%2d upper=%3d %-7s trees=%2d thre=%.1f cands=%5d scored=%5d: exp %s band %s cands %s score %s" % (
             seed, w, n, band, lower, upper, mode, len(rf.estimators_), thre, len(cx), ref["ri"].size,
-            "ok" if ok_e else "MISMATCH", "ok" if ok_b else "MISMATCH", "ok" if ok_c else "MISMATCH", "ok" if ok_s else "MISMATCH"))
+            "ok" if ok_e else "MISMATCH", "ok" if ok_b else "MISMATCH", "ok" if ok_c else "MISMATCH", "ok" if ok_s else "MISMATCH"),
+              "getwindow %d/%d ok" % (nwin, k))
         sys.stdout.flush()
         if not (ok_e and ok_b and ok_c and ok_s):
             sys.exit(1)
