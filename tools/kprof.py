@@ -13,6 +13,11 @@ fo = FlatForest.load("peakachu_amd/data/forest_w%d_t100.npz" % w)
 L = _lib.require_device()
 hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -2 * w + 1, upper + 2 * w - 1)
 hf = _lib.HipForest(fo)
+xb = int(os.environ.get("PK_XBLOCK", "0"))
+if xb:  # experiment: candidates tiled by x-range (x-block major, then diagonal, then x)
+    import numpy as np
+    o = np.lexsort((x, y - x, x // xb))
+    x, y = x[o].copy(), y[o].copy()
 cd = _lib.HipCands(x, y)
 for opts in (sys.argv[1:] or [""]):
     old = {}
