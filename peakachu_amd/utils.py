@@ -97,14 +97,82 @@ def calculate_expected(M, maxdis, raw=False, device=None):
     return isotonic_expected(exp_arr)
 
 
+def _pava_increasing(y):
+    """Pool-adjacent-violators on float64 `y` with unit weights, in place: the steps and the
+    arithmetic of scikit-learn's `_inplace_contiguous_isotonic_regression` (block sums grow
+    term by term from the left, a block's value is sum / count, backtrack after every merge)."""
+    n = y.size
+    w = np.ones(n, np.float64)
+    target = np.arange(n)
+    i = 0
+    while i < n:
+        k = target[i] + 1
+        if k == n:
+            break
+        if y[i] < y[k]:
+            i = k
+            continue
+        sum_wy = w[i] * y[i]
+        sum_w = w[i]
+        while True:
+            prev_y = y[k]
+            sum_wy += w[k] * y[k]
+            sum_w += w[k]
+            k = target[k] + 1
+            if k == n or prev_y < y[k]:
+                y[i] = sum_wy / sum_w
+                w[i] = sum_w
+                target[i] = k - 1
+                target[k - 1] = i
+                if i > 0:
+                    i = target[i - 1]
+                break
+    i = 0
+    while i < n:
+        k = target[i] + 1
+        y[i + 1:k] = y[i]
+        i = k
+    return y
+
+
 def isotonic_expected(exp_arr):
-    """peakachu/utils.py:173-178: non-increasing isotonic fit through the positive
-    diagonal means, evaluated at every distance (tiny: <= upper + 2w + 1 points)."""
-    from sklearn.isotonic import IsotonicRegression
+    """peakachu/utils.py:173-178: `IsotonicRegression(increasing=False, out_of_bounds='clip')`
+    fitted through the positive diagonal means and evaluated at every distance (tiny: <=
+    upper + 2w + 1 points).  The fit's last bits depend on the installation: scikit-learn up
+    to 1.3 (the reference's pin is 1.1.2) pools with its own Cython PAVA, later releases hand
+    the job to scipy >= 1.12's, which sums in another order.  So, like the reference, this
+    calls the scikit-learn that is installed; without scikit-learn the restatement of the
+    pinned-era algorithm below is used."""
+    try:
+        from sklearn.isotonic import IsotonicRegression
+    except ImportError:
+        return isotonic_expected_restated(exp_arr)
     IR = IsotonicRegression(increasing=False, out_of_bounds="clip")
     _d = np.where(exp_arr > 0)[0]
     IR.fit(_d, exp_arr[_d])
     return IR.predict(list(range(exp_arr.size)))
+
+
+def isotonic_expected_restated(exp_arr):
+    """The same without scikit-learn, as scikit-learn <= 1.3 computes it (bit for bit:
+    tests/test_host_golden.py against the Cython routine itself and against curves fitted by
+    scikit-learn 0.24.2):
+      * a decreasing fit = the increasing PAVA on the reversed sequence;
+      * fit() drops every point whose value equals both neighbours' (flat interior);
+      * predict() clips the abscissae to the fitted range and interpolates linearly --
+        scipy's interp1d hands float64 data to numpy.interp, which is called here directly."""
+    exp_arr = np.asarray(exp_arr, np.float64)
+    d = np.flatnonzero(exp_arr > 0)
+    if d.size == 0:
+        raise ValueError("Found array with 0 sample(s) (shape=(0,)) while a minimum of 1 is required.")
+    x = d.astype(np.float64)
+    y = _pava_increasing(exp_arr[d][::-1].copy())[::-1].copy()
+    t = np.clip(np.arange(exp_arr.size, dtype=np.float64), x[0], x[-1])
+    if y.size == 1:
+        return np.repeat(y, t.size)
+    keep = np.ones(y.size, bool)
+    keep[1:-1] = (y[1:-1] != y[:-2]) | (y[1:-1] != y[2:])
+    return np.interp(t, x[keep], y[keep])
 
 
 def _diagonal_means_device(M, keep, n, top, valid_cols, device):
