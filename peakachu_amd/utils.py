@@ -62,8 +62,6 @@ def calculate_expected(M, maxdis, raw=False, device=None):
     dense diagonals built on the device, summed in numpy's own order, so they are
     bit-identical to the host path below); validity flags and the isotonic fit
     stay on the host."""
-    from sklearn.isotonic import IsotonicRegression
-
     M = canonical_csr(M)
     n = M.shape[0]
     indices = M.indices.astype(np.int32, copy=False)

@@ -192,3 +192,35 @@ def test_isotonic_fit_without_sklearn():
         assert got.dtype == np.float64 and np.array_equal(got.view(np.uint64), want.view(np.uint64)), k
     with pytest.raises(ValueError):
         utils.isotonic_expected_restated(np.zeros(5))
+
+
+def test_host_side_runs_without_sklearn_joblib_cooler_h5py(tmp_path):
+    """The host side of the scoring path in an interpreter where scikit-learn, joblib, cooler
+    and h5py cannot be imported: the expected curve, a pickled model (written by scikit-learn
+    0.24.2) and a .cool contact map are all handled with numpy / scipy alone."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        class Block:
+            def find_spec(self, name, path=None, target=None):
+                if name.split(".")[0] in ("sklearn", "joblib", "cooler", "h5py"):
+                    raise ImportError("blocked for this test: " + name)
+        sys.meta_path.insert(0, Block())
+        import numpy as np
+        sys.path.insert(0, %r)
+        from peakachu_amd import io, utils, synth
+        from peakachu_amd.forest import load_model
+        M, _ = synth.synth_band(300, 60, seed=1)
+        e = utils.calculate_expected(M, 50, raw=True)
+        assert e.shape == (51,) and np.all(np.diff(e) <= 0) and np.all(e > 0)
+        ff = load_model(%r)
+        assert ff.T == 12 and ff.F == 121
+        lib = io.open_map(%r)
+        assert type(lib).__name__ == "CoolFile" and lib.chromnames == ["chr1", "chr2", "chrX"]
+        assert lib.matrix(balance="weight", sparse=True).fetch("chr2").shape == (200, 200)
+        assert not any(m.split(".")[0] in ("sklearn", "joblib", "cooler", "h5py") for m in sys.modules)
+        print("ok")
+    """) % (root, os.path.join(gio.GOLD, "old_sklearn_rf_plain.xz.joblib"), os.path.join(gio.GOLD, "cool_small.cool"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
