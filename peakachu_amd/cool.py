@@ -11,7 +11,8 @@ What `matrix(...).fetch(chrom)` returns is restated from cooler's `api.matrix` (
 branch): the upper-triangle pixels whose two bins lie in the chromosome, mirrored below the
 diagonal (`query_rect(..., duplex=True)`), as a COO matrix of the chromosome's size; with
 `balance` the data become `bias[row] * bias[col] * count` -- the two weights are multiplied
-first, so the matrix is exactly symmetric -- and are NaN where a weight is NaN.  cooler is
+first, so the matrix is exactly symmetric -- and are NaN where a weight is NaN; columns named
+KR, VC or SQRT_VC (hic2cool's) are divisive: `count / (bias[row] * bias[col])`.  cooler is
 not installed in the build image: the restatement is pinned against files written by the
 genuine HDF5 library in cooler's layout (tools/make_cool_fixture.py), not against cooler.
 """
@@ -87,6 +88,15 @@ class CoolFile:
                              "balancing weights or set balance=False." % name)  # cooler's message
         return np.asarray(bins[name][lo:hi], np.float64)
 
+    def _divisive(self, name):
+        """cooler: "weights are always assumed to be multiplicative by default unless named KR,
+        VC or SQRT_VC, in which case they are assumed to be divisive" (the columns hic2cool
+        copies from a .hic file); a `divisive_weights` attribute on the column decides otherwise."""
+        attr = self._g["bins"][name].attrs.get("divisive_weights")
+        if attr is not None:
+            return bool(attr)
+        return name in ("KR", "VC", "SQRT_VC")
+
     # -- the reference's three calls
     def matrix(self, balance=True, sparse=True):
         if not sparse:
@@ -112,7 +122,10 @@ class CoolFile:
             data = np.concatenate([v, v[off_diag]])
             if name:
                 w = self._weights(name, lo, hi)
-                data = w[row] * w[col] * data
+                if self._divisive(name):
+                    data = data / (w[row] * w[col])
+                else:
+                    data = w[row] * w[col] * data
             return sparse_coo(data, row, col, n)
         return _Selector(fetch)
 

@@ -50,6 +50,7 @@ def test_coolfile_serves_what_cooler_serves(uri):
     for name in c.chromnames:
         n = int(z[name + "/n"])
         assert c.chrom_bins(name) == n == io.chrom_bins(c, name)
+        # ("KR" is divisive by its name, as in cooler: count / (bias_i * bias_j))
         for tag, bal in (("raw", False), ("weight", "weight"), ("KR", "KR"), ("weight", True)):
             M = c.matrix(balance=bal, sparse=True).fetch(name)
             assert M.shape == (n, n) and sparse.isspmatrix_coo(M)
@@ -61,12 +62,18 @@ def test_coolfile_serves_what_cooler_serves(uri):
             assert np.array_equal(A.data.view(np.uint64), z["%s/%s/data" % (name, tag)].view(np.uint64))
             if bal is not False:  # the two weights are multiplied first: exactly symmetric, NaN where a weight is
                 assert (abs(A - A.T) > 0).nnz == 0 or np.isnan(A.data).any()
+        # the divisive_weights attribute of a column overrides the default its name implies
+        for tag, bal in (("KR", "DIV"), ("weight", "VC")):
+            M = c.matrix(balance=bal, sparse=True).fetch(name)
+            A = sparse.csr_matrix((M.data, (M.row, M.col)), shape=M.shape)
+            A.sort_indices()
+            assert np.array_equal(A.data.view(np.uint64), z["%s/%s/data" % (name, tag)].view(np.uint64))
         for col in ("weight", "KR"):
             assert np.array_equal(c.bins().fetch(name)[col].values, z[name + "/" + col], equal_nan=True)
     with pytest.raises(ValueError, match="Unknown sequence label"):
         c.matrix(balance=False, sparse=True).fetch("chr9")
-    with pytest.raises(ValueError, match="No column 'bins/VC'"):
-        c.matrix(balance="VC", sparse=True).fetch("chr1")
+    with pytest.raises(ValueError, match="No column 'bins/ICE'"):
+        c.matrix(balance="ICE", sparse=True).fetch("chr1")
     c.close()
 
 

@@ -93,7 +93,7 @@ def make(out, n):
             i, j, v = b1[m] - lo, b2[m] - lo, cnt[m]
             nbin = hi - lo
             for tag, w in (("raw", None), ("weight", weight[lo:hi]), ("KR", kr[lo:hi])):
-                vv = v if w is None else w[i] * w[j] * v
+                vv = v if w is None else (v / (w[i] * w[j]) if tag == "KR" else w[i] * w[j] * v)
                 od = i != j
                 rows = np.concatenate([i, j[od]]); cols = np.concatenate([j, i[od]]); vals = np.concatenate([vv, vv[od]])
                 oo = np.lexsort((cols, rows))

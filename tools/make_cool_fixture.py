@@ -62,6 +62,10 @@ def write_cool(grp, bs, scale=1):
     d.attrs["ignore_diags"] = 2
     d.attrs["converged"] = True
     g.create_dataset("KR", data=kr, chunks=(min(N, 512),), **kw)
+    d = g.create_dataset("DIV", data=kr, chunks=(min(N, 512),), **kw)   # divisive by attribute, not by name
+    d.attrs["divisive_weights"] = True
+    d = g.create_dataset("VC", data=weight, chunks=(min(N, 512),), **kw)  # multiplicative although named VC
+    d.attrs["divisive_weights"] = False
     g = grp.create_group("pixels")
     g.create_dataset("bin1_id", data=b1, chunks=(4096,), maxshape=(None,), **kw)
     g.create_dataset("bin2_id", data=b2, chunks=(4096,), maxshape=(None,), **kw)
@@ -103,7 +107,8 @@ for c, (name, _) in enumerate(chroms):
     for tag, w in (("raw", None), ("weight", weight[lo:hi]), ("KR", kr[lo:hi])):
         # cooler.api.matrix: `mat.data = bias1[mat.row] * bias2[mat.col] * mat.data` -- the two
         # weights are multiplied first, so the mirrored entry gets the identical value
-        vv = v if w is None else w[i] * w[j] * v
+        # columns named KR / VC / SQRT_VC are divisive in cooler: count / (bias_i * bias_j)
+        vv = v if w is None else (v / (w[i] * w[j]) if tag == "KR" else w[i] * w[j] * v)
         offd = i != j
         rows = np.concatenate([i, j[offd]]); cols = np.concatenate([j, i[offd]]); vals = np.concatenate([vv, vv[offd]])
         o = np.lexsort((cols, rows))
