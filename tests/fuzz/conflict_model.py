@@ -6,7 +6,7 @@ its distinct pairs fall into distinct 8-byte bank pairs = index mod 32).
 Cost of a half = max over the 32 bank pairs of the number of DISTINCT pair indices."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from oracle import oracle_np
 from peakachu_amd.forest import FlatForest

@@ -5,10 +5,10 @@ of the reference's constructor (peakachu/scoreUtils.py:10-68: utils.calculate_ex
 host, utils.band_filter, utils.candidates with scipy per pixel) and the oracle's score.
 Raw / balanced (NaN weights) / hic-style (raw_M separate, non-integer M) modes, thin and dense
 maps, empty far diagonals, NaN / inf cells, tiny chromosomes, upper beyond the matrix.
-usage: tools/fuzz_chromosome.py [n_cases] [seed]"""
+usage: tests/fuzz/fuzz_chromosome.py [n_cases] [seed]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from scipy import sparse

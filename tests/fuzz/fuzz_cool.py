@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """`.cool` reader fuzz, two stages (build container only):
-  1. /opt/conda/bin/python3.9 tools/fuzz_cool.py make <dir> [n]  -- h5py 3.3 / libhdf5 1.10.6 write
+  1. /opt/conda/bin/python3.9 tests/fuzz/fuzz_cool.py make <dir> [n]  -- h5py 3.3 / libhdf5 1.10.6 write
      n random coolers (1-6 chromosomes incl. empty ones, 1-3000 bins, random chunk sizes,
      gzip levels / no compression / shuffle on-off, int32 / int64 / float64 counts, int8 /
      int32 enum base, libver earliest / latest, nested mcool groups, extra weight columns) and
      the matrices cooler's matrix(balance, sparse=True).fetch(chrom) would return;
-  2. python tools/fuzz_cool.py check <dir>  -- peakachu_amd.cool.CoolFile (pure Python) must
+  2. python tests/fuzz/fuzz_cool.py check <dir>  -- peakachu_amd.cool.CoolFile (pure Python) must
      return them bit for bit."""
 import os, sys
 import numpy as np
@@ -107,7 +107,7 @@ def make(out, n):
 
 
 def check(out):
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from peakachu_amd import cool, h5lite
     names = sorted(f[:-4] for f in os.listdir(out) if f.endswith(".npz"))
     nmat = refused = 0

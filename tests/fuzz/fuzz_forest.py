@@ -4,10 +4,10 @@ oracle, bit for bit.  Shapes: 1 .. 1100 features (narrow word, wide word, too ma
 either), stumps to depth-40 combs, 1 .. 300 trees, trees too large for the pair field, more
 than 2047 thresholds on one feature, missing_go_to_left nodes, NaN / inf / exact-threshold
 inputs, 1 .. 70 000 rows (partial workgroups, persistent launches).
-usage: tools/fuzz_forest.py [n_cases] [seed]"""
+usage: tests/fuzz/fuzz_forest.py [n_cases] [seed]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle_np as onp
 from peakachu_amd import _lib
 from peakachu_amd.forest import FlatForest

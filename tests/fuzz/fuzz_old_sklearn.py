@@ -1,10 +1,10 @@
 #!/usr/bin/env python
 """Model-file ingestion fuzz, two stages (build container only):
-  1. /opt/conda/bin/python3.9 tools/fuzz_old_sklearn.py make <dir> [n]   -- scikit-learn 0.24.2 +
+  1. /opt/conda/bin/python3.9 tests/fuzz/fuzz_old_sklearn.py make <dir> [n]   -- scikit-learn 0.24.2 +
      joblib 1.1.0 fit n random forests (criteria, class weights, depths, leaf sizes, bootstrap
      on/off, few or many features) and dump each with a random joblib compression / pickle
      protocol, next to that scikit-learn's own predict_proba[:, 1] on random inputs;
-  2. python tools/fuzz_old_sklearn.py check <dir>   -- the system interpreter (no access to
+  2. python tests/fuzz/fuzz_old_sklearn.py check <dir>   -- the system interpreter (no access to
      that scikit-learn) reads every file with peakachu_amd.sk_pickle and walks it with the
      oracle: bit-identical probabilities required."""
 import os, sys
@@ -56,7 +56,7 @@ def make(out, n):
 
 
 def check(out):
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from oracle import oracle_np as onp
     from peakachu_amd.forest import FlatForest, load_model
     names = sorted(f[:-4] for f in os.listdir(out) if f.endswith(".npz"))

@@ -3,9 +3,9 @@
 call_loops.main against peakachu_amd.call_loops.main on many synthetic scored-pixel files
 (blobs, stripes, isolated pixels, exact ties; tools/make_golden.py's generator), thresholds and
 resolutions.  The two output files must be byte-identical.
-usage: tools/fuzz_pool.py [n_seeds] [first_seed]"""
+usage: tests/fuzz/fuzz_pool.py [n_seeds] [first_seed]"""
 import argparse, os, sys, tempfile, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import make_golden  # sets up the reference import (identity numba.njit) and sys.path
 from peakachu import call_loops as ref_pool

@@ -10,10 +10,10 @@ One known caveat (tools/make_golden.py): with numba absent the reference's windo
 is numpy's pairwise sum, production numba's is sequential (the oracle's order); a pixel whose
 centre / mean ratio sits within an ulp of 0.1 could differ.  Such a case is reported, not
 hidden; none has occurred.
-usage: tools/fuzz_reference.py [n_cases] [first_seed]"""
+usage: tests/fuzz/fuzz_reference.py [n_cases] [first_seed]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import make_golden as mg  # sets up the reference import (identity numba.njit)
 from scipy import sparse

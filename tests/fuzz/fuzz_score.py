@@ -4,10 +4,10 @@ rule) on seeded random inputs against the CPU oracle, bit for bit -- the shapes 
 tests/test_gpu_parity.py::test_randomised_score_vs_oracle, many more of them, plus matrices
 the fast extractor must hand to the general one (NaN / negative / tiny / huge cells, a zero
 or NaN in the expected curve) and random library options.
-usage: tools/fuzz_score.py [n_cases] [seed]"""
+usage: tests/fuzz/fuzz_score.py [n_cases] [seed]"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from scipy import sparse

@@ -650,7 +650,7 @@ def test_randomised_score_vs_oracle(hip_lib, seed):
 @pytest.mark.parametrize("w", [5, 6])
 @pytest.mark.parametrize("bad", [0.0, float("nan"), -1.0])
 def test_expected_value_beyond_the_band(hip_lib, w, bad):
-    """Found by tools/fuzz_score.py: the corner cell of a candidate at the largest distance lies
+    """Found by tests/fuzz/fuzz_score.py: the corner cell of a candidate at the largest distance lies
     at |col - row| = upper + 2w, one diagonal beyond the band (scoreUtils.py:30 filters with a
     strict <).  The reference divides that (zero) cell by the expected value all the same:
     0 / 0 = NaN, 0 / -1 = -0.  The pre-divided-band extractor takes a plain +0 there, so a
