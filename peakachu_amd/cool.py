@@ -62,6 +62,7 @@ class CoolFile:
         self.chromsizes = dict(zip(self.chromnames, (int(v) for v in self._g["chroms/length"].read())))
         self._chrom_offset = self._g["indexes/chrom_offset"].read().astype(np.int64)
         self._bin1_offset = None
+        self._last_pixels = (None, None)
         self.binsize = a.get("bin-size")
         if not isinstance(self.binsize, int):
             st, en = self._g["bins/start"][0:1], self._g["bins/end"][0:1]
@@ -97,6 +98,28 @@ class CoolFile:
             return bool(attr)
         return name in ("KR", "VC", "SQRT_VC")
 
+    def _mirrored(self, chrom, lo, hi):
+        """(row, col, count) of the chromosome's symmetric matrix.  The scoring drivers fetch a
+        chromosome twice in balanced mode (balanced values, then raw counts): the pixels are
+        read and inflated once."""
+        if self._last_pixels[0] == chrom:
+            return self._last_pixels[1]
+        n = hi - lo
+        if self._bin1_offset is None:
+            self._bin1_offset = self._g["indexes/bin1_offset"].read().astype(np.int64)
+        off = self._bin1_offset[lo:hi + 1]
+        p0, p1 = int(off[0]), int(off[-1])
+        # pixels are sorted by (bin1, bin2): bin1 follows from the index, no need to read it
+        i = np.repeat(np.arange(n, dtype=np.int64), np.diff(off))
+        j = self._g["pixels/bin2_id"][p0:p1].astype(np.int64) - lo
+        v = self._g["pixels/count"][p0:p1]
+        cis = j < n  # bin2 >= bin1 >= lo always; drop the trans pixels
+        i, j, v = i[cis], j[cis], v[cis]
+        off_diag = i != j
+        out = (np.concatenate([i, j[off_diag]]), np.concatenate([j, i[off_diag]]), np.concatenate([v, v[off_diag]]))
+        self._last_pixels = (chrom, out)
+        return out
+
     # -- the reference's three calls
     def matrix(self, balance=True, sparse=True):
         if not sparse:
@@ -106,27 +129,16 @@ class CoolFile:
         def fetch(chrom):
             lo, hi = self.extent(chrom)
             n = hi - lo
-            if self._bin1_offset is None:
-                self._bin1_offset = self._g["indexes/bin1_offset"].read().astype(np.int64)
-            off = self._bin1_offset[lo:hi + 1]
-            p0, p1 = int(off[0]), int(off[-1])
-            # pixels are sorted by (bin1, bin2): bin1 follows from the index, no need to read it
-            i = np.repeat(np.arange(n, dtype=np.int64), np.diff(off))
-            j = self._g["pixels/bin2_id"][p0:p1].astype(np.int64) - lo
-            v = self._g["pixels/count"][p0:p1]
-            cis = j < n  # bin2 >= bin1 >= lo always; drop the trans pixels
-            i, j, v = i[cis], j[cis], v[cis]
-            off_diag = i != j
-            row = np.concatenate([i, j[off_diag]])
-            col = np.concatenate([j, i[off_diag]])
-            data = np.concatenate([v, v[off_diag]])
+            row, col, data = self._mirrored(chrom, lo, hi)
             if name:
                 w = self._weights(name, lo, hi)
                 if self._divisive(name):
                     data = data / (w[row] * w[col])
                 else:
                     data = w[row] * w[col] * data
-            return sparse_coo(data, row, col, n)
+            else:
+                data = data.copy()  # (the cached arrays stay ours)
+            return sparse_coo(data, row.copy(), col.copy(), n)
         return _Selector(fetch)
 
     def bins(self):
