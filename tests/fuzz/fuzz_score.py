@@ -30,7 +30,7 @@ def main():
         band = int(rng.integers(4 * w + 10, min(200, n // 2)))
         upper = int(rng.integers(2 * w + 4, band))
         M, _ = synth.synth_band(n, band, seed=seed, loops=max(2, n // 30))
-        kind = int(rng.integers(0, 6))
+        kind = int(rng.integers(0, 9))
         raw = True
         if kind == 1:   # balanced, non-integer values with NaN weights
             M = synth.balance(M, synth.synth_weights(n, seed, n_nan=3))
@@ -43,7 +43,21 @@ def main():
             M.data[idx[6:9]] = 1e-120
             M.data[idx[9:]] = 1e160
             raw = False
+        if kind == 6:   # flat windows: equal counts everywhere (min-max scaling -> 0 / 0 -> NaN features)
+            M.data[:] = float(rng.choice([1.0, 3.0, 0.5]))
+            raw = False
+        if kind == 7:   # cells exactly on the limits the fast extractor's precondition tests
+            idx = rng.choice(M.data.size, 8, replace=False)
+            M.data[idx] = rng.choice([1e-100, 9.99e-101, 1e150, 9.9e149, 5e-324, 1.7e308], 8)
+            raw = False
+        if kind == 8:   # negative zeros and a few exact zeros stored explicitly
+            idx = rng.choice(M.data.size, 10, replace=False)
+            M.data[idx[:5]] = -0.0
+            M.data[idx[5:]] = 0.0
+            raw = False
         e = utils.calculate_expected(M, upper + 2 * w, raw=raw)
+        if kind == 6:
+            e = e[: max(3, int(rng.integers(3, e.size)))].copy()   # most windows stay unnormalised: truly flat
         if kind == 3:
             e = e.copy(); e[int(rng.integers(0, e.size))] = 0.0
         if kind == 4:
