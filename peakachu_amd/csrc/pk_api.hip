@@ -1065,12 +1065,20 @@ extern "C" int pk_cands_fetch(pk_cands *cd, int32_t *x, int32_t *y)
 // requires 0 <= x <= y < n, for which neither can happen.
 static int check_coords(const char *who, int32_t n, int64_t N, const int32_t *x, const int32_t *y)
 {
-    for (int64_t i = 0; i < N; i++)
-        if (x[i] < 0 || y[i] < x[i] || y[i] >= n) {
-            pk_set_error("%s: coordinate %lld = (%d, %d) violates 0 <= x <= y < n=%d", who,
-                         (long long)i, x[i], y[i], n);
-            return PK_E_INVALID;
-        }
+    // (block-wise and branch-free so that the compiler vectorises it: this runs over millions of
+    // coordinates on the host inside pk_score's timed path)
+    for (int64_t b = 0; b < N; b += 8192) {
+        const int64_t e = b + 8192 < N ? b + 8192 : N;
+        int bad = 0;
+        for (int64_t i = b; i < e; i++) bad |= (x[i] < 0) | (y[i] < x[i]) | (y[i] >= n);
+        if (bad)
+            for (int64_t i = b; i < e; i++)
+                if (x[i] < 0 || y[i] < x[i] || y[i] >= n) {
+                    pk_set_error("%s: coordinate %lld = (%d, %d) violates 0 <= x <= y < n=%d", who,
+                                 (long long)i, x[i], y[i], n);
+                    return PK_E_INVALID;
+                }
+    }
     return PK_OK;
 }
 
@@ -1103,6 +1111,20 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         PK_HIP(hipEventRecord(ctx->ev_for[0], ctx->stream));
         PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[0], 0));
     }
+    // pk_score hands host coordinates over: the upload of chunk k + 1 (second stream; the host
+    // blocks in the copy while the device scores chunk k) overlaps the kernels of chunk k
+    const bool stream_coords = cd->h_x != nullptr && !overlap;
+    auto upload = [&](int64_t c0) -> int {
+        const int64_t cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
+        PK_HIP(hipMemcpyAsync(cd->x + c0, cd->h_x + c0, (size_t)cn * 4, hipMemcpyHostToDevice, ctx->stream2));
+        PK_HIP(hipMemcpyAsync(cd->y + c0, cd->h_y + c0, (size_t)cn * 4, hipMemcpyHostToDevice, ctx->stream2));
+        PK_HIP(hipEventRecord(ctx->ev_ext[(c0 / chunk) & 1], ctx->stream2));
+        return PK_OK;
+    };
+    if (stream_coords) {
+        rc = upload(0);
+        if (rc) return rc;
+    }
     int64_t k = 0;
     for (int64_t c0 = 0; c0 < cd->N; c0 += chunk, k++) {
         const int64_t cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
@@ -1110,6 +1132,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         float *tiles = ctx->fea_tiles + (size_t)buf * tile_floats;
         if (overlap && k >= 2)  // forest(k-2) must be done with this buffer
             PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[buf], 0));
+        if (stream_coords) PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[k & 1], 0));
         rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0, cn, tiles, blk, cd->status,
                                nullptr);
         if (rc) return rc;
@@ -1120,6 +1143,10 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         rc = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob, prune_sum);
         if (rc) return rc;
         if (overlap) PK_HIP(hipEventRecord(ctx->ev_for[buf], ctx->stream));
+        if (stream_coords && c0 + chunk < cd->N) {
+            rc = upload(c0 + chunk);
+            if (rc) return rc;
+        }
     }
     return PK_OK;
 }
@@ -1222,14 +1249,14 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
     pk_device_ctx *ctx = pk_ctx(m->device);
     if (!ctx) return PK_E_NODEVICE;
     pk_cands *cd = ctx->score_cands;
+    bool deferred = false;
     if (cd && ctx->score_cands_cap >= N) {
         cd->N = N;
         cd->prune = 0;
-        if (N > 0 && (hipMemcpyAsync(cd->x, x, (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                      hipMemcpyAsync(cd->y, y, (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)) {
-            pk_set_error("pk_score: candidate upload failed");
-            return PK_E_HIP;
-        }
+        // the coordinates travel chunk by chunk inside run_pipeline, behind the kernels
+        cd->h_x = x;
+        cd->h_y = y;
+        deferred = N > 0;
     } else {
         if (cd) pk_cands_destroy(cd);
         ctx->score_cands = nullptr;
@@ -1240,6 +1267,10 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         ctx->score_cands_cap = N;
     }
     rc = pk_score_run(m, f, cd, w, thre, batch, n_out);
+    if (deferred) {
+        cd->h_x = cd->h_y = nullptr;  // borrowed for this call only
+        if (rc) hipStreamSynchronize(ctx->stream2);  // no copy may still read the caller's buffers
+    }
     if (!rc) rc = pk_score_fetch(cd, ox, oy, op, osignal);
     return rc;
 }

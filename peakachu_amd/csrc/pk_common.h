@@ -316,6 +316,9 @@ struct pk_cands {
     int32_t *batch_cnt;    // device [n_batches] survivors per reference batch
     int64_t n_batches_cap;
     int prune;             // pk_cands_set_prune: exact early termination for this list's runs
+    // pk_score (host buffers): coordinates still on the host; run_pipeline uploads chunk k + 1 on the
+    // second stream while chunk k is being scored (nullptr: everything is on the device already)
+    const int32_t *h_x = nullptr, *h_y = nullptr;
 };
 
 // ------------------------------------------------------------ kernel entry

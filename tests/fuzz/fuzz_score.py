@@ -55,7 +55,11 @@ def main():
             M.data[idx[:5]] = -0.0
             M.data[idx[5:]] = 0.0
             raw = False
-        e = utils.calculate_expected(M, upper + 2 * w, raw=raw)
+        try:
+            e = utils.calculate_expected(M, upper + 2 * w, raw=raw)
+        except ValueError as err:  # a diagonal mean overflowed: the reference's isotonic fit refuses it too
+            print("case %3d seed=%d kind=%d: expected curve refused (%s)" % (case, seed, kind, str(err)[:50]))
+            continue
         if kind == 6:
             e = e[: max(3, int(rng.integers(3, e.size)))].copy()   # most windows stay unnormalised: truly flat
         if kind == 3:
