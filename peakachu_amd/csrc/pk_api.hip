@@ -1112,22 +1112,31 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[0], 0));
     }
     // pk_score hands host coordinates over: the upload of chunk k + 1 (second stream; the host
-    // blocks in the copy while the device scores chunk k) overlaps the kernels of chunk k
+    // blocks in the copy while the device scores chunk k) overlaps the kernels of chunk k.  The
+    // chunks then GROW -- 256 Ki candidates first, doubling up to `chunk` -- so that only a
+    // small first upload is exposed and every later one (0.4 ns per candidate over PCIe) fits
+    // behind the scoring of its predecessor (1.1 ns per candidate).
     const bool stream_coords = cd->h_x != nullptr && !overlap;
-    auto upload = [&](int64_t c0) -> int {
-        const int64_t cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
+    auto span = [&](int64_t k_) -> int64_t {  // candidates of chunk k_
+        if (!stream_coords) return chunk;
+        int64_t sz = (int64_t)262144 << (k_ < 8 ? k_ : 8);
+        sz = (sz + blk - 1) / blk * blk;
+        return sz < chunk ? sz : chunk;
+    };
+    auto upload = [&](int64_t c0, int64_t k_) -> int {
+        const int64_t cn = cd->N - c0 < span(k_) ? cd->N - c0 : span(k_);
         PK_HIP(hipMemcpyAsync(cd->x + c0, cd->h_x + c0, (size_t)cn * 4, hipMemcpyHostToDevice, ctx->stream2));
         PK_HIP(hipMemcpyAsync(cd->y + c0, cd->h_y + c0, (size_t)cn * 4, hipMemcpyHostToDevice, ctx->stream2));
-        PK_HIP(hipEventRecord(ctx->ev_ext[(c0 / chunk) & 1], ctx->stream2));
+        PK_HIP(hipEventRecord(ctx->ev_ext[k_ & 1], ctx->stream2));
         return PK_OK;
     };
     if (stream_coords) {
-        rc = upload(0);
+        rc = upload(0, 0);
         if (rc) return rc;
     }
     int64_t k = 0;
-    for (int64_t c0 = 0; c0 < cd->N; c0 += chunk, k++) {
-        const int64_t cn = cd->N - c0 < chunk ? cd->N - c0 : chunk;
+    for (int64_t c0 = 0; c0 < cd->N; c0 += span(k), k++) {
+        const int64_t cn = cd->N - c0 < span(k) ? cd->N - c0 : span(k);
         const int buf = overlap ? (int)(k & 1) : 0;
         float *tiles = ctx->fea_tiles + (size_t)buf * tile_floats;
         if (overlap && k >= 2)  // forest(k-2) must be done with this buffer
@@ -1143,8 +1152,8 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         rc = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob, prune_sum);
         if (rc) return rc;
         if (overlap) PK_HIP(hipEventRecord(ctx->ev_for[buf], ctx->stream));
-        if (stream_coords && c0 + chunk < cd->N) {
-            rc = upload(c0 + chunk);
+        if (stream_coords && c0 + cn < cd->N) {
+            rc = upload(c0 + cn, k + 1);
             if (rc) return rc;
         }
     }

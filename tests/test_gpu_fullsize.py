@@ -184,6 +184,23 @@ def test_other_configs_sampled_parity(hip_lib, w, T, n, band, upper, stride):
     assert np.array_equal(gio.bits(pr[sel][keep]), gio.bits(p_ref))
 
 
+def test_host_buffer_call_streams_its_coordinates(config2):
+    """pk_score (host coordinate and result buffers) on the whole workload: the coordinates
+    travel in growing chunks behind the kernels of the previous chunk (256 Ki, 512 Ki, ... up to
+    the chunk size); the scored pixels equal those of the device-resident candidate list, also
+    when the call is repeated (reused device buffers) and for a list shorter than one chunk."""
+    c = config2
+    w = c["w"]
+    for sl in (slice(None), slice(0, 3_000_001), slice(5, 200_000)):
+        x, y = c["x"][sl], c["y"][sl]
+        cd = _lib.HipCands(x, y)
+        cd.run(c["hm"], c["hf"], w, 0.5)
+        base = digest(*cd.fetch())
+        cd.close()
+        for _ in range(2):
+            assert digest(*c["hm"].score(c["hf"], w, 0.5, x, y)) == base
+
+
 @pytest.mark.parametrize("thre", [0.5, 0.2, 0.9, 0.0])
 def test_early_exit_same_pixels(config2, thre):
     """Option early_exit: candidates whose sum provably cannot exceed thre*T stop
