@@ -1116,7 +1116,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     // chunks then GROW -- 256 Ki candidates first, doubling up to `chunk` -- so that only a
     // small first upload is exposed and every later one (0.4 ns per candidate over PCIe) fits
     // behind the scoring of its predecessor (1.1 ns per candidate).
-    const bool stream_coords = cd->h_x != nullptr && !overlap;
+    const bool stream_coords = cd->h_x != nullptr && !overlap && cd->N > 0;
     auto span = [&](int64_t k_) -> int64_t {  // candidates of chunk k_
         if (!stream_coords) return chunk;
         int64_t sz = (int64_t)262144 << (k_ < 8 ? k_ : 8);
@@ -1265,7 +1265,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         // the coordinates travel chunk by chunk inside run_pipeline, behind the kernels
         cd->h_x = x;
         cd->h_y = y;
-        deferred = N > 0;
+        deferred = true;
     } else {
         if (cd) pk_cands_destroy(cd);
         ctx->score_cands = nullptr;

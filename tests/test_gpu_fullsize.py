@@ -191,7 +191,7 @@ def test_host_buffer_call_streams_its_coordinates(config2):
     when the call is repeated (reused device buffers) and for a list shorter than one chunk."""
     c = config2
     w = c["w"]
-    for sl in (slice(None), slice(0, 3_000_001), slice(5, 200_000)):
+    for sl in (slice(None), slice(0, 3_000_001), slice(5, 200_000), slice(0, 0), slice(7, 8)):
         x, y = c["x"][sl], c["y"][sl]
         cd = _lib.HipCands(x, y)
         cd.run(c["hm"], c["hf"], w, 0.5)
