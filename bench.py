@@ -205,6 +205,34 @@ def pmc_rooflines(dom, launches_per_step_live):
     return traffic, issue, lds
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: run the same command under
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) as a child process and
+    hand back its exit code (3 = the RCCL communicator could not be built)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    # torch.distributed.run answers every failed rank with exit code 1; a rank that ends the
+    # run for a NAMED reason (3 = no RCCL communicator) leaves its code in this file
+    import tempfile
+    fd, code_file = tempfile.mkstemp(prefix="pk_bench_exit_")
+    os.close(fd)
+    env["PK_BENCH_EXIT_FILE"] = code_file
+    try:
+        rc = subprocess.call(cmd, env=env)
+        txt = open(code_file).read().strip()
+        return int(txt) if (rc != 0 and txt) else rc
+    finally:
+        os.unlink(code_file)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,9 +271,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "(--nproc-per-node %d)" % (a.gpus, a.gpus))
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            # started bare (`python bench.py --gpus N`): become the launcher.  The ranks are
+            # CHILD processes of torch.distributed.run (one per GPU); this parent has touched
+            # neither HIP nor the library, relays the child's output and exits with its code.
+            sys.exit(self_launch(a.gpus, sys.argv[1:]))
         a.gpus = world
 
     dist = None
@@ -312,6 +342,8 @@ def main():
                 if rank == 0:
                     sys.stderr.write("bench.py: the RCCL communicator could not be built on every rank; "
                                      "refusing to measure a gloo gather (pass --allow-gloo-gather to do so)\n")
+                    if os.environ.get("PK_BENCH_EXIT_FILE"):
+                        open(os.environ["PK_BENCH_EXIT_FILE"], "w").write("3")
                 dist.barrier()
                 dist.destroy_process_group()
                 sys.exit(3)

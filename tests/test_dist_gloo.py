@@ -24,3 +24,21 @@ def test_two_rank_gather_matches_reference(tmp_path):
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (tmp_path / "result.txt").read_text() == "OK"
+
+
+def test_bench_launches_itself_for_n_gpus():
+    """`python bench.py --gpus 2` (no launcher, as the driver starts --gpus 1) must start its
+    own ranks under torch.distributed.run as child processes: here, without a GPU, both ranks
+    get through the gloo rendezvous and stop at the library's device check -- loudly, and the
+    launcher passes the failure on."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("no HIP device visible") >= 2, r.stderr[-3000:]  # one per rank
+    assert "must be launched with" not in r.stderr
+    # no JSON line from a run that measured nothing
+    assert not [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")], r.stdout[-2000:]
