@@ -191,16 +191,20 @@ def pmc_rooflines(dom, launches_per_step_live):
              "frac": (c["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cyc)) if "SQ_INSTS_VALU" in c else None,
              "formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE/8)", "stale": stale,
              "source": note}
+    # tools/micro/lds_indep.hip on MI355X (profiles/r03_lds_indep.log): INDEPENDENT ds_read_u16 /
+    # b32 / b64 wave-instructions cost the CU 1.6-2.0 cycles each with >= 64 in flight (16 waves x
+    # 4), as the guide's LDS table says (2 LDS-array cycles) -- not the 4 cycles DESIGN.md round 2
+    # took from dependent chains.  The walk is a DEPENDENT chain (2 048 of them fit the LDS), so
+    # the array-busy fraction is the roofline and the instruction count x 2 cycles its floor.
     lds = {"bound": "lds", "lds_wave_insts_per_launch": c.get("SQ_INSTS_LDS"),
            "lds_array_cycles_per_launch": c.get("SQ_LDS_IDX_ACTIVE"),
            "bank_conflict_cycles_per_launch": c.get("SQ_LDS_BANK_CONFLICT"), "cus": 256,
-           "cycles_per_launch": cyc,
-           # an LDS wave-instruction occupies the CU's LDS pipe for >= 4 cycles whatever its
-           # width (tools/micro/lds_chain.hip on MI355X: 16 waves x 4 walks saturate at
-           # 11.9 cycles per 3 reads), so instructions / 4-cycle slots is the binding ratio
-           "frac_issue_slots": (c["SQ_INSTS_LDS"] * 4.0 / (256.0 * cyc)) if "SQ_INSTS_LDS" in c else None,
+           "cycles_per_launch": cyc, "cycles_per_lds_inst": 2,
+           "frac_issue_slots": (c["SQ_INSTS_LDS"] * 2.0 / (256.0 * cyc)) if "SQ_INSTS_LDS" in c else None,
            "frac_array_busy": (c["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)) if "SQ_LDS_IDX_ACTIVE" in c else None,
-           "formula": "SQ_INSTS_LDS x 4 cycles / (256 CUs x GRBM_GUI_ACTIVE/8); SQ_LDS_IDX_ACTIVE / (256 x cycles)",
+           "formula": "SQ_INSTS_LDS x 2 cycles / (256 CUs x GRBM_GUI_ACTIVE/8) [conflict-free floor]; "
+                      "SQ_LDS_IDX_ACTIVE / (256 x cycles) [array busy, bank conflicts included]",
+           "cost_model_source": "tools/micro/lds_indep.hip, profiles/r03_lds_indep.log",
            "stale": stale, "source": note}
     return traffic, issue, lds
 
@@ -264,6 +268,9 @@ def main():
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use device 0 and the RCCL gather is skipped "
                          "(RCCL refuses two ranks on one GPU); the result is not a valid measurement")
+    ap.add_argument("--busy-seconds", type=float, default=2.5,
+                    help="untimed scoring loop after the timed region, so that an outside GPU-activity "
+                         "sampler sees the device working (0 = off)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
     a = ap.parse_args()
 
@@ -408,6 +415,14 @@ def main():
     kern = {k: _lib.prof_get(k) for k in ("extract", "quant", "forest", "compact")}
     run_ms, gather_ms = t_run[0] / a.steps * 1e3, t_gather[0] / a.steps * 1e3
     gpu_pixels = cd.fetch() if world == 1 else None
+    # untimed: the timed region can be a fraction of a second (the driver fixes --steps), too
+    # short for a 1 Hz GPU-activity sampler; keep the same scoring loop running for >= 2 s
+    busy_steps = 0
+    if a.busy_seconds > 0:
+        t_b = time.perf_counter()
+        while time.perf_counter() - t_b < a.busy_seconds:
+            cd.run(hm, hf, w, a.thre, a.batch)
+            busy_steps += 1
 
     # extra, not the headline: the same pass with exact early termination (option
     # early_exit: candidates that provably end at p <= thre stop walking; same pixels)
@@ -512,11 +527,17 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "synthetic %dx%d band-diagonal (%d-bin band) CSR, w=%d, %d-tree RF%s, "
-                            "%s non-zero band pixels %d<=d<=%d"
+                            "%s non-zero band pixels %d<=d<=%d; value = device-resident candidate list "
+                            "(pk_score_run: what Chromosome.score runs on); SURVEY 8d's literal metric "
+                            "(host coordinate / result buffers) is the pcie_inclusive leg%s"
                             % (a.n, a.n, a.band, w, fo.T,
                                " (untrained random trees)" if (a.forest or "").startswith("random:") else "",
                                "all" if a.stride == 1 else "every %d-th of the" % a.stride,
-                               max(6, w + 1), upper),
+                               max(6, w + 1), upper,
+                               "" if world == 1 else
+                               ("; strong scaling: every rank holds chromosome seed 0" if strong else
+                                "; weak scaling: rank r scores its own synthetic chromosome, seed = r "
+                                "(seeds 0..%d), so N = 1 equals the single-GPU bench" % (world - 1))),
                 "candidates_per_gpu": n_local,
                 "features": F,
                 "trees": fo.T,
@@ -547,12 +568,18 @@ def main():
                 "avg_launch_ms": dom_ms / dom_n if dom_n else None,
                 "launches": dom_n,
                 "candidates_per_launch": n_local * a.steps / dom_n if dom_n else None,
+                # the same algorithmic bytes over (i) the forest STAGE = rank quantizer + forest
+                # kernel, (ii) the WHOLE path = SURVEY 8d's definition, value x B_alg / peak
+                "stage_frac": (alg_bytes_total / ((kern["forest"][0] + kern["quant"][0]) * 1e-3) / 1e9
+                               / HBM_PEAK_GBS) if (kern["forest"][0] + kern["quant"][0]) > 0 else None,
+                "whole_path_frac": value / world * b_alg(F) / 1e9 / HBM_PEAK_GBS,
             },
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kern.items()},
             "whole_path_alg_GBs": value * b_alg(F) / 1e9,
             "upload_s": upload_s,
             "per_rank_ms": per_rank_ms,       # device work of a step (pk_score_run), per rank
             "gather_ms": gather_ms,           # the exchange of a step, as seen by rank 0
+            "untimed_busy_steps": busy_steps,  # same scoring loop, after the timed region (--busy-seconds)
         }
         if issue_roof is not None:
             out["roofline_issue"] = issue_roof

@@ -107,6 +107,11 @@ int pk_csr_expected_means(pk_csr *, pk_matrix *band, int first, int top, int mod
  * (2w+1)^2 window, distance_normalize (peakachu/utils.py:211-237), gaussian
  * blur (sigma=1), image_normalize (peakachu/utils.py:204-209), ravel.
  * keep[i] = index into the input of survivor i (input order).
+ * Coordinates are whatever the caller has, as in the reference: those with x-w < 0 or
+ * y+w+1 > n are dropped; a lower-triangle coordinate (x > y) that passes is served from
+ * the stored diagonals (cells with col-row <= -2w read 0, scoreUtils.py:30-33; a column
+ * y-w+j < 0 is column n + (y-w+j), scipy's negative index); where the reference's gather
+ * raises IndexError (row x+w >= n, column y-w < -n) the call fails with PK_E_INVALID.
  * fea64 / fea32: [n_keep, F] row-major, either may be NULL.  A feature that is
  * NaN in the reference is NaN here; the sign bit / payload of a NaN is not
  * reproduced (IEEE 754 leaves it open and x86 and gfx950 differ). */

@@ -142,16 +142,22 @@ static void image_normalize(double *a, int n)
 /* ---- one candidate through peakachu/utils.py:211-237 (distance_normalize),
  * :180-202 (distance_normaize_core), then scoreUtils.py:85-88 (blur, scale,
  * ravel).  Returns 1 and fills fea[F] if the window survives the filters. */
-static int one_window(const int32_t *indptr, const int32_t *indices,
+static int one_window(int32_t n, const int32_t *indptr, const int32_t *indices,
                       const double *data, const double *exp_arr,
                       int64_t exp_len, int w, int64_t x, int64_t y, double *fea)
 {
     const int S = 2 * w + 1, F = S * S;
     double win[PKO_MAX_S * PKO_MAX_S];
-    /* scoreUtils.py:77-82: S x S gather, row offset i, col offset j */
+    /* scoreUtils.py:77-82: S x S gather, row offset i, col offset j.  scipy's fancy
+     * indexing counts a negative column from the far end (possible only when x > y;
+     * rows and columns beyond that raise there: see pko_extract). */
     for (int i = 0; i < S; i++)
-        for (int j = 0; j < S; j++)
-            win[i * S + j] = csr_get(indptr, indices, data, x - w + i, y - w + j);
+        for (int j = 0; j < S; j++) {
+            int64_t col = y - w + j;
+            if (col < 0)
+                col += n;
+            win[i * S + j] = csr_get(indptr, indices, data, x - w + i, col);
+        }
     /* utils.py:221-223: NaN -> 0 */
     int nnz = 0;
     for (int k = 0; k < F; k++) {
@@ -216,7 +222,11 @@ int64_t pko_extract(int32_t n, const int32_t *indptr, const int32_t *indices,
             continue;
         if (train_mask && !(yi - xi > w))
             continue;
-        if (!one_window(indptr, indices, data, exp_arr, exp_len, w, xi, yi, fea))
+        /* scoreUtils.py:81: M[rows, cols] raises IndexError for a row >= n or a column
+         * < -n (the mask above admits such windows only when x > y) */
+        if (xi + w >= n || yi - w < -(int64_t)n)
+            return -1;
+        if (!one_window(n, indptr, indices, data, exp_arr, exp_len, w, xi, yi, fea))
             continue;
         if (fea64)
             memcpy(fea64 + nk * F, fea, sizeof(double) * F);
@@ -357,7 +367,7 @@ int64_t pko_score_all_mt(int nthreads, int32_t n, const int32_t *indptr,
         int64_t xi = x[c], yi = y[c];
         if (!(xi - w >= 0 && yi + w + 1 <= n))
             continue;
-        if (!one_window(indptr, indices, data, exp_arr, exp_len, w, xi, yi, fea))
+        if (!one_window(n, indptr, indices, data, exp_arr, exp_len, w, xi, yi, fea))
             continue;
         for (int k = 0; k < F; k++)
             f32[k] = (float)fea[k];

@@ -12,9 +12,16 @@ branch): the upper-triangle pixels whose two bins lie in the chromosome, mirrore
 diagonal (`query_rect(..., duplex=True)`), as a COO matrix of the chromosome's size; with
 `balance` the data become `bias[row] * bias[col] * count` -- the two weights are multiplied
 first, so the matrix is exactly symmetric -- and are NaN where a weight is NaN; columns named
-KR, VC or SQRT_VC (hic2cool's) are divisive: `count / (bias[row] * bias[col])`.  cooler is
-not installed in the build image: the restatement is pinned against files written by the
-genuine HDF5 library in cooler's layout (tools/make_cool_fixture.py), not against cooler.
+KR, VC or SQRT_VC (hic2cool's), or carrying a `divisive_weights` attribute, are divisive:
+the biases are inverted first (`bias = 1 / bias`) and then applied the same way,
+`(1 / b[row]) * (1 / b[col]) * count`, which differs from `count / (b[row] * b[col])` in the
+last bits.  cooler is not installed in the build image: the restatement is pinned against
+files written by the genuine HDF5 library in cooler's layout (tools/make_cool_fixture.py),
+NOT against cooler itself.  The multiplicative path (`weight`, what peakachu's default
+`--clr-weight-name weight` uses) is a plain product with one possible operand order issue
+(none: the product of the two weights is formed first, so the result is symmetric); the
+divisive path's order of operations is recalled from cooler's source, UNVERIFIED -- where
+`cooler` is importable `io.open_map` uses it instead of this class.
 """
 import numpy as np
 from scipy import sparse
@@ -133,9 +140,12 @@ class CoolFile:
             if name:
                 w = self._weights(name, lo, hi)
                 if self._divisive(name):
-                    data = data / (w[row] * w[col])
-                else:
-                    data = w[row] * w[col] * data
+                    # divisive columns: the biases are inverted first and then applied like
+                    # multiplicative ones -- (1/b_i) * (1/b_j) * count, which does not round like
+                    # count / (b_i * b_j).  UNVERIFIED against cooler itself (see the module text)
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        w = 1.0 / w
+                data = w[row] * w[col] * data
             else:
                 data = data.copy()  # (the cached arrays stay ours)
             return sparse_coo(data, row.copy(), col.copy(), n)

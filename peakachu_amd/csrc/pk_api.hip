@@ -1060,9 +1060,8 @@ extern "C" int pk_cands_fetch(pk_cands *cd, int32_t *x, int32_t *y)
     return PK_OK;
 }
 
-// The reference raises on coordinates whose window leaves the matrix in the
-// row direction (scipy fancy indexing) or wraps negative columns; the build
-// requires 0 <= x <= y < n, for which neither can happen.
+// pk_score: the build requires 0 <= x <= y < n (what get_candidate produces).  pk_extract
+// (getwindow) takes any coordinates, see classify_coords below.
 static int check_coords(const char *who, int32_t n, int64_t N, const int32_t *x, const int32_t *y)
 {
     // (block-wise and branch-free so that the compiler vectorises it: this runs over millions of
@@ -1080,6 +1079,34 @@ static int check_coords(const char *who, int32_t n, int64_t N, const int32_t *x,
                 }
     }
     return PK_OK;
+}
+
+// getwindow's coordinates (peakachu/scoreUtils.py:70-93) are whatever the caller passes: the
+// reference drops those with x-w < 0 or y+w+1 > n and gathers the rest with scipy's fancy
+// indexing, which RAISES IndexError for a row x+w >= n or a column y-w < -n (possible only
+// with x > y) and reads a negative column from the far end.  -> 0: all coordinates satisfy
+// 0 <= x <= y < n (the fast kernels apply), 1: some do not (general kernel), < 0: the
+// reference would raise.
+static int classify_coords(int32_t n, int w, int64_t N, const int32_t *x, const int32_t *y)
+{
+    int any = 0;
+    for (int64_t b = 0; b < N; b += 8192) {
+        const int64_t e = b + 8192 < N ? b + 8192 : N;
+        int odd = 0;
+        for (int64_t i = b; i < e; i++) odd |= (x[i] < 0) | (y[i] < x[i]) | (y[i] >= n);
+        if (!odd) continue;
+        any = 1;
+        for (int64_t i = b; i < e; i++) {
+            const int64_t xi = x[i], yi = y[i];
+            if (!(xi - w >= 0 && yi + w + 1 <= n)) continue;  // dropped by the reference's mask
+            if (xi + w >= n || yi - w < -(int64_t)n) {
+                pk_set_error("pk_extract: coordinate %lld = (%d, %d): window index out of range for n=%d "
+                             "(IndexError in the reference)", (long long)i, x[i], y[i], n);
+                return PK_E_INVALID;
+            }
+        }
+    }
+    return any;
 }
 
 static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands *cd, int w,
@@ -1106,6 +1133,13 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     // and (at <= 72 VGPRs) room for one 216-register extractor wave per SIMD, which is
     // FP64-VALU bound: the two kernels are complementary on a CU.
     hipStream_t st_ext = overlap ? ctx->stream2 : ctx->stream;
+    if (overlap && cd->h_x != nullptr && cd->N > 0) {
+        // pk_score lent host coordinates (they are NOT on the device yet) and the chunk-by-chunk
+        // upload below is switched off in this mode: everything goes up front on the main
+        // stream, ahead of the event the extractor's stream waits for
+        PK_HIP(hipMemcpyAsync(cd->x, cd->h_x, (size_t)cd->N * 4, hipMemcpyHostToDevice, ctx->stream));
+        PK_HIP(hipMemcpyAsync(cd->y, cd->h_y, (size_t)cd->N * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (overlap) {
         // whatever precedes on the main stream (uploads) must be visible to the extractor
         PK_HIP(hipEventRecord(ctx->ev_for[0], ctx->stream));
@@ -1295,8 +1329,10 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     }
     *n_keep = 0;
     if (N == 0) return PK_OK;
-    int rc = check_coords("pk_extract", m->n, N, x, y);
-    if (rc) return rc;
+    int rc = classify_coords(m->n, w, N, x, y);
+    if (rc < 0) return rc;
+    const bool any_coords = rc == 1;
+    rc = PK_OK;
     pk_device_ctx *ctx = pk_ctx(m->device);
     if (!ctx) return PK_E_NODEVICE;
     const int F = (2 * w + 1) * (2 * w + 1);
@@ -1332,7 +1368,7 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     for (int64_t c0 = 0; !rc && c0 < N; c0 += chunk) {
         const int64_t cn = N - c0 < chunk ? N - c0 : chunk;
         rc = pk_launch_extract(ctx, ctx->stream, m, w, cd->x, cd->y, c0, cn, ctx->fea_tiles, blk,
-                               cd->status, d_rows);
+                               cd->status, d_rows, any_coords);
         if (rc) break;
         if (hipMemcpyAsync(h_rows.data(), d_rows, (size_t)cn * F * 8, hipMemcpyDeviceToHost,
                            ctx->stream) != hipSuccess ||

@@ -21,7 +21,7 @@ extern std::recursive_mutex g_api_mu;
 struct pk_comm {
     int device, nranks, rank;
     ncclComm_t comm;
-    int64_t *d_counts;  // device [nranks]
+    int64_t *d_counts;  // device [2 * nranks]: the counts, then the ranks' status words (comm_agree)
     int64_t *d_mine;    // device scalar: this rank's byte count (pk_comm_gatherv_bytes)
     // staging areas that live as long as the communicator and only ever grow: a gather is
     // part of the timed step of a multi-GPU run and must not allocate
@@ -54,6 +54,32 @@ static int comm_reserve(pk_comm *c, int i, size_t bytes)
     } while (0)
 
 static_assert(sizeof(ncclUniqueId) == 128, "pk_comm_unique_id assumes a 128-byte id");
+
+// Every rank tells every other whether it can go through with the transfer that follows
+// (0 = yes, else its error code): a rank that cannot post its half of a send/recv pair --
+// the root without a staging area, a result larger than the caller's buffers -- must not
+// simply return, or its peers sit in ncclSend / ncclRecv for ever.  All ranks call this at
+// the same point and all take the same decision: *bad = the first rank with a non-zero
+// word (-1 if none), *code = its word.
+static int comm_agree(pk_comm *c, hipStream_t s, int local_rc, int *bad, int *code)
+{
+    const int R = c->nranks;
+    const int64_t mine = local_rc;
+    std::vector<int64_t> h((size_t)R, 0);
+    PK_HIP(hipMemcpyAsync(c->d_mine, &mine, 8, hipMemcpyHostToDevice, s));
+    PK_NCCL(ncclAllGather(c->d_mine, c->d_counts + R, 1, ncclInt64, c->comm, s));
+    PK_HIP(hipMemcpyAsync(h.data(), c->d_counts + R, 8 * (size_t)R, hipMemcpyDeviceToHost, s));
+    PK_HIP(hipStreamSynchronize(s));
+    *bad = -1;
+    *code = 0;
+    for (int r = 0; r < R; r++)
+        if (h[(size_t)r] != 0) {
+            *bad = r;
+            *code = (int)h[(size_t)r];
+            break;
+        }
+    return PK_OK;
+}
 
 extern "C" int pk_comm_unique_id(uint8_t id[128])
 {
@@ -90,7 +116,7 @@ extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8
         delete c;
         return nullptr;
     }
-    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * (size_t)nranks) != hipSuccess ||
+    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * 2 * (size_t)nranks) != hipSuccess ||
         hipMalloc((void **)&c->d_mine, sizeof(int64_t)) != hipSuccess) {
         pk_set_error("pk_comm_create: device allocation failed");
         ncclCommDestroy(c->comm);
@@ -136,8 +162,33 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
     if (counts)
         for (int r = 0; r < R; r++) counts[r] = h_counts[(size_t)r];
 
+    // 2. what only the root can know -- whether the result fits the caller's buffers and its
+    // staging area could be made -- is agreed on by all ranks BEFORE anybody sends
+    const size_t t1 = ((size_t)(total > 0 ? total : 1) + 1) & ~(size_t)1;
+    int local_rc = PK_OK;
+    if (c->rank == 0) {
+        if (total > cap || (total > 0 && (!ox || !oy || !op || !osignal))) {
+            pk_set_error("pk_comm_gather_scored: %lld pixels exceed the root capacity %lld",
+                         (long long)total, (long long)cap);
+            local_rc = PK_E_INVALID;
+        } else {
+            local_rc = comm_reserve(c, 0, t1 * 24);  // one staging area [x | y | p | signal]
+        }
+    }
+    {
+        int bad = -1, code = 0;
+        const int rca = comm_agree(c, s, local_rc, &bad, &code);
+        if (rca) return rca;
+        if (bad >= 0) {
+            if (bad != c->rank)
+                pk_set_error("pk_comm_gather_scored: rank %d cannot take part in the gather (code %d); "
+                             "nothing was sent", bad, code);
+            return bad == c->rank ? local_rc : PK_E_COMM;
+        }
+    }
+
     if (c->rank != 0) {
-        // 2. peer -> root: four typed sends in one group
+        // 3. peer -> root: four typed sends in one group
         const size_t k = (size_t)h_counts[(size_t)c->rank];
         if (k > 0) {
             PK_NCCL(ncclGroupStart());
@@ -151,18 +202,7 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
         return PK_OK;
     }
 
-    // root
-    if (total > cap || (total > 0 && (!ox || !oy || !op || !osignal))) {
-        pk_set_error("pk_comm_gather_scored: %lld pixels exceed the root capacity %lld",
-                     (long long)total, (long long)cap);
-        // still drain the peers' sends into a scratch area to keep ranks in step
-    }
-    // one staging area [x | y | p | signal], 8-byte aligned parts
-    const size_t t1 = ((size_t)(total > 0 ? total : 1) + 1) & ~(size_t)1;
-    {
-        const int rcs = comm_reserve(c, 0, t1 * 24);
-        if (rcs) return rcs;
-    }
+    // root: 8-byte aligned parts of the staging area
     int32_t *gx = static_cast<int32_t *>(c->stage[0]), *gy = gx + t1;
     double *gp = reinterpret_cast<double *>(gy + t1), *gs = gp + t1;
     int rc = PK_OK;
@@ -196,7 +236,7 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
             rc = PK_E_COMM;
             break;
         }
-        if (total > 0 && total <= cap && ox && oy && op && osignal) {
+        if (total > 0) {
             const size_t t = (size_t)total;
             if (hipMemcpyAsync(ox, gx, t * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
                 hipMemcpyAsync(oy, gy, t * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -206,8 +246,6 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
                 rc = PK_E_HIP;
                 break;
             }
-        } else if (total > cap) {
-            rc = PK_E_INVALID;
         }
         if (hipStreamSynchronize(s) != hipSuccess) {
             pk_set_error("pk_comm_gather_scored: stream sync failed");
@@ -231,17 +269,23 @@ extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbyte
     const int R = c->nranks;
     int64_t *d_mine = c->d_mine;
     uint8_t *d_send = nullptr, *d_recv = nullptr;
-    int rc = comm_reserve(c, 0, (size_t)(nbytes > 0 ? nbytes : 1));
-    if (rc) return rc;
+    // a rank that cannot stage its bytes still takes part in the count exchange (with a count
+    // of zero) and reports the failure in the agreement that follows
+    int local_rc = comm_reserve(c, 0, (size_t)(nbytes > 0 ? nbytes : 1));
+    if (local_rc) nbytes = 0;
+    int rc = PK_OK;
     d_send = static_cast<uint8_t *>(c->stage[0]);
     std::vector<int64_t> h_counts((size_t)R);
     do {
-        if (hipMemcpyAsync(d_mine, &nbytes, 8, hipMemcpyHostToDevice, s) != hipSuccess ||
-            (nbytes > 0 &&
-             hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, s) != hipSuccess)) {
+        if (hipMemcpyAsync(d_mine, &nbytes, 8, hipMemcpyHostToDevice, s) != hipSuccess) {
             pk_set_error("pk_comm_gatherv_bytes: upload failed");
-            rc = PK_E_HIP;
+            rc = PK_E_HIP;  // (the stream itself is gone: the peers will see the communicator fail)
             break;
+        }
+        if (nbytes > 0 &&
+            hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, s) != hipSuccess) {
+            pk_set_error("pk_comm_gatherv_bytes: upload failed");
+            local_rc = PK_E_HIP;
         }
         ncclResult_t nr = ncclAllGather(d_mine, c->d_counts, 1, ncclInt64, c->comm, s);
         if (nr != ncclSuccess ||
@@ -256,6 +300,28 @@ extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbyte
         for (int r = 0; r < R; r++) total += h_counts[(size_t)r];
         if (counts)
             for (int r = 0; r < R; r++) counts[r] = h_counts[(size_t)r];
+        // the root's part (staging area, capacity) is settled before anybody sends
+        if (c->rank == 0 && !local_rc) {
+            if (total > cap || (total > 0 && !recv)) {
+                pk_set_error("pk_comm_gatherv_bytes: %lld bytes exceed the root capacity %lld",
+                             (long long)total, (long long)cap);
+                local_rc = PK_E_INVALID;
+            } else {
+                local_rc = comm_reserve(c, 1, (size_t)(total > 0 ? total : 1));
+            }
+        }
+        {
+            int bad = -1, code = 0;
+            rc = comm_agree(c, s, local_rc, &bad, &code);
+            if (rc) break;
+            if (bad >= 0) {
+                if (bad != c->rank)
+                    pk_set_error("pk_comm_gatherv_bytes: rank %d cannot take part in the gather (code %d); "
+                                 "nothing was sent", bad, code);
+                rc = bad == c->rank ? local_rc : PK_E_COMM;
+                break;
+            }
+        }
         if (c->rank != 0) {
             if (nbytes > 0) {
                 nr = ncclSend(d_send, (size_t)nbytes, ncclUint8, 0, c->comm, s);
@@ -268,8 +334,6 @@ extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbyte
             if (hipStreamSynchronize(s) != hipSuccess) rc = PK_E_HIP;
             break;
         }
-        rc = comm_reserve(c, 1, (size_t)(total > 0 ? total : 1));
-        if (rc) break;
         d_recv = static_cast<uint8_t *>(c->stage[1]);
         if (nbytes > 0 &&
             hipMemcpyAsync(d_recv, d_send, (size_t)nbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
@@ -289,14 +353,9 @@ extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbyte
             rc = PK_E_COMM;
             break;
         }
-        if (total > cap || (total > 0 && !recv)) {
-            pk_set_error("pk_comm_gatherv_bytes: %lld bytes exceed the root capacity %lld",
-                         (long long)total, (long long)cap);
-            rc = PK_E_INVALID;
-        } else if (total > 0 &&
-                   hipMemcpyAsync(recv, d_recv, (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess) {
+        if (total > 0 &&
+            hipMemcpyAsync(recv, d_recv, (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess)
             rc = PK_E_HIP;
-        }
         if (hipStreamSynchronize(s) != hipSuccess) rc = PK_E_HIP;
     } while (0);
     return rc;

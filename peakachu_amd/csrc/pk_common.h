@@ -335,7 +335,7 @@ int pk_matrix_prepare_norm(pk_device_ctx *, pk_matrix *);
 int pk_extract_upload_taps(const double *taps5);  // into the current device's constant memory
 int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
-                      int blk, uint8_t *d_status, double *fea64_rows);
+                      int blk, uint8_t *d_status, double *fea64_rows, bool any_coords = false);
 
 // walk the forest over feature tiles of candidates [c0, c0+cn)
 // prune_sum: -inf (full evaluation) or thre*T: candidates whose sum provably cannot reach it

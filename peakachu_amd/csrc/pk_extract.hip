@@ -743,7 +743,14 @@ __device__ __forceinline__ int reflect1(int q, int n)
 // configuration): every loop unrolls, so the 12 gather loads of a lane are all in flight
 // together and the 121 LDS reads of the sequential top-left sum are issued back to back
 // instead of one round trip each (measured at w = 11: 6.9 -> see DESIGN.md).  WT = 0: any w.
-template <int WT>
+// ANY: coordinates of any kind (pk_extract / getwindow with x > y or off-matrix entries).
+// The reference's getwindow (scoreUtils.py:70-93) masks only `x-w >= 0 and y+w+1 <= n`; a
+// lower-triangle coordinate that passes reads its window from the stored diagonals
+// (-2w < col-row < upper+2w, scoreUtils.py:30-33; below -2w the cells are 0), divides by
+// expected(|col-row|) of the UNWRAPPED coordinates, and a window column y-w+j < 0 is the
+// column n + (y-w+j) (scipy's negative indices).  Rows beyond the matrix make the reference
+// raise; the host refuses such calls before anything is launched.
+template <int WT, bool ANY = false>
 __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     int Wrt, const double *__restrict__ band, int64_t ld, int dlo, int dhi, int n,
     const double *__restrict__ exp_arr, int exp_len, const int32_t *__restrict__ xs,
@@ -760,7 +767,8 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     if (local >= cn) return;  // wave-uniform; no block barriers are used below
     const int64_t c = c0 + local;
     const int xi = xs[c], yi = ys[c];
-    if (!(xi - W >= 0 && yi + W + 1 <= n && PK_OTHER_EDGES(xi, yi, W, n))) {
+    if (ANY ? !(xi >= W && yi <= n - W - 1 && xi <= n - W - 1 && yi >= W - n)
+            : !(xi - W >= 0 && yi + W + 1 <= n && PK_OTHER_EDGES(xi, yi, W, n))) {
         if (lane == 0) status[c] = 0;
         return;
     }
@@ -778,7 +786,8 @@ __global__ __launch_bounds__(64 * GEN_WAVES) void extract_lds_kernel(
     for (int it = 0; it < steps; it++) {
         const int i = 2 * it + ihalf;
         if (jok && i < S) {
-            const int k = d + j - i;
+            int k = d + j - i;
+            if (ANY && yi - W + j < 0) k += n;  // a negative column counts from the far end
             double v = 0.0;
             if (k >= dlo && k <= dhi) v = band[(int64_t)(k - dlo) * ld + r0 + i];
             v = (v != v) ? 0.0 : v;
@@ -957,11 +966,23 @@ int pk_extract_upload_taps(const double *taps5)
 
 int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
-                      int blk, uint8_t *d_status, double *fea64_rows)
+                      int blk, uint8_t *d_status, double *fea64_rows, bool any_coords)
 {
     if (cn <= 0) return PK_OK;
     pk_prof_scope prof(ctx, PK_K_EXTRACT, st);
-    if ((w == 5 || w == 6) && g_opt.extract_pair) {
+    if (any_coords) {
+        // coordinates outside 0 <= x <= y < n (pk_extract only): the general kernel
+        if (w < 1 || w > 15) {
+            pk_set_error("pk_extract: w=%d unsupported (1..15)", w);
+            return PK_E_UNSUPPORTED;
+        }
+        const int F = (2 * w + 1) * (2 * w + 1);
+        const size_t lds = (size_t)GEN_WAVES * 2 * F * sizeof(double);
+        const unsigned grid = (unsigned)((cn + GEN_WAVES - 1) / GEN_WAVES);
+        hipLaunchKernelGGL((extract_lds_kernel<0, true>), dim3(grid), dim3(64 * GEN_WAVES), lds, st, w,
+                           m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0,
+                           cn, tiles, blk, d_status, fea64_rows);
+    } else if ((w == 5 || w == 6) && g_opt.extract_pair) {
         const unsigned grid = (unsigned)((cn + 31) / 32);
         const int F = (2 * w + 1) * (2 * w + 1);
         // the clean kernel addresses the bands and the tile buffer with 32-bit offsets

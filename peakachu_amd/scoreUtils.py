@@ -26,7 +26,9 @@ def _device_forest(model, device):
     hf = _lib.HipForest(as_flat_forest(model), device=device)
     _FOREST_CACHE.append((model, device, hf))
     while len(_FOREST_CACHE) > 4:
-        _FOREST_CACHE.pop(0)[2].close()
+        # only the cache's reference goes: a Chromosome that still holds the evicted forest
+        # keeps it alive, and HipForest.__del__ frees the device copy with the last holder
+        _FOREST_CACHE.pop(0)
     return hf
 
 
@@ -73,11 +75,13 @@ class Chromosome():
     def M(self):
         if self._M_val is None:
             self._M_val = utils.band_filter(self._M_src, self.w, self.upper)
+            self._M_src = None  # the reference keeps the filtered copy only (scoreUtils.py:29)
         return self._M_val
 
     @M.setter
     def M(self, value):
         self._M_val = value
+        self._M_src = None
 
     def _expected_on_device(self, csr, band, maxdis, balanced):
         """utils.calculate_expected with the diagonal means taken from device bands of the
@@ -172,7 +176,7 @@ class Chromosome():
         own = False
         if facts is not None and (lower, upper) == (self.lower, self.upper):
             # everything get_candidate needs to know about the raw counts came with the upload
-            n = self._M_src.shape[0]
+            n = self._shape[0]
             hi = min(int(upper), self.background.size - 1, n - 1)
             if hi < lower or facts["nnz"] == 0 or not facts["integer"] or facts["band"] is None:
                 if facts.get("own") and facts["band"] is not None:
@@ -232,9 +236,18 @@ class Chromosome():
         if coords.size == 0:
             return np.r_[[]], np.r_[[]]
         xi, yi = coords[:, 0].astype(np.int64), coords[:, 1].astype(np.int64)
-        if np.any(xi > yi):
-            raise ValueError("peakachu_amd.getwindow needs upper-triangle coords (x <= y)")
-        fea, _, keep = self._matrix().extract(self.w, xi, yi)
+        n, w = self._shape[0], self.w
+        # the reference masks `x-w >= 0 and y+w+1 <= n` (:75) and lets scipy's fancy indexing
+        # judge the rest: a row x+w >= n or a column y-w < -n raises (only possible with x > y)
+        passes = (xi - w >= 0) & (yi + w + 1 <= n)
+        bad = passes & ((xi + w >= n) | (yi - w < -n))
+        if np.any(bad):
+            k = int(np.flatnonzero(bad)[0])
+            raise IndexError("index out of range: window of (%d, %d) leaves the %d-bin matrix"
+                             % (xi[k], yi[k], n))
+        # (dropped coordinates only need to stay dropped when squeezed into 32 bits)
+        lim = n + 2 * w + 2
+        fea, _, keep = self._matrix().extract(self.w, np.clip(xi, -1, lim), np.clip(yi, -lim, lim))
         if keep.size == 0:
             return np.r_[[]], np.r_[[]]
         clist = np.stack([xi[keep], yi[keep]], axis=1)

@@ -21,8 +21,13 @@ This module needs neither scikit-learn nor joblib: a pure-Python Unpickler
 of; `FlatForest.from_tree_states` applies the same count -> fraction
 normalisation scikit-learn <= 1.3 applied at predict time.
 
-Only numpy classes and the placeholders are ever instantiated: loading a model
-file executes no code from it beyond numpy's array / dtype reconstruction.
+Only the handful of numpy constructors listed in `_ALLOWED_EXACT` (ndarray, dtype and their
+reconstruction helpers), a few builtin containers and the placeholders are ever
+instantiated or called: every other global a file names -- anything else under `numpy.*`
+included -- becomes an inert placeholder class, and object-dtype arrays (a nested pickle
+in joblib's format) go through the same restricted unpickler.  Loading a model file
+therefore executes no code from it beyond numpy's array / dtype reconstruction
+(tests/test_model_ingest.py::test_malicious_pickles_execute_nothing).
 """
 import bz2
 import gzip
@@ -71,7 +76,9 @@ class _ArrayWrapper(_Placeholder):
         shape, order, dtype = st["shape"], st["order"], st["dtype"]
         count = int(np.prod([int(x) for x in shape], dtype=np.int64)) if len(shape) else 1
         if dtype.hasobject:
-            arr = pickle.load(fh)
+            # joblib pickles an object array as a nested pickle: same restrictions as outside
+            # (forests do not hold such arrays; a parameter grid around one may)
+            arr = _Unpickler(fh).load()
         else:
             if st.get("numpy_array_alignment_bytes") is not None:  # joblib >= 1.2
                 pad = int.from_bytes(fh.read(1), "little")
@@ -89,8 +96,12 @@ class _ArrayWrapper(_Placeholder):
         return arr
 
 
-_ALLOWED_PREFIXES = ("numpy",)
-_ALLOWED_EXACT = {("builtins", "set"), ("builtins", "frozenset"), ("builtins", "slice"),
+_ALLOWED_EXACT = {# numpy: array / dtype / scalar reconstruction only (old and new module paths)
+                  ("numpy", "ndarray"), ("numpy", "dtype"),
+                  ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                  ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                  ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+                  ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "slice"),
                   ("builtins", "complex"), ("builtins", "range"), ("builtins", "bytearray"),
                   ("collections", "OrderedDict"), ("collections", "defaultdict"),
                   ("copyreg", "_reconstructor"), ("builtins", "object"), ("builtins", "int"),
@@ -111,7 +122,7 @@ class _Unpickler(pickle._Unpickler):  # the pure-Python one: its dispatch table 
     def find_class(self, module, name):
         if (module, name) in (("__builtin__", "object"), ("copy_reg", "_reconstructor")):  # Python 2 names
             module = {"__builtin__": "builtins", "copy_reg": "copyreg"}[module]
-        if module.split(".")[0] in _ALLOWED_PREFIXES or (module, name) in _ALLOWED_EXACT:
+        if (module, name) in _ALLOWED_EXACT:
             return super().find_class(module, name)
         key = (module, name)
         if key not in self._classes:

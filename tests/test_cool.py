@@ -50,7 +50,7 @@ def test_coolfile_serves_what_cooler_serves(uri):
     for name in c.chromnames:
         n = int(z[name + "/n"])
         assert c.chrom_bins(name) == n == io.chrom_bins(c, name)
-        # ("KR" is divisive by its name, as in cooler: count / (bias_i * bias_j))
+        # ("KR" is divisive by its name, as in cooler: (1 / bias_i) * (1 / bias_j) * count)
         for tag, bal in (("raw", False), ("weight", "weight"), ("KR", "KR"), ("weight", True)):
             M = c.matrix(balance=bal, sparse=True).fetch(name)
             assert M.shape == (n, n) and sparse.isspmatrix_coo(M)

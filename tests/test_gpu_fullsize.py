@@ -143,6 +143,45 @@ def test_config4_full_parity_trained_forest(hip_lib):
     assert np.array_equal(gio.bits(pr), gio.bits(pr_ref))
 
 
+def _full_parity(w, n, band, upper, fo, thre=0.5, seed=0, min_cands=0):
+    """The whole candidate list of a bench.py workload on the GPU and through the oracle (all
+    host cores): scored pixels, per-candidate status and probability, bit for bit."""
+    import bench
+    Mf, e, x, y, upper = bench.build_workload(seed, n, band, w, 6, upper)
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, n, e, -2 * w + 1, upper + 2 * w - 1)
+    hf = _lib.HipForest(fo)
+    cd = _lib.HipCands(x, y)
+    n1 = cd.run(hm, hf, w, thre)
+    ox, oy, op, osig = cd.fetch()
+    st, pr = cd.fetch_all()
+    assert x.size >= min_cands and n1 > 0
+    fod = {k: getattr(fo, k) for k in FlatForest.FIELDS}
+    (rx, ry, rp, rs), st_ref, pr_ref = onp.score_all(Mf, e, w, fod, thre, x, y)
+    assert rx.size == n1
+    assert np.array_equal(ox, rx) and np.array_equal(oy, ry)
+    assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
+    assert np.array_equal(st != 0, st_ref != 0)
+    assert np.array_equal(gio.bits(pr), gio.bits(pr_ref))
+    return x.size, n1
+
+
+def test_w6_full_parity_trained_forest(hip_lib):
+    """The width of every released 5 kb / 10 kb model (README.md:142): w = 6, 30 000 bins,
+    300-bin band, the TRAINED forest_w6_t100 -- all 7.95 M candidates against the oracle."""
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w6_t100.npz"))
+    n_cand, n_pix = _full_parity(6, 30000, 300, 300, fo, min_cands=7_900_000)
+    assert n_pix > 1000
+
+
+def test_config5_full_parity_at_bench_size(hip_lib):
+    """configs[4] exactly as bench.py runs it (-w 11 --forest random:500:20 --bins 8000): 23 x 23
+    windows, 529 features, 500 random trees of depth <= 20, all 1.42 M candidates."""
+    import bench
+    fo = bench.load_forest("random:500:20", 11, 529)
+    n_cand, n_pix = _full_parity(11, 8000, 200, 200, fo, min_cands=1_400_000)
+    assert n_pix > 100_000
+
+
 @pytest.mark.parametrize("w,T,n,band,upper,stride", [(6, 100, 20000, 300, 300, 7),
                                                      (11, 500, 4000, 120, 100, 3),
                                                      (5, 100, 60000, 800, 800, 40)])

@@ -59,6 +59,43 @@ def _extract_golden(name):
         assert L.pk_get_option(b"stat_extract_clean") > clean0
 
 
+@pytest.mark.parametrize("w", [5, 6, 11])
+def test_extract_any_coordinates_golden(hip_lib, w):
+    """G8: the reference's getwindow on lower-triangle coordinates (x > y: served from the
+    stored diagonals), coordinates its mask drops, windows whose columns wrap around column
+    0, through pk_extract and through Chromosome.getwindow; IndexError where scipy raises."""
+    from peakachu_amd import scoreUtils as su
+    z = gio.load("g8_any_coords.npz")
+    p = "w%d_" % w
+    upper = int(z[p + "upper"])
+    M = gio.sym_matrix(z, p + "M")
+    Mf = utils.band_filter(M, w, upper)
+    assert gio.digest(Mf) == str(z[p + "Mf_sha"])
+    x, y = z[p + "x"], z[p + "y"]
+    hm = hip_matrix(Mf, z[p + "exp_arr"], w, upper)
+    f64, f32, keep = hm.extract(w, x, y, want64=True, want32=True)
+    assert np.array_equal(np.stack([x[keep], y[keep]], 1), z[p + "clist"])
+    assert np.array_equal(gio.bits(f64), gio.bits(z[p + "fea"]))
+    assert np.array_equal(f32, z[p + "fea"].astype(np.float32))
+    with pytest.raises(_lib.PeakachuHipError, match="IndexError"):
+        hm.extract(w, z[p + "raises"][:1], z[p + "raises"][1:])
+
+    class _M:  # getwindow never calls the model
+        feature_importances_ = np.zeros((2 * w + 1) ** 2)
+    ch = su.Chromosome(M, _M(), raw_M=M, lower=6, upper=upper, width=w)
+    assert np.array_equal(gio.bits(ch.exp_arr), gio.bits(z[p + "exp_arr"]))
+    fea, clist = ch.getwindow([(int(a), int(b)) for a, b in zip(x, y)])
+    assert np.array_equal(clist, z[p + "clist"])
+    assert np.array_equal(gio.bits(fea), gio.bits(z[p + "fea"]))
+    with pytest.raises(IndexError):
+        ch.getwindow([tuple(int(v) for v in z[p + "raises"])])
+    # a standard call afterwards still takes the fast kernels
+    ok = (x <= y) & (x >= 0) & (y < M.shape[0])
+    f64b, _, keepb = hm.extract(w, x[ok], y[ok])
+    sel = np.flatnonzero(ok)[keepb]
+    assert np.array_equal(gio.bits(f64b), gio.bits(f64[np.searchsorted(keep, sel)]))
+
+
 @pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
 @pytest.mark.parametrize("ilp,lds,slots,pipe,img,q", [
     (4, 0, 8, 0, 0, 0), (1, 0, 8, 0, 0, 0), (8, 0, 8, 0, 0, 0),
@@ -343,6 +380,38 @@ def test_score_vs_oracle_synthetic(hip_lib, w, seed, batch):
     assert np.array_equal(ox, rx) and np.array_equal(oy, ry)
     assert np.array_equal(gio.bits(op), gio.bits(rp))
     assert np.array_equal(gio.bits(osig), gio.bits(rs))
+
+
+@pytest.mark.parametrize("opts", [dict(overlap=1), dict(overlap=1, chunk=4096), dict(chunk=4096), dict()])
+def test_score_twice_with_other_coordinates(hip_lib, opts):
+    """pk_score keeps its device-side candidate list between calls and lends it the caller's
+    host coordinates: a second call with OTHER coordinates (fewer, so the cached list is
+    reused) must score those, under every way the coordinates can travel (up front with
+    the two-stream pipeline, chunk by chunk behind the kernels)."""
+    w, upper = 5, 70
+    M, loops = synth.synth_band(900, 90, seed=11)
+    exp_arr = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    fo = gio.forest("g2_forest_plain.npz")
+    hm = hip_matrix(Mf, exp_arr, w, upper)
+    hf = _lib.HipForest(flat(fo))
+    L = _lib.load()
+    old = {k: L.pk_get_option(k.encode()) for k in opts}
+    for k, v in opts.items():
+        _lib.set_option(k, v)
+    try:
+        lists = [(x, y), (x[1::3].copy(), y[1::3].copy()), (x[::-1][: x.size // 2].copy(), y[::-1][: x.size // 2].copy()),
+                 (x[5:6].copy(), y[5:6].copy()), (x, y)]
+        for xs, ys in lists:
+            got = hm.score(hf, w, 0.3, xs, ys, batch=1000)
+            ref = onp.score(Mf, exp_arr, w, fo, 0.3, xs, ys, batch=1000, threads=8)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+            assert np.array_equal(gio.bits(got[2]), gio.bits(ref[2]))
+            assert np.array_equal(gio.bits(got[3]), gio.bits(ref[3]))
+    finally:
+        for k, v in old.items():
+            _lib.set_option(k, v)
 
 
 def random_forest_arrays(F, T, seed, depth=9):

@@ -193,3 +193,56 @@ def test_genuine_old_sklearn_pickles(tag, name):
     ff = load_model(os.path.join(GOLDEN, name))
     p = onp.predict({k: getattr(ff, k) for k in FlatForest.FIELDS}, z["X"])
     assert np.array_equal(p.view(np.uint64), z["p_" + tag].view(np.uint64))
+
+
+def _reduce_pickle(module, name, *args):
+    """A protocol-2 pickle that calls module.name(*args) when loaded with pickle.load."""
+    out = io.BytesIO()
+    out.write(b"\x80\x02c" + module.encode() + b"\n" + name.encode() + b"\n")
+    out.write(pickle.dumps(tuple(args), protocol=2)[2:-1])  # the argument tuple, without PROTO / STOP
+    out.write(b"R.")
+    return out.getvalue()
+
+
+def test_malicious_pickles_execute_nothing(tmp_path):
+    """The two ways a model file could run code: a global under `numpy.*` that
+    executes its argument, and an object-dtype joblib array (a nested, formerly unrestricted
+    pickle).  Neither may run; what they name becomes an inert placeholder."""
+    marker = tmp_path / "executed"
+    code = "open(%r, 'w').write('x')" % str(marker)
+    # (1) numpy.testing._private.utils.runstring(code, {}) -- execs a string under pickle.load
+    evil1 = _reduce_pickle("numpy.testing._private.utils", "runstring", code, {})
+    # (2) builtins.exec through a nested pickle behind a NumpyArrayWrapper that says dtype 'O'
+    evil_inner = _reduce_pickle("builtins", "exec", code)
+    import joblib.numpy_pickle as jnp
+    buf = io.BytesIO()
+    wrapper = jnp.NumpyArrayWrapper(np.ndarray, (1,), "C", np.dtype("O"), allow_mmap=False)
+    pickle.dump(wrapper, buf, protocol=2)
+    evil2 = buf.getvalue() + evil_inner
+    # sanity: the stock unpickler does run payload (1)
+    pickle.loads(evil1)
+    assert marker.exists()
+    marker.unlink()
+    for k, payload in enumerate((evil1, evil2, evil_inner)):
+        path = tmp_path / ("evil%d.pkl" % k)
+        path.write_bytes(payload)
+        try:
+            obj = sk_pickle.load(str(path))
+        except Exception:
+            obj = None  # refusing the file is as good as neutralising it
+        assert not marker.exists(), "payload %d was executed" % k
+        assert obj is None or isinstance(obj, sk_pickle._Placeholder)
+        with pytest.raises(Exception):
+            load_model(str(path))  # and it certainly is not a forest
+        assert not marker.exists()
+
+
+def test_only_reconstruction_helpers_of_numpy_are_allowed():
+    up = sk_pickle._Unpickler(io.BytesIO(b""))
+    assert up.find_class("numpy", "ndarray") is np.ndarray
+    assert up.find_class("numpy", "dtype") is np.dtype
+    for module, name in (("numpy.testing._private.utils", "runstring"), ("numpy", "load"),
+                         ("numpy.lib.npyio", "load"), ("numpy.random._pickle", "__randomstate_ctor"),
+                         ("os", "system"), ("builtins", "eval"), ("builtins", "exec")):
+        cls = up.find_class(module, name)
+        assert isinstance(cls, type) and issubclass(cls, sk_pickle._Placeholder), (module, name)

@@ -107,8 +107,11 @@ for c, (name, _) in enumerate(chroms):
     for tag, w in (("raw", None), ("weight", weight[lo:hi]), ("KR", kr[lo:hi])):
         # cooler.api.matrix: `mat.data = bias1[mat.row] * bias2[mat.col] * mat.data` -- the two
         # weights are multiplied first, so the mirrored entry gets the identical value
-        # columns named KR / VC / SQRT_VC are divisive in cooler: count / (bias_i * bias_j)
-        vv = v if w is None else (v / (w[i] * w[j]) if tag == "KR" else w[i] * w[j] * v)
+        # columns named KR / VC / SQRT_VC are divisive in cooler: the biases are inverted first
+        # (`bias = 1 / bias`) and then applied like multiplicative ones
+        if tag == "KR":
+            w = 1.0 / w
+        vv = v if w is None else w[i] * w[j] * v
         offd = i != j
         rows = np.concatenate([i, j[offd]]); cols = np.concatenate([j, i[offd]]); vals = np.concatenate([vv, vv[offd]])
         o = np.lexsort((cols, rows))

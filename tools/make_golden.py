@@ -231,6 +231,53 @@ def g1_extract():
          Mf_sha=digest(ch.M), **sym_parts(raw, "R"))
 
 
+# --------------------------------------------------------------------- G8
+def g8_any_coords():
+    """Chromosome.getwindow (scoreUtils.py:70-93) on coordinates get_candidate never makes:
+    lower-triangle pixels (x > y) near the diagonal -- answered from the stored diagonals
+    -2w < col-row, cells below read 0 --, further below it (all-zero windows, dropped),
+    windows whose columns start left of the matrix (x > y, y < w: scipy counts a negative
+    column from the far end), coordinates the mask drops, and the IndexError scipy raises
+    for a row x+w >= n."""
+    out = {}
+    for w, n, band, upper, seed in ((5, 400, 120, 100, 31), (6, 400, 120, 100, 32), (11, 300, 140, 100, 33)):
+        M, loops, dead = holey_band(n, band, seed, decay=1.2)
+        ch = make_chrom(M, _Dummy(), w, upper=upper)
+        rng = np.random.default_rng(seed + 100)
+        k = 260
+        x = rng.integers(w, n - w, size=k)
+        below = rng.integers(1, 3 * w + 3, size=k)          # x - y in [1, 3w+2]
+        y = x - below
+        # some upper-triangle and on-diagonal ones in between, masked ones, wrapped columns
+        xs = np.r_[x, rng.integers(w, n - w, size=40), [w, w + 1, 2 * w, 30, 31, 3, -4, n + 5, 50]]
+        ys = np.r_[y, xs[k:k + 40] + rng.integers(0, 2 * w, size=40), [0, 1, w - 1, 2, w - 2, 40, 9, n + 9, n - 2]]
+        okm = (xs - w >= 0) & (ys + w + 1 <= n)
+        assert not np.any(okm & ((xs + w >= n) | (ys - w < -n)))   # nothing here may raise
+        coords = [(int(a), int(b)) for a, b in zip(xs, ys)]
+        fea, clist = ch.getwindow(coords)
+        fea = np.asarray(fea, np.float64).reshape(-1, (2 * w + 1) ** 2)
+        clist = np.asarray(clist, np.int64).reshape(-1, 2)
+        lower_kept = int(np.sum(clist[:, 0] > clist[:, 1]))
+        wrapped_kept = int(np.sum((clist[:, 0] > clist[:, 1]) & (clist[:, 1] < w)))
+        print("G8 w=%d: %d coords, %d kept, %d of them below the diagonal, %d with wrapped columns"
+              % (w, len(coords), len(clist), lower_kept, wrapped_kept))
+        assert lower_kept > 20
+        # the reference raises where a window row leaves the matrix
+        raised = False
+        try:
+            ch.getwindow([(n - w, n - 3 * w)])
+        except IndexError:
+            raised = True
+        assert raised
+        out.update({"w%d_x" % w: xs.astype(np.int64), "w%d_y" % w: ys.astype(np.int64),
+                    "w%d_fea" % w: fea, "w%d_clist" % w: clist, "w%d_exp_arr" % w: ch.exp_arr,
+                    "w%d_upper" % w: np.int32(upper), "w%d_seed" % w: np.int64(seed),
+                    "w%d_raises" % w: np.array([n - w, n - 3 * w], np.int64),
+                    "w%d_Mf_sha" % w: digest(ch.M)})
+        out.update(sym_parts(M, "w%d_M" % w))
+    save("g8_any_coords.npz", **out)
+
+
 # ---------------------------------------------------------------- G2 + G5
 def train_forest(M, loops, w, T, seed, class_weight=None, n_neg=700):
     n = M.shape[0]
@@ -553,7 +600,11 @@ def main():
     """`make_golden.py` regenerates everything; `make_golden.py g6` only the
     named groups (g2 is always run: the later groups need its forest)."""
     os.makedirs(OUT, exist_ok=True)
-    want = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7"}
+    want = set(sys.argv[1:]) or {"g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"}
+    if "g8" in want:
+        g8_any_coords()
+        if want == {"g8"}:
+            return
     if "g7" in want:
         g7_pool()
         if want == {"g7"}:

@@ -20,6 +20,7 @@ import glob
 import hashlib
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -38,7 +39,11 @@ def source_sha():
 
 def kclass(name):
     n = name.replace(" ", "")
-    if "forest_q_kernel" in n or "forest_img_kernel" in n or "forest_img2_kernel" in n or "forest_lds_kernel" in n:
+    if "forest_q_kernel" in n:
+        # forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>: the full evaluation is PRUNE = false AND
+        # EARLY = false (`<..., true, false>` -- the early-exit extra pass -- also ends in "false>")
+        return "forest" if re.search(r"forest_q_kernel<[^>]*,false,false>", n) else None
+    if "forest_img_kernel" in n or "forest_img2_kernel" in n or "forest_lds_kernel" in n:
         return "forest" if "false>" in n else None
     if "quantize_tiles_kernel" in n:
         return "quant"
