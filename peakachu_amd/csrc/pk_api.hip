@@ -250,6 +250,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.extract_clean = value != 0;
     } else if (!strcmp(name, "extract_pair")) {
         g_opt.extract_pair = value != 0;
+    } else if (!strcmp(name, "extract_row16")) {
+        g_opt.extract_row16 = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
         if (value < 0 || value == 1 || value > 16) return PK_E_INVALID;
         g_opt.forest_slots = value;
@@ -297,6 +299,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_lds")) return g_opt.forest_lds;
     if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
     if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
+    if (!strcmp(name, "extract_row16")) return g_opt.extract_row16;
     if (!strcmp(name, "extract_clean")) return g_opt.extract_clean;
     if (!strcmp(name, "forest_warm")) return g_opt.forest_warm;
     if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
@@ -1124,7 +1127,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     const bool overlap = g_opt.overlap != 0;
     int rc = pk_ctx_reserve_tiles(ctx, (overlap ? 2 : 1) * tile_floats * sizeof(float));
     if (rc) return rc;
-    if ((w == 5 || w == 6) && g_opt.extract_pair && g_opt.extract_clean) {
+    if ((((w == 5 || w == 6) && g_opt.extract_pair) || (w == 11 && g_opt.extract_row16)) && g_opt.extract_clean) {
         rc = pk_matrix_prepare_norm(ctx, m);
         if (rc) return rc;
     }
@@ -1347,7 +1350,8 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     std::vector<double> h_rows((size_t)chunk * F);
     std::vector<uint8_t> h_status((size_t)chunk);
     rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
-    if (!rc && (w == 5 || w == 6) && g_opt.extract_pair && g_opt.extract_clean)
+    if (!rc && (((w == 5 || w == 6) && g_opt.extract_pair) || (w == 11 && g_opt.extract_row16)) &&
+        g_opt.extract_clean)
         rc = pk_matrix_prepare_norm(ctx, m);
     if (!rc) {  // the staging rows live in the context and only ever grow: no allocation per call
         const size_t need = (size_t)chunk * F * sizeof(double);

@@ -70,6 +70,7 @@ struct pk_options {
                                 // (measured: no gain -- kernels that share the chip slow each other down)
     int64_t extract_clean = 1;  // use the pre-divided band + shortcuts when the matrix qualifies
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
+    int64_t extract_row16 = 1;  // w = 11 on clean matrices: four register-blocked windows per wave
     int64_t forest_warm = 1;    // last tree group: pull the tile of workgroup id + N into this XCD's L2
                                 // (0 = off, 1 = N = number of CUs: the workgroup that follows on this XCD)
     int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit

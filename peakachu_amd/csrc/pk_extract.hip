@@ -725,6 +725,235 @@ __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) vo
 }
 
 // ------------------------------------------------------------------------
+// Wide windows on clean matrices (w = 8 .. 15; instantiated for w = 11, the 23 x 23 / 529-
+// feature stress configuration): FOUR windows per wave, one per 16-lane DPP row, the window
+// register-blocked.
+//
+// The one-window-per-wave kernel below keeps the window in LDS and is bound by LDS
+// instructions (~400 per window: 220 tap reads, the 121 reads of the sequential top-left sum,
+// the window writes) and by its 529 divisions.  Here
+//   * lane l of a row holds window COLUMNS l and l + 16 in registers (2 x S doubles): the
+//     axis-0 blur (scipy's first pass, along the rows i of one column) is lane-local;
+//   * the columns come from the pre-divided band (norm_band_kernel): no division per cell;
+//   * one transpose through LDS (S writes + S reads of 8 bytes per lane and slot; window
+//     buffers 16 (mod 32) doubles apart, so the 16 rows a read instruction touches in two
+//     windows fall into disjoint bank pairs) turns columns into ROWS l and l + 16: the
+//     axis-1 blur is lane-local again;
+//   * numba's sequential top-left sum (utils.py:228: C order, one rounding per add) runs as
+//     a chain through the lanes of the row: the partial sum travels lane j-1 -> lane j by
+//     DPP (row_shr:1; row_shl:W-1 back to lane 0 at the end of a window row) and every lane
+//     adds its own column's value -- W*W dependent adds for FOUR windows at once;
+//   * min / max are row reductions, the 2 x S divisions of the min-max scaling share one
+//     refined reciprocal (exact under the clean matrix's bounds, see the w = 5 kernel).
+// ------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_lane_f64(double v, int src_lane)  // value of lane `src_lane`
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+template <int W>
+struct row16_geom {
+    static constexpr int S = 2 * W + 1, F = S * S;
+    static constexpr int NS = (S + 15) / 16;             // column (row) slots per lane
+    static constexpr int TS = F + ((16 - F % 32) + 32) % 32;  // window stride in LDS, 16 (mod 32) doubles
+};
+
+template <int W, bool FEA64>
+__global__ __launch_bounds__(64, 2) void extract_row16_clean_kernel(
+    const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
+    const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
+    float *__restrict__ tiles, int blk, uint8_t *__restrict__ status,
+    double *__restrict__ fea64_rows)
+{
+    using G = row16_geom<W>;
+    constexpr int S = G::S, F = G::F, NS = G::NS, TS = G::TS;
+    static_assert(S > 16 && S <= 32 && NS == 2, "two column slots per lane");
+    static_assert(W >= 4, "reflect folds once");
+    __shared__ double T[4 * TS];
+    const unsigned lane = threadIdx.x, q = lane >> 4, l = lane & 15;
+    // XCD-aware order (see the w = 5 kernel): XCD x takes the x-th contiguous eighth
+    const unsigned per_xcd = gridDim.x >> 3;
+    const int64_t wave0 = (int64_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * 4;
+    const int64_t local = wave0 + q;
+    const bool in_range = local < cn;
+    const int64_t c = c0 + (in_range ? local : 0);
+    const int xi = xs[c], yi = ys[c];
+    bool ok = in_range && (xi - W >= 0 && yi + W + 1 <= n) && PK_OTHER_EDGES(xi, yi, W, n);
+    const unsigned long long okmask = __ballot(ok);
+    if (okmask == 0ull) {  // wave-uniform
+        if (in_range && l == 0) status[c] = 0;
+        return;
+    }
+    // rows without a window shadow the first valid one of the wave (every load stays in range)
+    const int lead = __builtin_ctzll(okmask);
+    const int xc = ok ? xi : __builtin_amdgcn_readlane(xi, lead);
+    const int yc = ok ? yi : __builtin_amdgcn_readlane(yi, lead);
+    const int d = yc - xc;
+    const bool normalise = max(iabs(d - 2 * W), iabs(d + 2 * W)) < exp_len;
+    const bool inside = (d - 2 * W >= dlo) && (d + 2 * W <= dhi);
+    const bool fast = __all(inside);
+
+    const char *bbase = reinterpret_cast<const char *>(band);
+    const int ld8 = ld * 8;
+    const unsigned raw0 = (unsigned)(((int64_t)(d - dlo) * ld + (xc - W)) * 8);
+    const unsigned row0 = raw0 + (normalise ? norm_off : 0u);
+    // byte offset of window cell (i, j): base + i * 8 + (j - i) * ld * 8
+#define PK_CELL(base_, i_, j_) \
+    (*reinterpret_cast<const double *>(bbase + (unsigned)((base_) + (i_) * 8 + __mul24((int)(j_) - (i_), ld8))))
+    int jj[NS];
+    bool jv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        jv[s] = (int)l + 16 * s < S;
+        jj[s] = jv[s] ? (int)l + 16 * s : (int)l;  // a slot without a column shadows slot 0
+    }
+    // ---- the window, column-wise (scoreUtils.py:77-82; pre-divided: utils.py:180-202)
+    double colv[NS][S];
+    double rawc[W + 1];  // raw counts of rows 0..W of column l: the top-left block and the centre
+    if (fast) {
+        if (normalise) {
+#pragma unroll
+            for (int i = 0; i <= W; i++) rawc[i] = PK_CELL(raw0, i, l);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+#pragma unroll
+            for (int i = 0; i < S; i++) colv[s][i] = PK_CELL(row0, i, jj[s]);
+        }
+    } else {
+        if (normalise) {
+#pragma unroll
+            for (int i = 0; i <= W; i++) {
+                const int k = d + (int)l - i;
+                rawc[i] = (k >= dlo && k <= dhi) ? PK_CELL(raw0, i, l) : 0.0;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+#pragma unroll
+            for (int i = 0; i < S; i++) {
+                const int k = d + jj[s] - i;
+                colv[s][i] = (k >= dlo && k <= dhi) ? PK_CELL(row0, i, jj[s]) : 0.0;
+            }
+        }
+    }
+#undef PK_CELL
+    if (!normalise) {
+#pragma unroll
+        for (int i = 0; i <= W; i++) rawc[i] = colv[0][i];
+    }
+    // ---- utils.py:228: window[:w, :w].mean() as numba computes it -- sequentially in C order.
+    // Step (i, j): lane j receives the partial sum from the lane that made step (i, j) - 1 and
+    // adds its own cell; the other lanes compute along (their values are never used).
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+#pragma unroll
+        for (int j = 0; j < W; j++) {
+            if (j > 0) acc = dpp_f64<0x111>(acc);                   // row_shr:1  lane j <- lane j-1
+            else if (i > 0) acc = dpp_f64<0x100 + (W - 1)>(acc);    // row_shl:W-1  lane 0 <- lane W-1
+            acc = acc + rawc[i];
+        }
+    }
+    const int row_base = (int)(q << 4);
+    const double ll_sum = row_lane_f64(acc, row_base + W - 1);
+    const double centre = row_lane_f64(rawc[W], row_base + W);
+    const double ll_mean = ll_sum / (double)(W * W);
+    ok = ok && (ll_mean > 0.0);
+    const double p2ll = centre / ll_mean;  // utils.py:230-232
+    ok = ok && (p2ll > 0.1);
+    // ---- utils.py:221-225 sparsity filter (quotient != 0 <=> count != 0 on a clean matrix)
+    int nnz = 0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+#pragma unroll
+        for (int i = 0; i < S; i++) nnz += (jv[s] && colv[s][i] != 0.0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 16);
+    ok = ok && !((double)nnz < (double)F * 0.1);
+    // ---- gaussian_filter(sigma=1), axis 0: down each column, straight into the transpose buffer
+    double *Tq = T + q * TS;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const double v = PK_BLUR9(colv[s][i], colv[s][reflect_idx(i - 4, S)], colv[s][reflect_idx(i + 4, S)],
+                                      colv[s][reflect_idx(i - 3, S)], colv[s][reflect_idx(i + 3, S)],
+                                      colv[s][reflect_idx(i - 2, S)], colv[s][reflect_idx(i + 2, S)],
+                                      colv[s][reflect_idx(i - 1, S)], colv[s][reflect_idx(i + 1, S)]);
+            if (jv[s]) Tq[i * S + jj[s]] = v;
+        }
+    }
+    __syncthreads();  // (one wave: orders this wave's LDS writes before its reads)
+    // ---- axis 1: lane l now owns window ROWS l and l + 16
+    double outv[NS][S];
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        double rowv[S];
+        const double *Tr = Tq + jj[s] * S;  // (row index = the same slot arithmetic as the columns)
+#pragma unroll
+        for (int j = 0; j < S; j++) rowv[j] = Tr[j];
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            outv[s][j] = PK_BLUR9(rowv[j], rowv[reflect_idx(j - 4, S)], rowv[reflect_idx(j + 4, S)],
+                                  rowv[reflect_idx(j - 3, S)], rowv[reflect_idx(j + 3, S)],
+                                  rowv[reflect_idx(j - 2, S)], rowv[reflect_idx(j + 2, S)],
+                                  rowv[reflect_idx(j - 1, S)], rowv[reflect_idx(j + 1, S)]);
+            if (jv[s]) {
+                mn = __builtin_fmin(mn, outv[s][j]);
+                mx = __builtin_fmax(mx, outv[s][j]);
+            }
+        }
+    }
+    // ---- utils.py:204-209 image_normalize
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        mn = __builtin_fmin(mn, __shfl_xor(mn, o, 16));
+        mx = __builtin_fmax(mx, __shfl_xor(mx, o, 16));
+    }
+    const double den = mx - mn;
+    const bool flat = !(den > 0.0);  // constant window: 0 / 0
+    const int64_t first = local / blk;
+    float *tp = tiles + (size_t)first * F * blk + (int)(local - first * blk);
+    double *rp = FEA64 ? fea64_rows + (size_t)local * F : nullptr;
+    double r = 0.0, qn = 0.0;
+    if (flat) {
+        qn = (mn - mn) / den;  // the true division
+    } else {
+        r = __builtin_amdgcn_rcp(den);
+        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    }
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            const double a = outv[s][j] - mn;
+            const double m = a * r;
+            const double v = flat ? qn : __builtin_fma(__builtin_fma(-den, m, a), r, m);
+            if (ok && jv[s]) {
+                const int f = jj[s] * S + j;
+                tp[(size_t)f * blk] = (float)v;  // sklearn's float32 cast (RNE)
+                if (FEA64) rp[f] = v;
+            }
+        }
+    }
+    if (in_range && l == 0) status[c] = ok ? (flat ? 2 : 1) : 0;
+}
+
+// ------------------------------------------------------------------------
 // Generic kernel (any w <= 15): one candidate per 64-lane wave, window in LDS.
 // Used for w = 11 (23x23, 529 features) where a window no longer fits one
 // lane's registers.  Same operation order as above.
@@ -1030,6 +1259,27 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
             return PK_E_UNSUPPORTED;
         }
         const int F = (2 * w + 1) * (2 * w + 1);
+        // w = 11 on a clean matrix: four register-blocked windows per wave (32-bit offsets, as
+        // the clean w = 5 / 6 kernel)
+        const bool row16 = w == 11 && g_opt.extract_row16 != 0 && m->norm != nullptr && m->clean &&
+                           g_opt.extract_clean != 0 && m->ld < (1 << 20) && blk % 4 == 0 &&
+                           ((size_t)((cn + blk - 1) / blk) * blk * F * sizeof(float) < (1ull << 33));
+        if (row16) {
+            g_stat_extract_clean++;
+            const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
+            const unsigned grid4 = (unsigned)(((cn + 3) / 4 + 7) & ~(int64_t)7);
+            if (fea64_rows)
+                hipLaunchKernelGGL((extract_row16_clean_kernel<11, true>), dim3(grid4), dim3(64), 0, st, m->band,
+                                   norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,
+                                   tiles, blk, d_status, fea64_rows);
+            else
+                hipLaunchKernelGGL((extract_row16_clean_kernel<11, false>), dim3(grid4), dim3(64), 0, st, m->band,
+                                   norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,
+                                   tiles, blk, d_status, fea64_rows);
+            PK_HIP(hipGetLastError());
+            return PK_OK;
+        }
+        g_stat_extract_general++;
         const size_t lds = (size_t)GEN_WAVES * 2 * F * sizeof(double);
         const unsigned grid = (unsigned)((cn + GEN_WAVES - 1) / GEN_WAVES);
         if (w == 11)

@@ -454,10 +454,16 @@ def test_empty_and_edge_inputs(hip_lib):
     y = np.array([10, 12, n - 2, n - 1], np.int32)
     f64, _, keep = hm.extract(w, x, y)
     assert keep.size == 0
+    # getwindow takes any coordinates (round 3; G8 pins the values): below the diagonal is
+    # answered, outside the matrix is dropped, as in the reference
+    f64, _, keep = hm.extract(w, np.array([50, 50, -3], np.int32), np.array([40, n, 20], np.int32))
+    ref, rkeep = onp.extract(Mf, z["exp_arr"], w, np.array([50, 50, -3]), np.array([40, n, 20]))
+    assert np.array_equal(keep, rkeep) and np.array_equal(gio.bits(f64), gio.bits(ref))
+    with pytest.raises(_lib.PeakachuHipError, match="IndexError"):
+        hm.extract(w, np.array([n - 2], np.int32), np.array([n - 40], np.int32))  # a row beyond the matrix
+    # pk_score keeps its contract: candidates are upper-triangle pixels of the matrix
     with pytest.raises(_lib.PeakachuHipError):
-        hm.extract(w, np.array([50], np.int32), np.array([40], np.int32))  # x > y
-    with pytest.raises(_lib.PeakachuHipError):
-        hm.extract(w, np.array([50], np.int32), np.array([n], np.int32))   # outside
+        hm.score(hf, w, 0.5, np.array([50], np.int32), np.array([40], np.int32))
 
 
 def test_chromosome_drop_in(hip_lib, tmp_path):
