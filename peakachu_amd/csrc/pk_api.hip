@@ -243,6 +243,9 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_lds = value;
     } else if (!strcmp(name, "overlap")) {
         g_opt.overlap = value != 0;
+    } else if (!strcmp(name, "sub_chunk")) {
+        if (value < 0) return PK_E_INVALID;
+        g_opt.sub_chunk = value;
     } else if (!strcmp(name, "forest_warm")) {
         if (value < 0) return PK_E_INVALID;
         g_opt.forest_warm = value;
@@ -305,6 +308,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
     if (!strcmp(name, "stat_extract_general")) return g_stat_extract_general;
     if (!strcmp(name, "overlap")) return g_opt.overlap;
+    if (!strcmp(name, "sub_chunk")) return g_opt.sub_chunk;
     if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
     if (!strcmp(name, "forest_l2_tile")) return g_opt.forest_l2_tile;
     if (!strcmp(name, "early_exit")) return g_opt.early_exit;
@@ -1179,6 +1183,28 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         if (overlap && k >= 2)  // forest(k-2) must be done with this buffer
             PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[buf], 0));
         if (stream_coords) PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[k & 1], 0));
+        // rank kernels: the float tiles are an intermediate of this chunk only (extractor ->
+        // quantizer); made and consumed piece by piece through the start of the buffer they
+        // never have to leave the Infinity Cache
+        int64_t sub = (g_opt.sub_chunk + blk - 1) / blk * blk;
+        const bool pieces = !overlap && sub > 0 && sub < cn && f->plan_kind == 2 && f->q_state == 1 &&
+                            blk == (f->q_ch == 1 ? 128 : 128 * PK_Q_FTILE);
+        if (pieces) {
+            rc = pk_forest_q_reserve(ctx, f, cn);
+            for (int64_t s0 = 0; !rc && s0 < cn; s0 += sub) {
+                const int64_t sn = cn - s0 < sub ? cn - s0 : sub;
+                rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0 + s0, sn, tiles, blk, cd->status,
+                                       nullptr);
+                if (!rc) rc = pk_launch_quant_q(ctx, ctx->stream, f, tiles, s0 / 128, sn);
+            }
+            if (!rc) rc = pk_launch_forest_q_walk(ctx, f, cd->status, c0, cn, cd->prob, prune_sum);
+            if (rc) return rc;
+            if (stream_coords && c0 + cn < cd->N) {
+                rc = upload(c0 + cn, k + 1);
+                if (rc) return rc;
+            }
+            continue;
+        }
         rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0, cn, tiles, blk, cd->status,
                                nullptr);
         if (rc) return rc;

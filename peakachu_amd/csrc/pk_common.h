@@ -66,6 +66,14 @@ struct pk_options {
     int64_t forest_slots = 0;   // LDS kernel: tree slots (wave pairs) per workgroup; 0 = as many as
                                 // average trees fit beside the tile (8 at w=5, 7 at w=6)
     int64_t forest_lds = 160;   // KiB cap of the LDS tree buffer (0 = read nodes via L2)
+    // rank kernels: extract + quantize in pieces of this many candidates, every piece through
+    // the START of the float tile buffer (so that it stays in the 256 MB Infinity Cache between
+    // the extractor's stores and the quantizer's loads); 0 = the whole chunk at once (default).
+    // MEASURED (round 3, config 2, ms per step extract / quantizer): whole chunk 1.21 / 0.95,
+    // 512 Ki 1.34 / 1.16, 256 Ki 1.49 / 1.31, 128 Ki 1.69 / 2.21 -- both kernels want launches of
+    // >= 1 M candidates (the quantizer loads 24 KB of tables per block), which costs more than
+    // the cache residency gives
+    int64_t sub_chunk = 0;
     int64_t overlap = 0;        // 1: extract(k+1) on a second stream as soon as its tile buffer is free
                                 // (measured: no gain -- kernels that share the chip slow each other down)
     int64_t extract_clean = 1;  // use the pre-divided band + shortcuts when the matrix qualifies
@@ -268,6 +276,12 @@ int pk_forest_q_plan(pk_forest *f);   // PK_OK when the rank image applies (buil
 void pk_forest_q_release(pk_forest *f);
 int pk_launch_forest_q(pk_device_ctx *, pk_forest *f, const float *tiles, const uint8_t *d_status,
                        int64_t c0, int64_t cn, double *d_prob, double prune_sum);
+// the same in three steps (run_pipeline quantizes sub-chunk by sub-chunk from a cache-resident
+// float buffer and walks the whole chunk at once)
+int pk_forest_q_reserve(pk_device_ctx *, pk_forest *f, int64_t cn);
+int pk_launch_quant_q(pk_device_ctx *, hipStream_t st, pk_forest *f, const float *tiles, int64_t t0, int64_t cn);
+int pk_launch_forest_q_walk(pk_device_ctx *, pk_forest *f, const uint8_t *d_status, int64_t c0, int64_t cn,
+                            double *d_prob, double prune_sum);
 
 // (re)build f->grp for this launch shape; returns PK_OK or an error code
 int pk_forest_groups(pk_forest *f, int tree_words, int slots);

@@ -740,9 +740,8 @@ __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) vo
 //     windows fall into disjoint bank pairs) turns columns into ROWS l and l + 16: the
 //     axis-1 blur is lane-local again;
 //   * numba's sequential top-left sum (utils.py:228: C order, one rounding per add) runs as
-//     a chain through the lanes of the row: the partial sum travels lane j-1 -> lane j by
-//     DPP (row_shr:1; row_shl:W-1 back to lane 0 at the end of a window row) and every lane
-//     adds its own column's value -- W*W dependent adds for FOUR windows at once;
+//     W*W dependent additions in every lane: the cell (i, j) is broadcast from lane j to its
+//     row by DPP (row_newbcast:j), beside the chain -- FOUR windows at once;
 //   * min / max are row reductions, the 2 x S divisions of the min-max scaling share one
 //     refined reciprocal (exact under the clean matrix's bounds, see the w = 5 kernel).
 // ------------------------------------------------------------------------
@@ -759,6 +758,16 @@ __device__ __forceinline__ double row_lane_f64(double v, int src_lane)  // value
     const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
     return __hiloint2double(hi, lo);
+}
+
+// out[j] = the value lane j of the row holds, j = 0 .. N-1 (row_newbcast:j)
+template <int N, int J = 0>
+__device__ __forceinline__ void row_bcast_all(double v, double (&out)[N])
+{
+    if constexpr (J < N) {
+        out[J] = dpp_f64<0x150 + J>(v);
+        row_bcast_all<N, J + 1>(v, out);
+    }
 }
 
 template <int W>
@@ -853,21 +862,32 @@ __global__ __launch_bounds__(64, 2) void extract_row16_clean_kernel(
         for (int i = 0; i <= W; i++) rawc[i] = colv[0][i];
     }
     // ---- utils.py:228: window[:w, :w].mean() as numba computes it -- sequentially in C order.
-    // Step (i, j): lane j receives the partial sum from the lane that made step (i, j) - 1 and
-    // adds its own cell; the other lanes compute along (their values are never used).
+    // Cell (i, j) lives in lane j: it is broadcast to the lanes of its row (row_newbcast:j, two
+    // 32-bit DPP moves that do not depend on the sum), and every lane adds it: the dependent
+    // chain is the W*W additions alone, the broadcasts of the next cells run beside them.
+    // (First version: the partial sum itself travelled from lane to lane, two DPP moves
+    // inside every link of the chain.)
+    // (left alone the compiler hoists all W*W broadcasts -- 242 live registers, 118 spills --
+    // and scheduling fences derail its register allocation elsewhere: the source of row i+1's
+    // broadcasts is tied to the sum as it stands BEFORE row i by an empty asm, so at most two
+    // rows of broadcasts are ever live)
     double acc = 0.0;
+    double rowc[W], rown[W];
+    row_bcast_all<W>(rawc[0], rowc);
 #pragma unroll
     for (int i = 0; i < W; i++) {
-#pragma unroll
-        for (int j = 0; j < W; j++) {
-            if (j > 0) acc = dpp_f64<0x111>(acc);                   // row_shr:1  lane j <- lane j-1
-            else if (i > 0) acc = dpp_f64<0x100 + (W - 1)>(acc);    // row_shl:W-1  lane 0 <- lane W-1
-            acc = acc + rawc[i];
+        if (i + 1 < W) {
+            double src = rawc[i + 1];
+            asm volatile("" : "+v"(src) : "v"(acc));
+            row_bcast_all<W>(src, rown);
         }
+#pragma unroll
+        for (int j = 0; j < W; j++) acc = acc + rowc[j];
+#pragma unroll
+        for (int j = 0; j < W; j++) rowc[j] = rown[j];
     }
-    const int row_base = (int)(q << 4);
-    const double ll_sum = row_lane_f64(acc, row_base + W - 1);
-    const double centre = row_lane_f64(rawc[W], row_base + W);
+    const double ll_sum = acc;
+    const double centre = dpp_f64<0x150 + W>(rawc[W]);
     const double ll_mean = ll_sum / (double)(W * W);
     ok = ok && (ll_mean > 0.0);
     const double p2ll = centre / ll_mean;  // utils.py:230-232

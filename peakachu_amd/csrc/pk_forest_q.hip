@@ -734,18 +734,15 @@ int pk_forest_q_plan(pk_forest *f)
         else Q_LAUNCH_P(CH, WPT, HALF1, false, EARLY);                                         \
     } while (0)
 
-int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, const uint8_t *d_status,
-                       int64_t c0, int64_t cn, double *d_prob, double prune_sum)
+// Room for the rank tiles of `cn` candidates (scratch of the context; grows only).
+int pk_forest_q_reserve(pk_device_ctx *ctx, pk_forest *f, int64_t cn)
 {
-    if (cn <= 0) return PK_OK;
     if (f->q_state != 1 || !f->q_layout) {
         pk_set_error("forest rank kernel launched without a rank image (internal error)");
         return PK_E_INVALID;
     }
-    const pk_q_layout &L = *f->q_layout;
-    const int F = f->F;
     const int64_t n_tiles = (cn + 127) / 128;
-    const size_t qbytes = (size_t)n_tiles * F * 128 * sizeof(unsigned short);
+    const size_t qbytes = (size_t)n_tiles * f->F * 128 * sizeof(unsigned short);
     if (qbytes > ctx->q_tiles_bytes) {
         if (ctx->q_tiles) {
             PK_HIP(hipStreamSynchronize(ctx->stream));
@@ -756,18 +753,52 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
         PK_HIP(hipMalloc((void **)&ctx->q_tiles, qbytes));
         ctx->q_tiles_bytes = qbytes;
     }
-    {
-        pk_prof_scope prof(ctx, PK_K_QUANT);
-        // enough blocks per feature to fill the chip, few enough that the tables are
-        // loaded for many tiles each
-        int64_t split = (n_tiles + 255) / 256;
-        if (split > 64) split = 64;
-        if (split < 1) split = 1;
-        hipLaunchKernelGGL(quantize_tiles_kernel, dim3((unsigned)F, (unsigned)split), dim3(256), 0,
-                           ctx->stream, tiles, n_tiles, F, f->q_thr, f->q_off, f->q_lut, f->q_par,
-                           ctx->q_tiles, L.ch == 1 ? 1 : 0);
-        PK_HIP(hipGetLastError());
+    return PK_OK;
+}
+
+// float tiles of candidates [t0 * 128, t0 * 128 + cn) of a chunk -> their rank tiles.  `tiles`
+// holds the floats of THOSE candidates from its start (option sub_chunk: the extractor of a
+// piece writes from the start of the buffer every time), the rank tiles go to tile t0 onwards.
+int pk_launch_quant_q(pk_device_ctx *ctx, hipStream_t st, pk_forest *f, const float *tiles, int64_t t0,
+                      int64_t cn)
+{
+    if (cn <= 0) return PK_OK;
+    const pk_q_layout &L = *f->q_layout;
+    const int F = f->F;
+    const int64_t n_tiles = (cn + 127) / 128;
+    pk_prof_scope prof(ctx, PK_K_QUANT, st);
+    // enough blocks per feature to fill the chip, few enough that the tables are
+    // loaded for many tiles each
+    int64_t split = (n_tiles + 255) / 256;
+    if (split > 64) split = 64;
+    if (split < 1) split = 1;
+    hipLaunchKernelGGL(quantize_tiles_kernel, dim3((unsigned)F, (unsigned)split), dim3(256), 0, st, tiles,
+                       n_tiles, F, f->q_thr, f->q_off, f->q_lut, f->q_par,
+                       ctx->q_tiles + (size_t)t0 * F * 128, L.ch == 1 ? 1 : 0);
+    PK_HIP(hipGetLastError());
+    return PK_OK;
+}
+
+int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, const uint8_t *d_status,
+                       int64_t c0, int64_t cn, double *d_prob, double prune_sum)
+{
+    if (cn <= 0) return PK_OK;
+    int rc = pk_forest_q_reserve(ctx, f, cn);
+    if (!rc) rc = pk_launch_quant_q(ctx, ctx->stream, f, tiles, 0, cn);
+    if (!rc) rc = pk_launch_forest_q_walk(ctx, f, d_status, c0, cn, d_prob, prune_sum);
+    return rc;
+}
+
+// the walk over the rank tiles of candidates [c0, c0 + cn) (tile 0 = candidate c0)
+int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_status, int64_t c0, int64_t cn,
+                            double *d_prob, double prune_sum)
+{
+    if (cn <= 0) return PK_OK;
+    if (f->q_state != 1 || !f->q_layout) {
+        pk_set_error("forest rank kernel launched without a rank image (internal error)");
+        return PK_E_INVALID;
     }
+    const pk_q_layout &L = *f->q_layout;
     pk_prof_scope prof(ctx, PK_K_FOREST);
     const int C = 64 * L.ch;
     unsigned grid = (unsigned)((cn + C - 1) / C);

@@ -74,7 +74,7 @@ def test_config2_properties(config2):
     # invariance to chunking and kernel variant
     old = {k: _lib.load().pk_get_option(k.encode())
            for k in ("chunk", "forest_slots", "forest_lds", "forest_pipe", "forest_pipe_slots",
-                     "extract_pair", "overlap", "forest_img", "forest_q", "forest_q_ch",
+                     "extract_pair", "overlap", "sub_chunk", "forest_img", "forest_q", "forest_q_ch",
                      "forest_q_persist")}
     try:
         for opts in (dict(chunk=65536), dict(chunk=1000003), dict(forest_slots=12), dict(forest_q_ch=2),
@@ -85,7 +85,8 @@ def test_config2_properties(config2):
                      dict(forest_q=0, forest_img=0, forest_pipe=0, forest_slots=4),
                      dict(forest_q=0, forest_img=0, forest_pipe=2),
                      dict(forest_q=0, forest_img=0, forest_pipe=2, forest_pipe_slots=4),
-                     dict(forest_lds=0), dict(extract_pair=0), dict(overlap=1), dict(overlap=1, chunk=65536)):
+                     dict(forest_lds=0), dict(extract_pair=0), dict(overlap=1), dict(overlap=1, chunk=65536),
+                     dict(sub_chunk=262144), dict(sub_chunk=100000, chunk=1000000)):
             for k, v in opts.items():
                 _lib.set_option(k, v)
             cd2 = _lib.HipCands(x, y)

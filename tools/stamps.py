@@ -9,9 +9,11 @@ import bench
 from peakachu_amd import _lib
 from peakachu_amd.forest import FlatForest
 
+# usage: stamps.py [bins [w [forest spec]]]   (defaults: config 2's shape; `11 random:500:20` = config 5)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
-Mf, e, x, y, upper = bench.build_workload(0, n, 200, 5, 6, 200)
-fo = FlatForest.load("peakachu_amd/data/forest_w5_t100.npz")
+w = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+Mf, e, x, y, upper = bench.build_workload(0, n, 200, w, 6, 200)
+fo = bench.load_forest(sys.argv[3] if len(sys.argv) > 3 else None, w, (2 * w + 1) ** 2)
 L = _lib.require_device()
 dbg_extra = 0
 for kv in filter(None, os.environ.get("PK_OPTS", "").split(",")):
@@ -20,12 +22,12 @@ for kv in filter(None, os.environ.get("PK_OPTS", "").split(",")):
         dbg_extra = int(v)
     else:
         _lib.set_option(k, int(v))
-hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -9, upper + 9)
+hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -2 * w + 1, upper + 2 * w - 1)
 hf = _lib.HipForest(fo)
 cd = _lib.HipCands(x, y)
-cd.run(hm, hf, 5, 0.5)
+cd.run(hm, hf, w, 0.5)
 _lib.set_option("forest_dbg", 16 | dbg_extra)
-cd.run(hm, hf, 5, 0.5)
+cd.run(hm, hf, w, 0.5)
 _lib.set_option("forest_dbg", 0)
 buf = np.zeros(16 * 32 * 5, np.int64)
 _lib.check(L.pk_debug_read(0, buf, buf.size), "dbg")
