@@ -12,7 +12,16 @@ from scipy import sparse, stats
 
 
 def tocsr(X):
-    """peakachu/utils.py:10-15."""
+    """peakachu/utils.py:10-15.  A matrix from this package's own `.cool` reader arrives in
+    canonical order with its row pointer attached (cool.sparse_coo): the CSR is then assembled
+    from the parts, as long as nobody has touched the COO arrays since."""
+    parts = getattr(X, "_pk_csr_parts", None)
+    if parts is not None and parts[1] is X.col and parts[2] is X.data:
+        indptr, col, data = parts
+        out = sparse.csr_matrix((data.astype(float), col, indptr), shape=X.shape)
+        out.has_sorted_indices = True
+        out.has_canonical_format = True
+        return out
     return sparse.csr_matrix((X.data, (X.row, X.col)), shape=X.shape, dtype=float)
 
 

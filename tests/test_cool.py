@@ -123,3 +123,45 @@ def test_libver_latest_files():
                 e = ramp(a.size)
                 assert np.array_equal(f[k][1001:7777], e[1001:7777]), k
             assert a.dtype == np.int16 and np.array_equal(a, e), k
+
+
+def test_fetch_hands_utils_tocsr_a_ready_made_csr():
+    """The matrix a fetch returns is a coo_matrix in canonical order with its row pointer attached;
+    utils.tocsr (the reference's next step, peakachu/utils.py:10-15) assembles the CSR from the
+    parts -- the same CSR the plain COO -> CSR conversion makes -- unless the arrays were replaced."""
+    from peakachu_amd import utils
+    c = cool.CoolFile(os.path.join(G, "cool_small.cool"))
+    for bal in (False, "weight", "KR"):
+        X = c.matrix(balance=bal, sparse=True).fetch("chr1")
+        assert sparse.isspmatrix_coo(X) and X._pk_csr_parts[1] is X.col
+        key = np.lexsort((X.col, X.row))
+        assert np.array_equal(key, np.arange(key.size))  # canonical order
+        fast = utils.tocsr(X)
+        assert fast.has_canonical_format and fast.data.dtype == np.float64
+        slow = sparse.csr_matrix((X.data, (X.row, X.col)), shape=X.shape, dtype=float)
+        slow.sum_duplicates()
+        slow.sort_indices()
+        for k in ("indptr", "indices"):
+            assert np.array_equal(getattr(fast, k), getattr(slow, k))
+        assert np.array_equal(fast.data.view(np.uint64), slow.data.view(np.uint64))
+        X.data = X.data * 2.0  # a caller who edits the COO gets the plain conversion
+        assert np.array_equal(utils.tocsr(X).data.view(np.uint64), (slow.data * 2.0).view(np.uint64))
+    c.close()
+
+
+def test_mirror_by_scatter_equals_the_transposed_sum():
+    """Pixel lists with explicit zero counts take the numpy path (scipy's sorted-row addition
+    would drop the zeros): same canonical order, zeros kept."""
+    rng = np.random.default_rng(5)
+    n = 300
+    i = np.sort(rng.integers(0, n, 4000)).astype(np.int32)
+    j = np.minimum(i + rng.integers(0, 40, i.size), n - 1).astype(np.int32)
+    key = np.unique(i.astype(np.int64) * n + j)
+    i, j = (key // n).astype(np.int32), (key % n).astype(np.int32)
+    v = rng.integers(0, 5, i.size).astype(np.int32)  # zeros among them
+    row, col, val, indptr = cool.CoolFile._mirror_by_scatter(i, j, v, n)
+    off = i != j
+    R, Cc, V = np.r_[i, j[off]], np.r_[j, i[off]], np.r_[v, v[off]]
+    o = np.lexsort((Cc, R))
+    assert np.array_equal(row, R[o]) and np.array_equal(col, Cc[o]) and np.array_equal(val, V[o])
+    assert np.array_equal(indptr, np.searchsorted(R[o], np.arange(n + 1)))
