@@ -118,10 +118,12 @@ class CoolFile:
         p0, p1 = int(off[0]), int(off[-1])
         # pixels are sorted by (bin1, bin2): bin1 follows from the index, no need to read it
         i = np.repeat(np.arange(n, dtype=np.int32), np.diff(off))
-        j = (self._g["pixels/bin2_id"][p0:p1].astype(np.int64) - lo)
+        j = self._g["pixels/bin2_id"][p0:p1]
         v = self._g["pixels/count"][p0:p1]
-        cis = j < n  # bin2 >= bin1 >= lo always; drop the trans pixels
-        i, j, v = i[cis], j[cis].astype(np.int32), v[cis]
+        cis = j < hi  # bin2 >= bin1 >= lo always; drop the trans pixels
+        j = (j - lo).astype(np.int32)
+        if not cis.all():
+            i, j, v = i[cis], j[cis], v[cis]
         # The mirrored matrix in CANONICAL order (row-major, columns ascending) without a sort of
         # the pixel list: upper part U = the file's own order (a canonical CSR as it stands),
         # lower part = the transpose of U without its diagonal (scipy's csc -> csr, a counting

@@ -21,6 +21,23 @@ library wrote (tests/golden/cool_small*.cool, tools/make_cool_fixture.py).
 import struct
 import zlib
 
+_POOL = None
+
+
+def _inflate_pool():
+    """Worker threads for chunk inflation (made on first use; sized to the CPUs this process
+    may use, at most 8)."""
+    global _POOL
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            n = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n = os.cpu_count() or 1
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, n)), thread_name_prefix="h5lite-inflate")
+    return _POOL
+
 import numpy as np
 
 SIGNATURE = b"\x89HDF\r\n\x1a\n"
@@ -395,6 +412,7 @@ class Dataset:
         import bisect
         starts = [ch[0][0] for ch in chunks]
         k = max(0, bisect.bisect_right(starts, lo) - 1)
+        todo = []
         while k < len(chunks) and chunks[k][0][0] < hi:
             offs, addr, nbytes, mask = chunks[k]
             k += 1
@@ -402,10 +420,22 @@ class Dataset:
             b = min(hi, offs[0] + c, self.shape[0])
             if b <= a:
                 continue
-            raw = r.at(addr, nbytes)
+            todo.append((a, b, offs[0], r.at(addr, nbytes), mask))  # (file reads stay on this thread)
+
+        def place(item):
+            a, b, o0, raw, mask = item
             if filters:
                 raw = self._unfilter(raw, filters, mask)
-            out[(a - lo) * es:(b - lo) * es] = np.frombuffer(raw, np.uint8, (b - offs[0]) * es)[(a - offs[0]) * es:]
+            out[(a - lo) * es:(b - lo) * es] = np.frombuffer(raw, np.uint8, (b - o0) * es)[(a - o0) * es:]
+
+        # a chromosome of a 10 kb map is tens of 1 M-element chunks: zlib and numpy's copies
+        # release the GIL, so the chunks are inflated side by side (each writes its own range)
+        if filters and len(todo) > 2:
+            for _ in _inflate_pool().map(place, todo):
+                pass
+        else:
+            for item in todo:
+                place(item)
         return f._decode(self._type, out.tobytes(), n, (n,))
 
     def _walk_chunk_btree(self, addr, rank):
