@@ -230,7 +230,13 @@ def self_launch(n, argv):
     os.close(fd)
     env["PK_BENCH_EXIT_FILE"] = code_file
     try:
-        rc = subprocess.call(cmd, env=env)
+        # the ranks' stdout carries library chatter ("[Gloo] Rank 0 is connected ...") beside rank
+        # 0's JSON line: only the JSON goes to this process's stdout, the rest to stderr
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        for line in proc.stdout:
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+        rc = proc.wait()
         txt = open(code_file).read().strip()
         return int(txt) if (rc != 0 and txt) else rc
     finally:

@@ -8,7 +8,7 @@ cd "$root"
 for args in "" "-w 6 --band 300 --upper 300" "--bins 60000 --band 800 --upper 800" \
             "-w 11 --forest random:500:20 --bins 8000"; do
   echo "== bench.py --steps 3 --warmup 1 --no-pcie --cpu-seconds 600 $args" >> "$out"
-  timeout -k 10 900 python3 bench.py --steps 3 --warmup 1 --no-pcie --cpu-seconds 600 $args 2>/dev/null | python3 -c "
+  timeout -k 10 900 python3 bench.py --steps 3 --warmup 1 --no-pcie --busy-seconds 0 --cpu-seconds 600 $args 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read())
 c = d['cpu_baseline']
