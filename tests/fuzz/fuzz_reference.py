@@ -101,6 +101,38 @@ def main():
         if not ok_g:
             print("   getwindow MISMATCH: kept", clist.shape[0], keep.size)
             sys.exit(1)
+        # ---- round 3: coordinates of ANY kind -- below the diagonal (near it and far), off the
+        # matrix, near column 0 (scipy counts a negative column from the far end) -- and the
+        # IndexError the reference's fancy index raises for a window row beyond the matrix
+        k2 = 200
+        ax = rng.integers(-2, n + 2, k2)
+        style = rng.integers(0, 3, k2)
+        ay = np.where(style == 0, ax - rng.integers(0, 3 * w + 2, k2),
+             np.where(style == 1, rng.integers(-2, n + 2, k2), rng.integers(0, 2 * w + 1, k2)))
+        passes = (ax - w >= 0) & (ay + w + 1 <= n)
+        raising = passes & ((ax + w >= n) | (ay - w < -n))
+        if raising.any():
+            for fn in (lambda: ch2.getwindow(list(zip(ax.tolist(), ay.tolist()))), lambda: onp.extract(Mf, e, w, ax, ay)):
+                try:
+                    fn()
+                    print("   a call with a window row beyond the matrix did not raise")
+                    sys.exit(1)
+                except IndexError:
+                    pass
+            ax, ay = ax[~raising], ay[~raising]
+        fea_ref, clist = ch2.getwindow(list(zip(ax.tolist(), ay.tolist())))
+        fea_ref = np.asarray(fea_ref, np.float64).reshape(-1, F)
+        clist = np.asarray(clist, np.int64).reshape(-1, 2)
+        fea_o, keep = onp.extract(Mf, e, w, ax, ay)
+        ok_a = (np.array_equal(clist[:, 0], ax[keep]) and np.array_equal(clist[:, 1], ay[keep])
+                and fea_ref.shape == fea_o.shape
+                and bool(((bits(fea_ref) == bits(fea_o)) | (np.isnan(fea_ref) & np.isnan(fea_o))).all()))
+        if not ok_a:
+            print("   getwindow (any coordinates) MISMATCH: kept", clist.shape[0], keep.size)
+            sys.exit(1)
+        n_any = globals().get("_n_any", 0) + clist.shape[0]
+        n_low = globals().get("_n_low", 0) + int(np.sum(clist[:, 0] > clist[:, 1]))
+        globals()["_n_any"], globals()["_n_low"] = n_any, n_low
         nwin = clist.shape[0]
         npix += int(ref["ri"].size)
         ncand += int(len(cx))
@@ -111,8 +143,9 @@ def main():
         sys.stdout.flush()
         if not (ok_e and ok_b and ok_c and ok_s):
             sys.exit(1)
-    print("all %d chromosomes identical to the reference in %.0f s (%d candidates, %d scored pixels)" % (
-        n_cases, time.time() - t0, ncand, npix))
+    print("all %d chromosomes identical to the reference in %.0f s (%d candidates, %d scored pixels; "
+          "getwindow on any coordinates: %d windows kept, %d of them below the diagonal)" % (
+              n_cases, time.time() - t0, ncand, npix, globals().get("_n_any", 0), globals().get("_n_low", 0)))
 
 
 if __name__ == "__main__":

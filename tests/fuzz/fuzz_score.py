@@ -25,7 +25,7 @@ def main():
     for case in range(n_cases):
         seed = seed0 + case
         rng = np.random.default_rng(seed)
-        w = int(rng.choice([1, 2, 3, 4, 5, 5, 5, 6, 6, 6, 7, 8, 11, 13, 15]))
+        w = int(rng.choice([1, 2, 3, 4, 5, 5, 5, 6, 6, 6, 7, 8, 11, 11, 11, 13, 15]))
         n = int(rng.integers(8 * w + 60, 900))
         band = int(rng.integers(4 * w + 10, min(200, n // 2)))
         upper = int(rng.integers(2 * w + 4, band))
@@ -89,6 +89,8 @@ def main():
             opts["extract_pair"] = 0
         if rng.random() < 0.1:
             opts["extract_clean"] = 0
+        if rng.random() < 0.15:
+            opts["extract_row16"] = 0
         if rng.random() < 0.15:
             opts["early_exit"] = 1
         old = {k: L.pk_get_option(k.encode()) for k in opts}
