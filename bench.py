@@ -209,6 +209,45 @@ def pmc_rooflines(dom, launches_per_step_live):
     return traffic, issue, lds
 
 
+def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, steps):
+    """One of the non-headline BASELINE.json configurations, measured the same way in the same
+    process (device-resident candidates, pk_score_run, HIP-event kernel times), a few steps
+    only: so that the driver's record carries them too, not only the builder's logs."""
+    from peakachu_amd import _lib
+    F = (2 * w + 1) ** 2
+    fo = load_forest(forest_spec, w, F)
+    Mf, exp_arr, x, y, upper = build_workload(0, n, band, w, 6, upper)
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], exp_arr, -2 * w + 1, upper + 2 * w - 1,
+                        device=dev)
+    hf = _lib.HipForest(fo, device=dev)
+    cd = _lib.HipCands(x, y, device=dev)
+    try:
+        cd.run(hm, hf, w, thre, batch)
+        L.pk_prof_enable(1)
+        L.pk_prof_reset()
+        _lib.check(L.pk_device_synchronize(dev), "sync")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            n_out = cd.run(hm, hf, w, thre, batch)
+        _lib.check(L.pk_device_synchronize(dev), "sync")
+        el = time.perf_counter() - t0
+        L.pk_prof_enable(0)
+        kern = {k: _lib.prof_get(k) for k in ("extract", "quant", "forest", "compact")}
+    finally:
+        cd.close(); hf.close(); hm.close()
+    value = x.size * steps / el
+    dom = max(("extract", "quant", "forest"), key=lambda k: kern[k][0])
+    dom_ms, dom_n = kern[dom]
+    return {"workload": "%s: synthetic %dx%d (%d-bin band), w=%d, %d-tree RF%s" % (
+                name, n, n, band, w, fo.T, " (untrained random trees)" if (forest_spec or "").startswith("random:") else ""),
+            "value": value, "unit": "candidates/s", "steps": steps, "ms_per_step": el / steps * 1e3,
+            "candidates": int(x.size), "scored_pixels": int(n_out),
+            "kernel_ms_per_step": {k: v[0] / steps for k, v in kern.items()},
+            "roofline_frac_dominant_kernel": (float(x.size) * steps * b_alg(F) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                             if dom_ms > 0 else None,
+            "whole_path_frac": value * b_alg(F) / 1e9 / HBM_PEAK_GBS}
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher: run the same command under
     torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) as a child process and
@@ -274,6 +313,9 @@ def main():
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use device 0 and the RCCL gather is skipped "
                          "(RCCL refuses two ranks on one GPU); the result is not a valid measurement")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the short legs on the other BASELINE.json shapes (w=6 / 300-bin band with the "
+                         "trained forest; w=11 x 500 random trees) that the default single-GPU run appends")
     ap.add_argument("--busy-seconds", type=float, default=2.5,
                     help="untimed scoring loop after the timed region, so that an outside GPU-activity "
                          "sampler sees the device working (0 = off)")
@@ -466,6 +508,18 @@ def main():
                 "note": "pk_score with host buffers: candidate upload (8 B each), per-call device "
                         "allocations and result download included; NOT the headline value"}
 
+    # extra, not the headline: the other single-GPU shapes of BASELINE.json, a few steps each
+    extras = None
+    if (world == 1 and not a.no_extra_configs and w == 5 and a.n == 30000 and a.band == 200 and a.stride == 1
+            and not a.forest and not a.opt):
+        extras = []
+        for name, kw in (("w6 (the released 5/10 kb models' window)", dict(n=30000, band=300, w=6, upper=300, forest_spec=None)),
+                         ("configs[4]", dict(n=8000, band=200, w=11, upper=200, forest_spec="random:500:20"))):
+            try:
+                extras.append(extra_config(L, dev, name, thre=a.thre, batch=a.batch, steps=5, **kw))
+            except Exception as e:  # reported, never fatal for the headline
+                extras.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
+
     # strong scaling: the merged result must equal the single-GPU result of the whole list
     strong_check = None
     if strong:
@@ -596,6 +650,8 @@ def main():
             out["strong_check"] = strong_check
         if early is not None:
             out["early_exit"] = early
+        if extras is not None:
+            out["other_configs"] = extras
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(Mf, exp_arr, w, fo, a.thre, x, y, a.batch, gpu_pixels,
                                                target_s=a.cpu_seconds)

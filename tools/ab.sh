@@ -10,7 +10,7 @@ cp peakachu_amd/libpeakachu_hip.so /tmp/pk_keep.so
 for rep in 1 2; do
   for so in "$@"; do
     cp "tools/ab/$so" peakachu_amd/libpeakachu_hip.so
-    timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-pcie --busy-seconds 0 --steps 40 --warmup 3 $args 2>/dev/null | python3 -c "
+    timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-pcie --busy-seconds 0 --no-extra-configs --steps 40 --warmup 3 $args 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('%-14s' % sys.argv[1], round(d['value']/1e6,1), 'M/s', {k:round(v,3) for k,v in d['kernel_ms_per_step'].items()}, d['config']['scored_pixels_rank0'])" "$so"
   done
 done
