@@ -547,6 +547,151 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #undef Q_STAMP
 }
 
+// ------------------------------------------------------------------------
+// The 64-candidate shape (more than 255 features: the wide node word), TWO rank tiles per
+// workgroup trip (round 3).
+//
+// Measured on configs[4] (529 features, 500 trees, 7 trees = 84 KB per group, 64 candidates = 68 KB
+// per tile; forest_q_kernel<1,1,...>): a tree group costs 5 460 cycles of which the walk is 2 460
+// (seven waves, one dependent chain each: latency-bound) -- the rest is staging: 84 KB per group
+// and 64 candidates through the CU's L2 path alone take 2 420 cycles (35 B per cycle, the guide's
+// L2-gather rate), the commit to LDS 1 500.  Candidates x trees resident is capped near 450 by
+// the 160 KiB, so every staged byte serves a tenth of the walk work it serves at 121 features.
+// The register file is the larger memory (512 KB per CU, 128 VGPRs x 1024 threads): a SECOND
+// rank tile waits there (5 x 16 B per thread) while the first is walked, and is exchanged with
+// it between the two walks of a group -- 68 KB out, 68 KB in, all sixteen waves -- so that every
+// staged group serves 128 candidates: half the L2 traffic, half the commits, half the barriers
+// per candidate for one exchange.  The tile left in LDS by a group is the one the next group
+// walks first.  No next-tile prefetch (the staging registers and the spare tile leave no room;
+// a trip is 72 groups long), no early termination (Chromosome.score's prune keeps the
+// one-tile kernel), no issue priorities (seven latency-bound waves).
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
+    const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
+    int F, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
+    const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob,
+    long long *__restrict__ stamps)
+{
+    constexpr int THREADS = Q_THREADS;
+    // six staging registers (groups of <= 96 KiB), five for the spare tile (<= 5 x 1024 units of
+    // 16 B: F <= 639) per thread
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
+    const int HB = F * 128;  // bytes of a rank tile [F][64] u16
+    const int upt = HB >> 4;
+    const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
+    if (!lds_at_zero && threadIdx.x == 0 && stamps) stamps[65535] = 2;
+    const int64_t n_pair = (cn + 127) / 128;
+    for (int64_t pr = blockIdx.x; pr < n_pair; pr += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // (keeps per-trip address arithmetic inside the trip)
+        const int lane = tid & 63;
+        const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned lk0 = (unsigned)lane << 1;
+        const int64_t cbase = pr * 128;  // tile A = candidates cbase .. +63, tile B = the next 64
+        const bool has_b = cbase + 64 < cn;
+        if (pr != (int64_t)blockIdx.x) __syncthreads();  // the previous trip's tile is no longer read
+        // tile A -> LDS, tile B -> registers
+        // (named registers, expanded by macros: arrays of them are moved to scratch or LDS)
+#define Q2_TB5(X) X(0) X(1) X(2) X(3) X(4)
+#define Q2_PF6(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#define Q2_TB_DECL(k) v4u tb##k = {0u, 0u, 0u, 0u};
+        Q2_TB5(Q2_TB_DECL)
+        {
+            const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
+#define Q2_TILES_IN(k)                                        \
+    {                                                         \
+        const int u = tid + (k) * THREADS;                    \
+        if (u < upt) {                                        \
+            *LDS_AT(lds_u4, u << 4) = src[u];                 \
+            if (has_b) tb##k = src[upt + u];                  \
+        }                                                     \
+    }
+            Q2_TB5(Q2_TILES_IN)
+#undef Q2_TILES_IN
+        }
+        // lane's candidate in either tile; thread tid < 128 owns candidate cbase + tid (ordered sum)
+        const int64_t la = cbase + lane, lb = cbase + 64 + lane;
+        const bool act_a = lds_at_zero && la < cn && status[c0 + la] != 0;
+        const bool act_b = lds_at_zero && lb < cn && status[c0 + lb] != 0;
+        const bool owner = tid < 128;
+        const bool valid = owner && cbase + tid < cn;
+        const bool active = valid && lds_at_zero && status[c0 + cbase + tid] != 0;
+#define Q2_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u};
+        Q2_PF6(Q2_PF_DECL)
+#define Q2_PF_LOAD(q) if ((q) * THREADS < pf_nu) pf##q = pf_src[min(tid + (q) * THREADS, pf_nu - 1)];
+#define Q2_PF_STORE(q)                                                        \
+    {                                                                         \
+        const int u = tid + (q) * THREADS;                                    \
+        if (u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q;           \
+    }
+        int4 g_cur = gtab[0];
+        int4 tt = ttab[min(g_cur.x + slot, T - 1)];
+        const v4u *pf_src = img + g_cur.z;
+        int pf_nu = g_cur.w;
+        {   // first group: global -> VGPR -> LDS
+            Q2_PF6(Q2_PF_LOAD)
+            Q2_PF6(Q2_PF_STORE)
+        }
+        __syncthreads();  // tile A and the first group are in LDS
+        double acc = 0.0;
+        int cur = 0;  // (uniform) the tile that sits in LDS: 0 = A, 1 = B
+        for (int g = 0; g < n_grp; g++) {
+            const int gt = g_cur.y;
+            const int4 g_nxt = gtab[g + 1];
+            const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];
+            if (g + 1 < n_grp) {  // the next group flies while this one is walked twice
+                pf_src = img + g_nxt.z;
+                pf_nu = g_nxt.w;
+                Q2_PF6(Q2_PF_LOAD)
+            }
+            const unsigned tbase = (unsigned)(img_off + tt.x);
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                // walk the tile in LDS; thread tid owns candidate (tile `cur`, lane tid & 63)
+                if (slot < gt) {  // (lanes without a live candidate walk along: their values are not stored)
+                    double v[1];
+                    q_walk<1, 0, 32768, false, false, -1>((unsigned)tt.z, tt.y, tbase, lk0, lk0 + 2u, v);
+                    if (cur ? act_b : act_a) *LDS_AT(lds_f64, val_off + (slot * 64 + lane) * 8) = v[0];
+                }
+                __syncthreads();  // every walk of this tile is done, every value parked
+                if (active && (tid >> 6) == cur)  // tree order: sklearn's sequential float64 sum
+                    for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * 64 + (tid & 63)) * 8);
+                if (half == 0) {
+                    if (has_b) {  // exchange the tiles: this thread's units of the one in LDS against its spare
+#define Q2_SWAP_RD(k) v4u t##k = tb##k; if (tid + (k) * THREADS < upt) t##k = *LDS_AT(lds_u4, (tid + (k) * THREADS) << 4);
+#define Q2_SWAP_WR(k)                                                           \
+    if (tid + (k) * THREADS < upt) {                                            \
+        *LDS_AT(lds_u4, (tid + (k) * THREADS) << 4) = tb##k;                    \
+        tb##k = t##k;                                                           \
+    }
+                        Q2_TB5(Q2_SWAP_RD)
+                        Q2_TB5(Q2_SWAP_WR)
+#undef Q2_SWAP_RD
+#undef Q2_SWAP_WR
+                        cur ^= 1;
+                        __syncthreads();  // the other tile is in; the parked values are consumed
+                    } else {
+                        break;  // (uniform) a trip with one tile: one walk per group
+                    }
+                }
+            }
+            if (g + 1 < n_grp) {  // commit the next group (every walk of this one is behind a barrier)
+                Q2_PF6(Q2_PF_STORE)
+            }
+            __syncthreads();  // next group staged; values consumed
+            g_cur = g_nxt;
+            tt = tt_nxt;
+        }
+        if (valid) prob[c0 + cbase + tid] = active ? acc / (double)T : 0.0;
+    }
+#undef Q2_TB5
+#undef Q2_PF6
+#undef Q2_TB_DECL
+#undef Q2_PF_DECL
+#undef Q2_PF_LOAD
+#undef Q2_PF_STORE
+}
+
 template <typename KernelT>
 int q_set_max_lds(KernelT k, size_t bytes)
 {
@@ -823,6 +968,17 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         else Q_LAUNCH(4, 1, 49152, false);
     } else if (L.ch == 2) {
         Q_LAUNCH(2, 1, 32768, false);
+    } else if (L.ch == 1 && g_opt.forest_q_two && !(prune_sum > -1e300) && cn > 64 && f->F <= 639 &&
+               L.cap <= 6 * 16384) {
+        // two rank tiles per trip (see forest_q2_kernel)
+        int rc2 = q_set_max_lds(forest_q2_kernel, 163840);
+        if (rc2) return rc2;
+        unsigned grid2 = (unsigned)((cn + 127) / 128);
+        if (g_opt.forest_q_persist != 0 && grid2 > want) grid2 = want;
+        hipLaunchKernelGGL(forest_q2_kernel, dim3(grid2), dim3(Q_THREADS), 163840, ctx->stream,
+                           reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab),
+                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.val_off, L.img_off,
+                           ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf);
     } else if (L.ch == 1) {
         Q_LAUNCH(1, 1, 32768, false);
     } else {
