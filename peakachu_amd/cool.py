@@ -23,6 +23,8 @@ NOT against cooler itself.  The multiplicative path (`weight`, what peakachu's d
 divisive path's order of operations is recalled from cooler's source, UNVERIFIED -- where
 `cooler` is importable `io.open_map` uses it instead of this class.
 """
+import threading
+
 import numpy as np
 from scipy import sparse
 
@@ -69,7 +71,8 @@ class CoolFile:
         self.chromsizes = dict(zip(self.chromnames, (int(v) for v in self._g["chroms/length"].read())))
         self._chrom_offset = self._g["indexes/chrom_offset"].read().astype(np.int64)
         self._bin1_offset = None
-        self._last_pixels = (None, None)
+        self._pixel_cache = {}  # chromosome -> its mirrored pixels; the last two (two reader threads)
+        self._pixel_lock = threading.Lock()
         self.binsize = a.get("bin-size")
         if not isinstance(self.binsize, int):
             st, en = self._g["bins/start"][0:1], self._g["bins/end"][0:1]
@@ -109,8 +112,10 @@ class CoolFile:
         """(row, col, count) of the chromosome's symmetric matrix.  The scoring drivers fetch a
         chromosome twice in balanced mode (balanced values, then raw counts): the pixels are
         read and inflated once."""
-        if self._last_pixels[0] == chrom:
-            return self._last_pixels[1]
+        with self._pixel_lock:
+            hit = self._pixel_cache.get(chrom)
+        if hit is not None:
+            return hit
         n = hi - lo
         if self._bin1_offset is None:
             self._bin1_offset = self._g["indexes/bin1_offset"].read().astype(np.int64)
@@ -143,7 +148,14 @@ class CoolFile:
             M = Us.T.tocsr() + U
             row = np.repeat(np.arange(n, dtype=np.int32), np.diff(M.indptr))
             out = (row, M.indices, M.data, M.indptr)
-        self._last_pixels = (chrom, out)
+        # the matrices handed out share these arrays (a chromosome's two fetches, balanced and raw,
+        # would otherwise copy 4 x 56 MB for 25 000 bins): nobody may write into them
+        for a in out:
+            a.flags.writeable = False
+        with self._pixel_lock:
+            self._pixel_cache[chrom] = out
+            while len(self._pixel_cache) > 2:  # (dicts keep insertion order: the oldest goes)
+                del self._pixel_cache[next(iter(self._pixel_cache))]
         return out
 
     @staticmethod
@@ -188,10 +200,13 @@ class CoolFile:
                     # count / (b_i * b_j).  UNVERIFIED against cooler itself (see the module text)
                     with np.errstate(divide="ignore", invalid="ignore"):
                         w = 1.0 / w
-                data = w[row] * w[col] * data
-            else:
-                data = data.copy()  # (the cached arrays stay ours)
-            return sparse_coo(data, row.copy(), col.copy(), n, indptr)
+                # (w[row] * w[col]) * count: the row factor by repetition (the rows are runs)
+                f = np.repeat(w, np.diff(indptr))
+                f *= np.take(w, col)
+                f *= data
+                data = f
+            # row, col (and the raw counts) are the cached arrays themselves, read-only
+            return sparse_coo(data, row, col, n, indptr)
         return _Selector(fetch)
 
     def bins(self):

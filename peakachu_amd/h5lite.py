@@ -18,6 +18,7 @@ container itself, in pure Python + numpy, after the HDF5 File Format Specificati
 Everything else raises `H5Unsupported` naming the feature.  Pinned by files the genuine
 library wrote (tests/golden/cool_small*.cool, tools/make_cool_fixture.py).
 """
+import os
 import struct
 import zlib
 
@@ -61,8 +62,14 @@ class _Reader:
         self.fh.close()
 
     def at(self, addr, n):
-        self.fh.seek(self.base + addr)
-        b = self.fh.read(n)
+        # (positional reads: the file position is not shared state, so that chromosomes can be
+        # read on several threads at once)
+        b = os.pread(self.fh.fileno(), n, self.base + addr)
+        while 0 < len(b) < n:  # (a short read is legal for pread)
+            more = os.pread(self.fh.fileno(), n - len(b), self.base + addr + len(b))
+            if not more:
+                break
+            b += more
         if len(b) != n:
             raise H5FormatError("read past the end of the file (address %d, %d bytes)" % (addr, n))
         return b

@@ -32,19 +32,24 @@ def fetch_inputs(Lib, key, correct):
 
 
 def prefetched(Lib, keys, correct):
-    """(key, inputs) for every key, in order; the NEXT chromosome is read on a background thread
-    while the caller prepares and scores the current one.  Reading and inflating a chromosome
-    costs more host time than scoring it on the GPU; zlib and numpy release the GIL.  All file
-    access happens on that one thread, in the reference's order."""
+    """(key, inputs) for every key, in order; the NEXT chromosomes (two by default,
+    PK_PREFETCH=n) are read on background threads while the caller prepares and scores the
+    current one.  Reading and inflating a chromosome costs more host time than scoring it on
+    the GPU; zlib and numpy release the GIL, and the built-in readers use positional reads
+    (h5lite.at) and a locked pixel cache (cool.CoolFile._mirrored), so two chromosomes can be
+    in the making at once.  Each chromosome's own reads stay in the reference's order."""
+    from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     keys = list(keys)
     if not keys:
         return
-    with ThreadPoolExecutor(max_workers=1) as pool:
-        nxt = pool.submit(fetch_inputs, Lib, keys[0], correct)
+    depth = max(1, int(os.environ.get("PK_PREFETCH", "2")))
+    with ThreadPoolExecutor(max_workers=depth) as pool:
+        ahead = deque(pool.submit(fetch_inputs, Lib, k, correct) for k in keys[:depth])
         for i, key in enumerate(keys):
-            cur = nxt.result()
-            nxt = pool.submit(fetch_inputs, Lib, keys[i + 1], correct) if i + 1 < len(keys) else None
+            cur = ahead.popleft().result()
+            if i + depth < len(keys):
+                ahead.append(pool.submit(fetch_inputs, Lib, keys[i + depth], correct))
             yield key, cur
 
 

@@ -18,7 +18,7 @@ def tocsr(X):
     parts = getattr(X, "_pk_csr_parts", None)
     if parts is not None and parts[1] is X.col and parts[2] is X.data:
         indptr, col, data = parts
-        out = sparse.csr_matrix((data.astype(float), col, indptr), shape=X.shape)
+        out = sparse.csr_matrix((data.astype(float, copy=False), col, indptr), shape=X.shape)
         out.has_sorted_indices = True
         out.has_canonical_format = True
         return out

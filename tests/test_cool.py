@@ -165,3 +165,33 @@ def test_mirror_by_scatter_equals_the_transposed_sum():
     o = np.lexsort((Cc, R))
     assert np.array_equal(row, R[o]) and np.array_equal(col, Cc[o]) and np.array_equal(val, V[o])
     assert np.array_equal(indptr, np.searchsorted(R[o], np.arange(n + 1)))
+
+
+def test_chromosomes_read_on_two_threads_and_shared_arrays():
+    """score_genome reads the next two chromosomes on background threads (positional reads, a
+    locked pixel cache): what they deliver equals what one thread reads one after the other.
+    The matrices of one chromosome share its cached index arrays, which are read-only."""
+    from peakachu_amd import score_genome
+    path = os.path.join(G, "cool_small.cool")
+    ref = cool.CoolFile(path)
+    names = ref.chromnames * 3
+    want = [score_genome.fetch_inputs(ref, k, "weight") for k in names]
+    for depth in ("1", "2", "3"):
+        os.environ["PK_PREFETCH"] = depth
+        try:
+            c = cool.CoolFile(path)
+            got = list(score_genome.prefetched(c, names, "weight"))
+        finally:
+            del os.environ["PK_PREFETCH"]
+        assert [k for k, _ in got] == names
+        for (_, (M, R, wts)), (M0, R0, w0) in zip(got, want):
+            for A, B in ((M, M0), (R, R0)):
+                assert np.array_equal(A.row, B.row) and np.array_equal(A.col, B.col)
+                assert np.array_equal(A.data, B.data, equal_nan=True) and A.data.dtype == B.data.dtype
+            assert np.array_equal(wts, w0, equal_nan=True)
+            assert M.row is R.row or np.shares_memory(M.row, R.row)
+            with pytest.raises(ValueError, match="read-only"):
+                R.data[0] = 1
+            M.data[0] = M.data[0]  # the balanced values are the caller's own
+        c.close()
+    ref.close()
