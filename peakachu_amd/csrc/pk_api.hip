@@ -270,6 +270,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_l2_tile = value != 0;
     } else if (!strcmp(name, "forest_q_two")) {
         g_opt.forest_q_two = value != 0;
+    } else if (!strcmp(name, "forest_q_help")) {
+        g_opt.forest_q_help = value != 0;
     } else if (!strcmp(name, "forest_dbg")) {
         g_opt.forest_dbg = value;
     } else if (!strcmp(name, "forest_q")) {
@@ -322,6 +324,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_q_persist")) return g_opt.forest_q_persist;
     if (!strcmp(name, "forest_q_prio")) return g_opt.forest_q_prio;
     if (!strcmp(name, "forest_q_two")) return g_opt.forest_q_two;
+    if (!strcmp(name, "forest_q_help")) return g_opt.forest_q_help;
     if (!strcmp(name, "forest_dbg")) return g_opt.forest_dbg;
     if (!strcmp(name, "forest_q_early")) return g_opt.forest_q_early;
     return -1;

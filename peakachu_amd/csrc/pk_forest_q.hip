@@ -570,17 +570,26 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
     int F, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
     const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob,
-    long long *__restrict__ stamps)
+    long long *__restrict__ stamps, int dbg, int help_from)
 {
     constexpr int THREADS = Q_THREADS;
-    // six staging registers (groups of <= 96 KiB), five for the spare tile (<= 5 x 1024 units of
-    // 16 B: F <= 639) per thread
+    // twelve staging registers and five for the spare tile (<= 5 x 1024 units of 16 B: F <= 639)
+    // per thread.  help_from = 16: every thread stages its share of the next group (six registers,
+    // groups of <= 96 KiB), issued in front of the walk.  help_from < 16 (no group has more trees):
+    // waves help_from .. 15, which never walk, stage ALL of it -- half of their loads in front of
+    // the first walk, half in front of the second -- and the walkers start at once.  Measured
+    // (stamps, configs[4]): the 96 wave-loads of a group keep every wave ~3 100 cycles in front of a
+    // walk of 2 600: the CU's memory pipeline accepts a 1-KiB wave-load every ~32 cycles when the
+    // lines come from beyond the L2 (the image, 6 MB, cycles through the 4-MiB L2 of each XCD once
+    // per trip), and a wave cannot walk before its own loads are accepted.
     extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
     const int HB = F * 128;  // bytes of a rank tile [F][64] u16
     const int upt = HB >> 4;
     const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
     if (!lds_at_zero && threadIdx.x == 0 && stamps) stamps[65535] = 2;
     const int64_t n_pair = (cn + 127) / 128;
+    const bool help = help_from < 16;
+    unsigned warm_sink = 0;
     for (int64_t pr = blockIdx.x; pr < n_pair; pr += gridDim.x) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (keeps per-trip address arithmetic inside the trip)
@@ -593,7 +602,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         // tile A -> LDS, tile B -> registers
         // (named registers, expanded by macros: arrays of them are moved to scratch or LDS)
 #define Q2_TB5(X) X(0) X(1) X(2) X(3) X(4)
-#define Q2_PF6(X) X(0) X(1) X(2) X(3) X(4) X(5)
+#define Q2_NREG 12
+#define Q2_PF14(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
 #define Q2_TB_DECL(k) v4u tb##k = {0u, 0u, 0u, 0u};
         Q2_TB5(Q2_TB_DECL)
         {
@@ -617,32 +627,67 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         const bool valid = owner && cbase + tid < cn;
         const bool active = valid && lds_at_zero && status[c0 + cbase + tid] != 0;
 #define Q2_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u};
-        Q2_PF6(Q2_PF_DECL)
-#define Q2_PF_LOAD(q) if ((q) * THREADS < pf_nu) pf##q = pf_src[min(tid + (q) * THREADS, pf_nu - 1)];
-#define Q2_PF_STORE(q)                                                        \
-    {                                                                         \
-        const int u = tid + (q) * THREADS;                                    \
-        if (u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q;           \
+        Q2_PF14(Q2_PF_DECL)
+        // register q of stager wave pf_h (of pf_H) carries unit ((q * pf_H + pf_h) * 64 + lane) of the
+        // group; registers [pf_q0, pf_q1) are moved (all conditions but the last are wave-uniform)
+#define Q2_PF_LOAD(q)                                                                              \
+    if ((q) >= pf_q0 && (q) < pf_q1 && pf_on && (q) * pf_H * 64 < pf_nu)                             \
+        pf##q = pf_src[min(((q) * pf_H + pf_h) * 64 + lane, pf_nu - 1)];
+#define Q2_PF_STORE(q)                                                                             \
+    {                                                                                              \
+        const int u = ((q) * pf_H + pf_h) * 64 + lane;                                             \
+        if (pf_on && (q) * pf_H * 64 < pf_nu && u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q; \
     }
         int4 g_cur = gtab[0];
         int4 tt = ttab[min(g_cur.x + slot, T - 1)];
         const v4u *pf_src = img + g_cur.z;
         int pf_nu = g_cur.w;
-        {   // first group: global -> VGPR -> LDS
-            Q2_PF6(Q2_PF_LOAD)
-            Q2_PF6(Q2_PF_STORE)
+        int pf_H = 16, pf_h = slot, pf_q0 = 0, pf_q1 = Q2_NREG;
+        bool pf_on = true;
+        {   // first group: global -> VGPR -> LDS, every thread its share
+            Q2_PF14(Q2_PF_LOAD)
+            Q2_PF14(Q2_PF_STORE)
         }
+        if (help) {
+            pf_H = 16 - help_from;
+            pf_h = slot - help_from;
+            pf_on = slot >= help_from;
+        }
+        const int pf_split = (help && has_b) ? Q2_NREG / 2 : Q2_NREG;
+        const bool wk = help && slot < help_from;  // a walker: register 0 takes a unit behind the helpers'
+        const int wk_u = (16 - help_from) * 64 * Q2_NREG + slot * 64 + lane;
         __syncthreads();  // tile A and the first group are in LDS
         double acc = 0.0;
         int cur = 0;  // (uniform) the tile that sits in LDS: 0 = A, 1 = B
+#define Q2_STAMP(k_)                                                                    \
+    do {                                                                                \
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && g < 32)             \
+            stamps[((tid >> 6) * 32 + g) * 8 + (k_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
         for (int g = 0; g < n_grp; g++) {
             const int gt = g_cur.y;
+            Q2_STAMP(0);
             const int4 g_nxt = gtab[g + 1];
             const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];
             if (g + 1 < n_grp) {  // the next group flies while this one is walked twice
                 pf_src = img + g_nxt.z;
                 pf_nu = g_nxt.w;
-                Q2_PF6(Q2_PF_LOAD)
+                pf_q0 = 0;
+                pf_q1 = pf_split;
+                // (what the helpers' registers cannot hold: one unit per walker lane, one load in front
+                // of the walk)
+                if (wk && wk_u - lane < pf_nu) pf0 = pf_src[min(wk_u, pf_nu - 1)];
+                Q2_PF14(Q2_PF_LOAD)
+            }
+            if (slot == 15 && !(dbg & 128)) {
+                // the group after the next one -> this XCD's L2 (the image is larger than it and is
+                // walked in the same order by every workgroup): workgroup i runs on XCD i % 8; the 32
+                // of an XCD share the lines of the group, one dword of each 128-byte line is asked for
+                const int4 gw = gtab[g + 2 < n_grp ? g + 2 : g + 2 - n_grp < n_grp ? g + 2 - n_grp : 0];
+                const int lines = (gw.w + 7) >> 3, per = (lines + 31) >> 5;
+                const int first = (int)((blockIdx.x >> 3) & 31) * per;
+                for (int i = first + lane; i < min(first + per, lines); i += 64)
+                    warm_sink += reinterpret_cast<const unsigned *>(img + gw.z)[i * 32];
             }
             const unsigned tbase = (unsigned)(img_off + tt.x);
 #pragma unroll
@@ -653,7 +698,9 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
                     q_walk<1, 0, 32768, false, false, -1>((unsigned)tt.z, tt.y, tbase, lk0, lk0 + 2u, v);
                     if (cur ? act_b : act_a) *LDS_AT(lds_f64, val_off + (slot * 64 + lane) * 8) = v[0];
                 }
+                Q2_STAMP(half ? 5 : 1);
                 __syncthreads();  // every walk of this tile is done, every value parked
+                Q2_STAMP(half ? 6 : 2);
                 if (active && (tid >> 6) == cur)  // tree order: sklearn's sequential float64 sum
                     for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * 64 + (tid & 63)) * 8);
                 if (half == 0) {
@@ -664,28 +711,43 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         *LDS_AT(lds_u4, (tid + (k) * THREADS) << 4) = tb##k;                    \
         tb##k = t##k;                                                           \
     }
-                        Q2_TB5(Q2_SWAP_RD)
-                        Q2_TB5(Q2_SWAP_WR)
+                        // (three units, then two: five exchange registers at once spill)
+                        Q2_SWAP_RD(0) Q2_SWAP_RD(1) Q2_SWAP_RD(2)
+                        Q2_SWAP_WR(0) Q2_SWAP_WR(1) Q2_SWAP_WR(2)
+                        Q2_SWAP_RD(3) Q2_SWAP_RD(4)
+                        Q2_SWAP_WR(3) Q2_SWAP_WR(4)
 #undef Q2_SWAP_RD
 #undef Q2_SWAP_WR
                         cur ^= 1;
+                        Q2_STAMP(3);
                         __syncthreads();  // the other tile is in; the parked values are consumed
+                        Q2_STAMP(4);
+                        if (g + 1 < n_grp && pf_split < Q2_NREG) {  // the helpers' second half
+                            pf_q0 = pf_split;
+                            pf_q1 = Q2_NREG;
+                            Q2_PF14(Q2_PF_LOAD)
+                        }
                     } else {
                         break;  // (uniform) a trip with one tile: one walk per group
                     }
                 }
             }
             if (g + 1 < n_grp) {  // commit the next group (every walk of this one is behind a barrier)
-                Q2_PF6(Q2_PF_STORE)
+                Q2_PF14(Q2_PF_STORE)
+                if (wk && wk_u < pf_nu) *LDS_AT(lds_u4, img_off + (wk_u << 4)) = pf0;
             }
             __syncthreads();  // next group staged; values consumed
+            Q2_STAMP(7);
             g_cur = g_nxt;
             tt = tt_nxt;
         }
         if (valid) prob[c0 + cbase + tid] = active ? acc / (double)T : 0.0;
     }
+    if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-up loads alive
+#undef Q2_STAMP
 #undef Q2_TB5
-#undef Q2_PF6
+#undef Q2_PF14
+#undef Q2_NREG
 #undef Q2_TB_DECL
 #undef Q2_PF_DECL
 #undef Q2_PF_LOAD
@@ -812,6 +874,8 @@ static int q_plan_build(pk_forest *f)
     f->q_slot_bytes = slot_bytes;
     f->q_ch = ch;
     f->q_n_grp = best.n_grp;
+    f->q_max_group_bytes = 0;
+    for (int g = 0; g < best.n_grp; g++) f->q_max_group_bytes = std::max(f->q_max_group_bytes, best.gtab[4 * g + 3] * 16);
     int rc = q_upload((void **)&f->q_img, best.pairs);
     if (!rc) rc = q_upload((void **)&f->q_gtab, best.gtab);
     if (!rc) rc = q_upload((void **)&f->q_ttab, best.ttab);
@@ -878,6 +942,17 @@ int pk_forest_q_plan(pk_forest *f)
         if (prune_sum > -1e300) Q_LAUNCH_P(CH, WPT, HALF1, true, EARLY);                       \
         else Q_LAUNCH_P(CH, WPT, HALF1, false, EARLY);                                         \
     } while (0)
+
+// forest_q2_kernel: the first wave that never walks (no group has more than q_slots trees), if the
+// waves from there on can hold a whole group in twelve 16-byte registers per lane; else 16
+static int q2_help_from(const pk_forest *f, const pk_q_layout &L)
+{
+    const int helpers = 16 - f->q_slots;
+    if (!g_opt.forest_q_help || helpers < 4) return 16;
+    // (12 = Q2_NREG registers per helper lane, one per walker lane)
+    if (((int64_t)helpers * 12 + f->q_slots) * 64 * 16 < (int64_t)f->q_max_group_bytes) return 16;
+    return f->q_slots;
+}
 
 // Room for the rank tiles of `cn` candidates (scratch of the context; grows only).
 int pk_forest_q_reserve(pk_device_ctx *ctx, pk_forest *f, int64_t cn)
@@ -969,8 +1044,10 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     } else if (L.ch == 2) {
         Q_LAUNCH(2, 1, 32768, false);
     } else if (L.ch == 1 && g_opt.forest_q_two && !(prune_sum > -1e300) && cn > 64 && f->F <= 639 &&
-               L.cap <= 6 * 16384) {
-        // two rank tiles per trip (see forest_q2_kernel)
+               (f->q_max_group_bytes <= 6 * 16384 || q2_help_from(f, L) < 16)) {
+        // two rank tiles per trip (see forest_q2_kernel); the waves that never walk stage the groups
+        // when twelve registers of theirs hold one (option forest_q_help, on)
+        const int help_from = q2_help_from(f, L);
         int rc2 = q_set_max_lds(forest_q2_kernel, 163840);
         if (rc2) return rc2;
         unsigned grid2 = (unsigned)((cn + 127) / 128);
@@ -978,7 +1055,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         hipLaunchKernelGGL(forest_q2_kernel, dim3(grid2), dim3(Q_THREADS), 163840, ctx->stream,
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab),
                            f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.val_off, L.img_off,
-                           ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf);
+                           ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)g_opt.forest_dbg, help_from);
     } else if (L.ch == 1) {
         Q_LAUNCH(1, 1, 32768, false);
     } else {

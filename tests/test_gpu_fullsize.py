@@ -181,12 +181,15 @@ def test_config5_full_parity_at_bench_size(hip_lib):
     fo = bench.load_forest("random:500:20", 11, 529)
     n_cand, n_pix = _full_parity(11, 8000, 200, 200, fo, min_cands=1_400_000)
     assert n_pix > 100_000
-    old = _lib.load().pk_get_option(b"forest_q_two")
-    try:  # the one-tile kernel on the same workload (what Chromosome.score's pruned runs use)
-        _lib.set_option("forest_q_two", 0)
-        assert _full_parity(11, 8000, 200, 200, fo, min_cands=1_400_000) == (n_cand, n_pix)
-    finally:
-        _lib.set_option("forest_q_two", old)
+    # the two-tile kernel with every thread staging its share of a group (no helper waves), and the
+    # one-tile kernel (what Chromosome.score's pruned runs use), on the same workload
+    for name in ("forest_q_help", "forest_q_two"):
+        old = _lib.load().pk_get_option(name.encode())
+        try:
+            _lib.set_option(name, 0)
+            assert _full_parity(11, 8000, 200, 200, fo, min_cands=1_400_000) == (n_cand, n_pix)
+        finally:
+            _lib.set_option(name, old)
 
 
 @pytest.mark.parametrize("w,T,n,band,upper,stride", [(6, 100, 20000, 300, 300, 7),

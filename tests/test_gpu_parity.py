@@ -276,12 +276,16 @@ def test_forest_q_modes(hip_lib, name, opts):
 
 @pytest.mark.parametrize("opts", [{}, {"forest_slots": 5}, {"forest_q_persist": -2}, {"forest_q_prio": 0},
                                   {"forest_q": 0}, {"forest_q_two": 0}, {"forest_q_two": 0, "forest_q_persist": -2},
-                                  {"forest_q_persist": 0}, {"forest_slots": 16}])
+                                  {"forest_q_persist": 0}, {"forest_slots": 16}, {"forest_q_help": 0},
+                                  {"forest_slots": 5, "forest_q_help": 0}, {"forest_slots": 9},
+                                  {"forest_slots": 12}, {"forest_slots": 3, "forest_q_persist": -2}])
 @pytest.mark.parametrize("F,with_miss", [(529, False), (300, False), (529, True)])
 def test_forest_wide_format(hip_lib, F, with_miss, opts):
     """More than 255 features (w = 11: 529): the rank kernel on 64-candidate tiles with the wide
     node word (10-bit feature, 11-bit pair index), two tiles per workgroup trip (forest_q2_kernel:
-    the second one waits in registers) or one -- forests without missing_go_to_left nodes;
+    the second one waits in registers; the groups staged by the waves without a tree when there are
+    enough of them -- forest_slots 3 / 5 / 9 -- else by every thread) or one -- forests without
+    missing_go_to_left nodes;
     one with such nodes does not fit the word and takes the float kernels.  Rows with exact 0 / 1,
     values on thresholds, NaN cells and all-NaN rows; bit-exact against the oracle."""
     from test_forest_qimage import _random_forest
