@@ -89,7 +89,7 @@ struct pk_options {
     int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
     int64_t forest_q = 1;       // rank-quantised tiles + 4-byte nodes (forest_q_kernel) when the forest fits
     int64_t forest_q_two = 1;   // 64-candidate shape: two rank tiles per workgroup trip (forest_q2_kernel)
-    int64_t forest_q_help = 1;  // forest_q2_kernel: the waves without a tree stage the groups, the walkers none
+    int64_t forest_q_help = 1;  // forest_q2_kernel: the waves that walk load their share of a group behind the first walk
     int64_t forest_q_ch = 0;    // walks per lane of forest_q_kernel: 0 = auto (4 when F <= 128), 2, 4
     int64_t forest_q_wpt = 0;   // waves per tree with 4 walks per lane: 0 = auto (2), 1, 2
     int64_t forest_q_persist = 1; // rank kernel: persistent launch, this many workgroups per CU, each looping over

@@ -570,25 +570,25 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
     int F, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
     const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob,
-    long long *__restrict__ stamps, int dbg, int help_from)
+    long long *__restrict__ stamps, int dbg, int late_below)
 {
     constexpr int THREADS = Q_THREADS;
-    // twelve staging registers and five for the spare tile (<= 5 x 1024 units of 16 B: F <= 639)
-    // per thread.  help_from = 16: every thread stages its share of the next group (six registers,
-    // groups of <= 96 KiB), issued in front of the walk.  help_from < 16 (no group has more trees):
-    // waves help_from .. 15, which never walk, stage ALL of it -- half of their loads in front of
-    // the first walk, half in front of the second -- and the walkers start at once.  Measured
-    // (stamps, configs[4]): the 96 wave-loads of a group keep every wave ~3 100 cycles in front of a
-    // walk of 2 600: the CU's memory pipeline accepts a 1-KiB wave-load every ~32 cycles when the
-    // lines come from beyond the L2 (the image, 6 MB, cycles through the 4-MiB L2 of each XCD once
-    // per trip), and a wave cannot walk before its own loads are accepted.
+    // six staging registers (groups of <= 96 KiB) and five for the spare tile (<= 5 x 1024 units of
+    // 16 B: F <= 639) per thread.  Every thread stages its share of the next group, but the waves
+    // that walk (slot < late_below: no group has more trees) issue their loads BEHIND the first
+    // walk of a group, the others in front of it.  Measured (stamps, configs[4]): a wave cannot walk
+    // before the memory pipeline has accepted its loads, and with all sixteen issuing at once that
+    // took longer than the walk itself.  (Letting the idle waves stage everything -- twelve
+    // registers each -- frees the walkers just as well, but a wave's LDS stores do not overlap:
+    // ~230 cycles per ds_write_b128 and wave, so the commit of a group takes as long as the wave
+    // with the most registers needs -- 2 900 cycles for twelve against 1 400 for six: 12.5 vs
+    // 11.9 ms.)
     extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
     const int HB = F * 128;  // bytes of a rank tile [F][64] u16
     const int upt = HB >> 4;
     const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
     if (!lds_at_zero && threadIdx.x == 0 && stamps) stamps[65535] = 2;
     const int64_t n_pair = (cn + 127) / 128;
-    const bool help = help_from < 16;
     unsigned warm_sink = 0;
     for (int64_t pr = blockIdx.x; pr < n_pair; pr += gridDim.x) {
         int tid = threadIdx.x;
@@ -602,22 +602,25 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         // tile A -> LDS, tile B -> registers
         // (named registers, expanded by macros: arrays of them are moved to scratch or LDS)
 #define Q2_TB5(X) X(0) X(1) X(2) X(3) X(4)
-#define Q2_NREG 12
-#define Q2_PF14(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
+#define Q2_PF6(X) X(0) X(1) X(2) X(3) X(4) X(5)
 #define Q2_TB_DECL(k) v4u tb##k = {0u, 0u, 0u, 0u};
         Q2_TB5(Q2_TB_DECL)
         {
             const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
-#define Q2_TILES_IN(k)                                        \
-    {                                                         \
-        const int u = tid + (k) * THREADS;                    \
-        if (u < upt) {                                        \
-            *LDS_AT(lds_u4, u << 4) = src[u];                 \
-            if (has_b) tb##k = src[upt + u];                  \
-        }                                                     \
+            // (all ten loads first, then the stores: a store behind every load is five round trips
+            // to memory in a row)
+#define Q2_TILES_LD(k)                                                       \
+    v4u ta##k = {0u, 0u, 0u, 0u};                                            \
+    if (tid + (k) * THREADS < upt) {                                         \
+        ta##k = src[tid + (k) * THREADS];                                    \
+        if (has_b) tb##k = src[upt + tid + (k) * THREADS];                   \
     }
-            Q2_TB5(Q2_TILES_IN)
-#undef Q2_TILES_IN
+#define Q2_TILES_ST(k) \
+    if (tid + (k) * THREADS < upt) *LDS_AT(lds_u4, (tid + (k) * THREADS) << 4) = ta##k;
+            Q2_TB5(Q2_TILES_LD)
+            Q2_TB5(Q2_TILES_ST)
+#undef Q2_TILES_LD
+#undef Q2_TILES_ST
         }
         // lane's candidate in either tile; thread tid < 128 owns candidate cbase + tid (ordered sum)
         const int64_t la = cbase + lane, lb = cbase + 64 + lane;
@@ -626,36 +629,38 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         const bool owner = tid < 128;
         const bool valid = owner && cbase + tid < cn;
         const bool active = valid && lds_at_zero && status[c0 + cbase + tid] != 0;
-#define Q2_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u};
-        Q2_PF14(Q2_PF_DECL)
-        // register q of stager wave pf_h (of pf_H) carries unit ((q * pf_H + pf_h) * 64 + lane) of the
-        // group; registers [pf_q0, pf_q1) are moved (all conditions but the last are wave-uniform)
-#define Q2_PF_LOAD(q)                                                                              \
-    if ((q) >= pf_q0 && (q) < pf_q1 && pf_on && (q) * pf_H * 64 < pf_nu)                             \
-        pf##q = pf_src[min(((q) * pf_H + pf_h) * 64 + lane, pf_nu - 1)];
-#define Q2_PF_STORE(q)                                                                             \
-    {                                                                                              \
-        const int u = ((q) * pf_H + pf_h) * 64 + lane;                                             \
-        if (pf_on && (q) * pf_H * 64 < pf_nu && u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q; \
+#define Q2_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u}, pl##q = {0u, 0u, 0u, 0u};
+        Q2_PF6(Q2_PF_DECL)
+        // Thread tid moves units tid, tid + 1024, ... of the group.  The loads in front of the walk
+        // and the late ones use DIFFERENT registers (pf / pl; a wave uses one set), and an explicit
+        // vmcnt(0) stands in front of the commit: with the same registers loaded at two places, or a
+        // wait only inside the conditional stores, the compiler cannot rule out a load still pending
+        // on a register it is about to overwrite (address arithmetic lands in the destination) and
+        // waits for vmcnt(0) in front of EVERY load -- six round trips to the L2 in a row where six
+        // loads in flight take one.
+#define Q2_PF_LOAD(q) if ((q) * THREADS < pf_nu) pf##q = pf_src[min(tid + (q) * THREADS, pf_nu - 1)];
+#define Q2_PL_LOAD(q) if ((q) * THREADS < pf_nu) pl##q = pf_src[min(tid + (q) * THREADS, pf_nu - 1)];
+#define Q2_PF_STORE(q)                                                        \
+    {                                                                         \
+        const int u = tid + (q) * THREADS;                                    \
+        if (u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pf##q;           \
     }
+#define Q2_PL_STORE(q)                                                        \
+    {                                                                         \
+        const int u = tid + (q) * THREADS;                                    \
+        if (u < pf_nu) *LDS_AT(lds_u4, img_off + (u << 4)) = pl##q;           \
+    }
+#define Q2_VMCNT0() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0); expcnt, lgkmcnt untouched
         int4 g_cur = gtab[0];
         int4 tt = ttab[min(g_cur.x + slot, T - 1)];
         const v4u *pf_src = img + g_cur.z;
         int pf_nu = g_cur.w;
-        int pf_H = 16, pf_h = slot, pf_q0 = 0, pf_q1 = Q2_NREG;
-        bool pf_on = true;
-        {   // first group: global -> VGPR -> LDS, every thread its share
-            Q2_PF14(Q2_PF_LOAD)
-            Q2_PF14(Q2_PF_STORE)
+        {   // first group: global -> VGPR -> LDS
+            Q2_PF6(Q2_PF_LOAD)
+            Q2_VMCNT0();
+            Q2_PF6(Q2_PF_STORE)
         }
-        if (help) {
-            pf_H = 16 - help_from;
-            pf_h = slot - help_from;
-            pf_on = slot >= help_from;
-        }
-        const int pf_split = (help && has_b) ? Q2_NREG / 2 : Q2_NREG;
-        const bool wk = help && slot < help_from;  // a walker: register 0 takes a unit behind the helpers'
-        const int wk_u = (16 - help_from) * 64 * Q2_NREG + slot * 64 + lane;
+        const bool pf_late = has_b && slot < late_below;  // (uniform) this wave loads behind the first walk
         __syncthreads();  // tile A and the first group are in LDS
         double acc = 0.0;
         int cur = 0;  // (uniform) the tile that sits in LDS: 0 = A, 1 = B
@@ -669,25 +674,21 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
             Q2_STAMP(0);
             const int4 g_nxt = gtab[g + 1];
             const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];
-            if (g + 1 < n_grp) {  // the next group flies while this one is walked twice
-                pf_src = img + g_nxt.z;
-                pf_nu = g_nxt.w;
-                pf_q0 = 0;
-                pf_q1 = pf_split;
-                // (what the helpers' registers cannot hold: one unit per walker lane, one load in front
-                // of the walk)
-                if (wk && wk_u - lane < pf_nu) pf0 = pf_src[min(wk_u, pf_nu - 1)];
-                Q2_PF14(Q2_PF_LOAD)
-            }
+            unsigned warm_v = 0;
             if (slot == 15 && !(dbg & 128)) {
                 // the group after the next one -> this XCD's L2 (the image is larger than it and is
                 // walked in the same order by every workgroup): workgroup i runs on XCD i % 8; the 32
-                // of an XCD share the lines of the group, one dword of each 128-byte line is asked for
+                // of an XCD share the lines of the group (<= 1 024: at most 32 each), one dword of
+                // each 128-byte line is asked for and only looked at behind the commit's wait
                 const int4 gw = gtab[g + 2 < n_grp ? g + 2 : g + 2 - n_grp < n_grp ? g + 2 - n_grp : 0];
                 const int lines = (gw.w + 7) >> 3, per = (lines + 31) >> 5;
-                const int first = (int)((blockIdx.x >> 3) & 31) * per;
-                for (int i = first + lane; i < min(first + per, lines); i += 64)
-                    warm_sink += reinterpret_cast<const unsigned *>(img + gw.z)[i * 32];
+                const int i = (int)((blockIdx.x >> 3) & 31) * per + lane;
+                if (lane < per && i < lines) warm_v = reinterpret_cast<const unsigned *>(img + gw.z)[i * 32];
+            }
+            if (g + 1 < n_grp) {  // the next group flies while this one is walked twice
+                pf_src = img + g_nxt.z;
+                pf_nu = g_nxt.w;
+                if (!pf_late) { Q2_PF6(Q2_PF_LOAD) }
             }
             const unsigned tbase = (unsigned)(img_off + tt.x);
 #pragma unroll
@@ -701,6 +702,9 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
                 Q2_STAMP(half ? 5 : 1);
                 __syncthreads();  // every walk of this tile is done, every value parked
                 Q2_STAMP(half ? 6 : 2);
+                if (half == 0 && g + 1 < n_grp && pf_late) {  // the walkers' loads: in flight during the
+                    Q2_PF6(Q2_PL_LOAD)                          // exchange and the second walk
+                }
                 if (active && (tid >> 6) == cur)  // tree order: sklearn's sequential float64 sum
                     for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * 64 + (tid & 63)) * 8);
                 if (half == 0) {
@@ -722,22 +726,19 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
                         Q2_STAMP(3);
                         __syncthreads();  // the other tile is in; the parked values are consumed
                         Q2_STAMP(4);
-                        if (g + 1 < n_grp && pf_split < Q2_NREG) {  // the helpers' second half
-                            pf_q0 = pf_split;
-                            pf_q1 = Q2_NREG;
-                            Q2_PF14(Q2_PF_LOAD)
-                        }
                     } else {
                         break;  // (uniform) a trip with one tile: one walk per group
                     }
                 }
             }
+            Q2_VMCNT0();
+            Q2_STAMP(7);
+            warm_sink += warm_v;
             if (g + 1 < n_grp) {  // commit the next group (every walk of this one is behind a barrier)
-                Q2_PF14(Q2_PF_STORE)
-                if (wk && wk_u < pf_nu) *LDS_AT(lds_u4, img_off + (wk_u << 4)) = pf0;
+                if (pf_late) { Q2_PF6(Q2_PL_STORE) }
+                else { Q2_PF6(Q2_PF_STORE) }
             }
             __syncthreads();  // next group staged; values consumed
-            Q2_STAMP(7);
             g_cur = g_nxt;
             tt = tt_nxt;
         }
@@ -746,8 +747,10 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
     if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-up loads alive
 #undef Q2_STAMP
 #undef Q2_TB5
-#undef Q2_PF14
-#undef Q2_NREG
+#undef Q2_PF6
+#undef Q2_VMCNT0
+#undef Q2_PL_LOAD
+#undef Q2_PL_STORE
 #undef Q2_TB_DECL
 #undef Q2_PF_DECL
 #undef Q2_PF_LOAD
@@ -943,17 +946,6 @@ int pk_forest_q_plan(pk_forest *f)
         else Q_LAUNCH_P(CH, WPT, HALF1, false, EARLY);                                         \
     } while (0)
 
-// forest_q2_kernel: the first wave that never walks (no group has more than q_slots trees), if the
-// waves from there on can hold a whole group in twelve 16-byte registers per lane; else 16
-static int q2_help_from(const pk_forest *f, const pk_q_layout &L)
-{
-    const int helpers = 16 - f->q_slots;
-    if (!g_opt.forest_q_help || helpers < 4) return 16;
-    // (12 = Q2_NREG registers per helper lane, one per walker lane)
-    if (((int64_t)helpers * 12 + f->q_slots) * 64 * 16 < (int64_t)f->q_max_group_bytes) return 16;
-    return f->q_slots;
-}
-
 // Room for the rank tiles of `cn` candidates (scratch of the context; grows only).
 int pk_forest_q_reserve(pk_device_ctx *ctx, pk_forest *f, int64_t cn)
 {
@@ -1044,10 +1036,10 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     } else if (L.ch == 2) {
         Q_LAUNCH(2, 1, 32768, false);
     } else if (L.ch == 1 && g_opt.forest_q_two && !(prune_sum > -1e300) && cn > 64 && f->F <= 639 &&
-               (f->q_max_group_bytes <= 6 * 16384 || q2_help_from(f, L) < 16)) {
-        // two rank tiles per trip (see forest_q2_kernel); the waves that never walk stage the groups
-        // when twelve registers of theirs hold one (option forest_q_help, on)
-        const int help_from = q2_help_from(f, L);
+               f->q_max_group_bytes <= 6 * 16384) {
+        // two rank tiles per trip (see forest_q2_kernel); the waves that walk load their share of
+        // the next group behind the first walk (option forest_q_help, on)
+        const int late_below = g_opt.forest_q_help ? f->q_slots : 0;
         int rc2 = q_set_max_lds(forest_q2_kernel, 163840);
         if (rc2) return rc2;
         unsigned grid2 = (unsigned)((cn + 127) / 128);
@@ -1055,7 +1047,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         hipLaunchKernelGGL(forest_q2_kernel, dim3(grid2), dim3(Q_THREADS), 163840, ctx->stream,
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab),
                            f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.val_off, L.img_off,
-                           ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)g_opt.forest_dbg, help_from);
+                           ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)g_opt.forest_dbg, late_below);
     } else if (L.ch == 1) {
         Q_LAUNCH(1, 1, 32768, false);
     } else {

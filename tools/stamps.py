@@ -37,16 +37,18 @@ if (2 * w + 1) ** 2 > 255 and not os.environ.get("PK_STAMP_Q1"):
     ng = int((st[0, :, 0] != 0).sum())
     st = st[:, :ng, :].astype(np.float64)
     walkers = np.arange(16) < int(os.environ.get("PK_STAMP_WALKERS", "7"))  # waves with a tree
-    names = ["issue loads + walk tile 1", "barrier", "ordered sum + tile swap", "barrier",
-             "walk tile 2", "barrier", "ordered sum + commit + barrier"]
+    names = ["issue loads + walk tile 1", "barrier", "issue loads + ordered sum + tile swap", "barrier",
+             "walk tile 2", "barrier", "ordered sum + wait for the loads", "commit + barrier"]
+    st = np.concatenate([st, np.concatenate([st[:, 1:, :1], st[:, -1:, 7:8]], axis=1)], axis=2)  # end = next start
     print("forest_q2_kernel: groups", ng, "(first 32 at most); cycles per group, mean over the %d walking waves | all 16"
           % walkers.sum())
     for k, nm in enumerate(names):
         d = st[:, :, k + 1] - st[:, :, k]
-        print("  %-32s %8.0f | %8.0f" % (nm, d[walkers].mean(), d.mean()))
-    print("  %-32s %8.0f" % ("total per group", (st[:, :, 7] - st[:, :, 0]).mean()))
+        d = d[:, :-1]
+        print("  %-38s %8.0f | %8.0f" % (nm, d[walkers].mean(), d.mean()))
+    print("  %-32s %8.0f" % ("total per group", (st[:, :-1, 8] - st[:, :-1, 0]).mean()))
     for k, nm in enumerate(names):
-        print("  per wave, %-28s" % nm, np.round((st[:, :, k + 1] - st[:, :, k]).mean(1)).astype(int).tolist())
+        print("  per wave, %-38s" % nm, np.round((st[:, :-1, k + 1] - st[:, :-1, k]).mean(1)).astype(int).tolist())
     sys.exit(0)
 buf = np.zeros(16 * 32 * 5, np.int64)
 _lib.check(L.pk_debug_read(0, buf, buf.size), "dbg")
