@@ -474,6 +474,11 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             }
             Q_STAMP(1);
             if (EARLY) {
+                // (the staging loads were issued in front of the walk: an explicit vmcnt(0) here costs
+                // nothing and lets the compiler see that no load is pending on a staging register when
+                // the next group's loads overwrite it -- without it every load of a group waits for
+                // the one before, see forest_q2_kernel: 4.39 -> 4.10 ms, still behind 3.79)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
                 // this wave no longer reads the tree of its slot; when its partner does not
                 // either, each stages its half of the slot's next tree.  The partner waits for
                 // nothing before it counts itself in, so the wait is bounded by its walk.
