@@ -255,6 +255,15 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
 #define Q_PF_LOAD(q)                                                           \
     if constexpr ((q) < PFN)                                                   \
         if ((q) * pf_stride < pf_nu) pf##q = pf_src[min(pf_i0 + (q) * pf_stride, pf_nu - 1)];
+#define Q_PF_LOADX(q)                                                                           \
+    if constexpr ((q) < PFN) {                                                                  \
+        if ((q) < 3) {                                                                          \
+            if ((q) * ld_stride < ld_lo) pf##q = pf_src[min(ld_i0 + (q) * ld_stride, ld_lo - 1)];  \
+        } else {                                                                                \
+            const int r_ = (q) * ld_stride - ld_shift;                                          \
+            if (r_ < ld_hi) pf##q = pf_src[ld_base + min(ld_i0 + r_, ld_hi - 1)];               \
+        }                                                                                       \
+    }
 #define Q_PF_STORE(q)                                                          \
     if constexpr ((q) < PFN) {                                                 \
         const int u = pf_i0 + (q) * pf_stride;                                 \
@@ -398,28 +407,38 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             const int4 g_nxt = gtab[g + 1];
             const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];  // (scalar loads: in flight during the walk)
             Q_STAMP(0);
+            // What the staging registers fetch during this walk: the next group, or (last group) the
+            // next tile -- through ONE set of load instructions.  (With a second set for the tile the
+            // compiler loads it into copies of the staging registers, registers the walk uses as
+            // temporaries: the s_waitcnt vmcnt(0) that protects them stood in front of EVERY group's
+            // walk and made each wave wait for its eight staging loads to return before walking.)
+            // register q < 3: units ld_i0 + q * ld_stride of the first ld_lo; q >= 3: units
+            // ld_i0 + q * ld_stride - ld_shift of the ld_hi that follow ld_base
+            bool ld_on = false;
+            int ld_i0 = pf_i0, ld_stride = pf_stride, ld_lo = 0, ld_hi = 0, ld_base = 0, ld_shift = 0;
             if (g + 1 < n_grp) {  // loads fly while this group is walked
                 stage_of(g_nxt, tt_nxt);
-                Q_PF16(Q_PF_LOAD)
+                ld_lo = ld_hi = pf_nu;
+                ld_on = true;
             } else if (wg_next < n_wg && (HB >> 4) <= (CH == 4 ? 3 : 6) * THREADS) {
                 // last group of this tile: the next tile travels global -> VGPR during the walk
                 const int64_t cb = wg_next * C;
                 // (into the staging registers, which carry nothing during the last group: registers
-                // 0-2 the first rank tile, 3-5 the second; <= 3 x 1024 units of 16 B per tile)
-                const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cb * F);
+                // 0-2 the first rank tile, 3-5 the second; <= 3 x 1024 units of 16 B per tile; CH < 4:
+                // one tile of <= 6 x 1024 units)
+                pf_src = reinterpret_cast<const v4u *>(qtiles + (size_t)cb * F);
                 const int upt = HB >> 4;
-                const bool two = CH == 4 && cb + 128 < cn;
-#define Q_TILE_LOAD(q, half, j)                                                   \
-    if ((j) * THREADS < upt && ((half) == 0 || two))                              \
-        pf##q = src[(half) * upt + min(tid + (j) * THREADS, upt - 1)];
-                if (CH == 4) {  // two tiles of <= 3 x 1024 units
-                    Q_TILE_LOAD(0, 0, 0) Q_TILE_LOAD(1, 0, 1) Q_TILE_LOAD(2, 0, 2)
-                    Q_TILE_LOAD(3, 1, 0) Q_TILE_LOAD(4, 1, 1) Q_TILE_LOAD(5, 1, 2)
-                } else {  // one tile of <= 6 x 1024 units
-                    Q_TILE_LOAD(0, 0, 0) Q_TILE_LOAD(1, 0, 1) Q_TILE_LOAD(2, 0, 2)
-                    Q_TILE_LOAD(3, 0, 3) Q_TILE_LOAD(4, 0, 4) Q_TILE_LOAD(5, 0, 5)
+                ld_i0 = tid;
+                ld_stride = THREADS;
+                ld_lo = upt;
+                if (CH == 4) {
+                    ld_hi = cb + 128 < cn ? upt : 0;
+                    ld_base = upt;
+                    ld_shift = 3 * THREADS;
+                } else {
+                    ld_hi = upt;
                 }
-#undef Q_TILE_LOAD
+                ld_on = true;
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     const int64_t loc = cb + lane + 64 * (NCH * sub + c);
@@ -435,6 +454,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
                     for (int line = tid; line < F * CH; line += THREADS)
                         warm_sink += reinterpret_cast<const unsigned *>(qtiles + (size_t)ahead * C * F)[line * 32];
             }
+            if (ld_on) { Q_PF16(Q_PF_LOADX) }
             bool walk[NCH];
             bool any_walk = false;
 #pragma unroll
@@ -498,6 +518,15 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             }
             __syncthreads();  // every walk of the group is done (EARLY: and the next group staged)
             Q_STAMP(2);
+            // Everything this wave has loaded (the next group, or the next tile and its status bytes)
+            // has had the whole walk to arrive: an explicit vmcnt(0) here is free, and it is what
+            // lets the compiler see that no load is pending on any register when the next iteration
+            // starts.  Without it the status bytes the LAST group prefetches count as pending all
+            // around the loop, their register is reused in front of the walk, and the s_waitcnt
+            // vmcnt(0) the compiler puts there makes every wave wait for its eight staging loads to
+            // RETURN before it walks (found in the assembly in round 3; it is the "12 % the staging
+            // loads cost" of the ablation above).
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             if (!EARLY && g + 1 < n_grp && !(dbg & 4)) { Q_PF16(Q_PF_STORE) }  // (dbg 4: timing ablation, wrong results)
             const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
             if (owner && active && undecided) {
