@@ -210,30 +210,51 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
         q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1); \
     } while (0)
     if (POS >= 0) {
-        // (four levels per priority measured best: 3.85 ms; two 3.91, one 3.93, none 4.01)
+        // (round 2: four levels per priority measured best: 3.85 ms; two 3.91, one 3.93, none 4.01)
+        // The priority of a wave in block b of four levels is (POS + O_b) & 3.  Round 2 stepped UP
+        // (O = 0, 1, 2, 3, then one level per priority); stepping DOWN after the first block
+        // (0, 3, 2, 1; the last four levels two at POS, two at POS + 3) is 3 % faster on the same
+        // box, 3.66 -> 3.55 ms: the waves of the highest position start last (the load issue in
+        // front of the walk is served in wave order) and this order lets them finish with the
+        // others.  Eleven schedules measured (profiles/r03_prio_schedules.log); -DPK_Q_O0=.. etc.
+        // build another one.
+#ifndef PK_Q_O0
+#define PK_Q_O0 0
+#define PK_Q_O1 3
+#define PK_Q_O2 2
+#define PK_Q_O3 1
+#define PK_Q_OT 0
+#define PK_Q_OT2 3
+#endif
         for (; d >= 16; d -= 16) {
-            __builtin_amdgcn_s_setprio((POS + 0) & 3);
+            __builtin_amdgcn_s_setprio((POS + PK_Q_O0) & 3);
             Q_TWO_LEVELS();
             Q_TWO_LEVELS();
-            __builtin_amdgcn_s_setprio((POS + 1) & 3);
+            __builtin_amdgcn_s_setprio((POS + PK_Q_O1) & 3);
             Q_TWO_LEVELS();
             Q_TWO_LEVELS();
-            __builtin_amdgcn_s_setprio((POS + 2) & 3);
+            __builtin_amdgcn_s_setprio((POS + PK_Q_O2) & 3);
             Q_TWO_LEVELS();
             Q_TWO_LEVELS();
-            __builtin_amdgcn_s_setprio((POS + 3) & 3);
+            __builtin_amdgcn_s_setprio((POS + PK_Q_O3) & 3);
             Q_TWO_LEVELS();
             Q_TWO_LEVELS();
         }
-        for (; d >= 4; d -= 4) {  // what is left of the depth: one level per priority
-            __builtin_amdgcn_s_setprio((POS + 0) & 3);
+        for (; d >= 4; d -= 4) {  // what is left of the depth
+#ifdef PK_Q_OT2
+            __builtin_amdgcn_s_setprio((POS + PK_Q_OT) & 3);
             q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            __builtin_amdgcn_s_setprio((POS + 1) & 3);
             q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            __builtin_amdgcn_s_setprio((POS + 2) & 3);
+            __builtin_amdgcn_s_setprio((POS + PK_Q_OT2) & 3);
             q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            __builtin_amdgcn_s_setprio((POS + 3) & 3);
             q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+#else
+            __builtin_amdgcn_s_setprio((POS + PK_Q_OT) & 3);
+            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+#endif
         }
         for (; d >= 2; d -= 2) Q_TWO_LEVELS();
     } else {
