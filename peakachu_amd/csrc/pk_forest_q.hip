@@ -211,50 +211,37 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
     } while (0)
     if (POS >= 0) {
         // (round 2: four levels per priority measured best: 3.85 ms; two 3.91, one 3.93, none 4.01)
-        // The priority of a wave in block b of four levels is (POS + O_b) & 3.  Round 2 stepped UP
-        // (O = 0, 1, 2, 3, then one level per priority); stepping DOWN after the first block
-        // (0, 3, 2, 1; the last four levels two at POS, two at POS + 3) is 3 % faster on the same
-        // box, 3.66 -> 3.55 ms: the waves of the highest position start last (the load issue in
-        // front of the walk is served in wave order) and this order lets them finish with the
-        // others.  Eleven schedules measured (profiles/r03_prio_schedules.log); -DPK_Q_O0=.. etc.
-        // build another one.
-#ifndef PK_Q_O0
-#define PK_Q_O0 0
-#define PK_Q_O1 3
-#define PK_Q_O2 2
-#define PK_Q_O3 1
-#define PK_Q_OT 0
-#define PK_Q_OT2 3
+        // The priority of a wave by its position POS (among the four waves of its SIMD) and the block
+        // of levels: four blocks of four, then two of two (depth 20).  Round 2 stepped UP,
+        // (POS + {0,1,2,3}) & 3 and one level per priority at the end; stepping DOWN after the first
+        // block, (POS + {0,3,2,1}) & 3 and POS, POS + 3 at the end, is 3 % faster on the same box,
+        // 3.66 -> 3.55 ms: the waves of the highest position start last (the load issue in front of
+        // the walk is served in wave order) and this order lets them finish with the others.
+        // Schedules measured: profiles/r03_prio_schedules.log; -DPK_Q_PRIO_TAB=... builds another.
+#ifndef PK_Q_PRIO_TAB
+#define PK_Q_PRIO_TAB {0, 3, 2, 1, 0, 3}, {1, 0, 3, 2, 1, 0}, {2, 1, 0, 3, 2, 1}, {3, 2, 1, 0, 3, 2}
 #endif
+        constexpr int PT[4][6] = {PK_Q_PRIO_TAB};
+        constexpr int PP = POS & 3;
         for (; d >= 16; d -= 16) {
-            __builtin_amdgcn_s_setprio((POS + PK_Q_O0) & 3);
+            __builtin_amdgcn_s_setprio(PT[PP][0]);
             Q_TWO_LEVELS();
             Q_TWO_LEVELS();
-            __builtin_amdgcn_s_setprio((POS + PK_Q_O1) & 3);
+            __builtin_amdgcn_s_setprio(PT[PP][1]);
             Q_TWO_LEVELS();
             Q_TWO_LEVELS();
-            __builtin_amdgcn_s_setprio((POS + PK_Q_O2) & 3);
+            __builtin_amdgcn_s_setprio(PT[PP][2]);
             Q_TWO_LEVELS();
             Q_TWO_LEVELS();
-            __builtin_amdgcn_s_setprio((POS + PK_Q_O3) & 3);
+            __builtin_amdgcn_s_setprio(PT[PP][3]);
             Q_TWO_LEVELS();
             Q_TWO_LEVELS();
         }
         for (; d >= 4; d -= 4) {  // what is left of the depth
-#ifdef PK_Q_OT2
-            __builtin_amdgcn_s_setprio((POS + PK_Q_OT) & 3);
-            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            __builtin_amdgcn_s_setprio((POS + PK_Q_OT2) & 3);
-            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-#else
-            __builtin_amdgcn_s_setprio((POS + PK_Q_OT) & 3);
-            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-            q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
-#endif
+            __builtin_amdgcn_s_setprio(PT[PP][4]);
+            Q_TWO_LEVELS();
+            __builtin_amdgcn_s_setprio(PT[PP][5]);
+            Q_TWO_LEVELS();
         }
         for (; d >= 2; d -= 2) Q_TWO_LEVELS();
     } else {
