@@ -86,7 +86,11 @@ struct pk_options {
     int64_t forest_l2_tile = 0; // large F: 1 = keep the LDS feature tile (one wave per CU), 0 = no-LDS kernel
     int64_t early_exit = 0;     // pk_score_run: stop walking candidates that provably end at p <= thre
                                 // (identical output pixels; per-candidate probabilities of pruned pixels read 0)
-    int64_t forest_dbg = 0;     // timing-only ablations of the LDS forest kernel (wrong results)
+    // diagnostics of the rank kernels (pk_forest_q.hip), bits: 2 no walk, 4 no commit stores, 8 every
+    // lane takes the left child (2, 4, 8: timing ablations, WRONG results); 16 in-kernel cycle stamps
+    // of workgroup 0 (tools/stamps.py); 32 no wave priorities (set by forest_q_prio = 0);
+    // 128 forest_q2_kernel without its L2 warm-up
+    int64_t forest_dbg = 0;
     int64_t forest_q = 1;       // rank-quantised tiles + 4-byte nodes (forest_q_kernel) when the forest fits
     int64_t forest_q_two = 1;   // 64-candidate shape: two rank tiles per workgroup trip (forest_q2_kernel)
     int64_t forest_q_help = 1;  // forest_q2_kernel: the waves that walk load their share of a group behind the first walk
