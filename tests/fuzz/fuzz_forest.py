@@ -86,6 +86,8 @@ def main():
             opts["forest_slots"] = int(rng.choice([2, 3, 5, 8, 11, 16]))
         if rng.random() < 0.1:
             opts["forest_q"] = 0
+        if F > 255 and rng.random() < 0.4:  # the wide word: one tile or two per trip, walkers loading early or late
+            opts[str(rng.choice(["forest_q_two", "forest_q_help"]))] = 0
         old = {k: L.pk_get_option(k.encode()) for k in opts}
         try:
             for k, v in opts.items():
