@@ -93,7 +93,9 @@ def make(out, n):
             i, j, v = b1[m] - lo, b2[m] - lo, cnt[m]
             nbin = hi - lo
             for tag, w in (("raw", None), ("weight", weight[lo:hi]), ("KR", kr[lo:hi])):
-                vv = v if w is None else (v / (w[i] * w[j]) if tag == "KR" else w[i] * w[j] * v)
+                # (divisive columns: the biases inverted first, then applied like multiplicative ones --
+                # the order peakachu_amd.cool uses; unverified against cooler itself, see cool.py)
+                vv = v if w is None else ((1.0 / w)[i] * (1.0 / w)[j] * v if tag == "KR" else w[i] * w[j] * v)
                 od = i != j
                 rows = np.concatenate([i, j[od]]); cols = np.concatenate([j, i[od]]); vals = np.concatenate([vv, vv[od]])
                 oo = np.lexsort((cols, rows))
