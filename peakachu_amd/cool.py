@@ -18,11 +18,13 @@ the biases are inverted first (`bias = 1 / bias`) and then applied the same way,
 last bits.  cooler is not installed in the build image: the restatement is pinned against
 files written by the genuine HDF5 library in cooler's layout (tools/make_cool_fixture.py),
 NOT against cooler itself.  The multiplicative path (`weight`, what peakachu's default
-`--clr-weight-name weight` uses) is a plain product with one possible operand order issue
-(none: the product of the two weights is formed first, so the result is symmetric); the
-divisive path's order of operations is recalled from cooler's source, UNVERIFIED -- where
-`cooler` is importable `io.open_map` uses it instead of this class.
+`--clr-weight-name weight` uses) is a plain product, `(w[row] * w[col]) * count`: the two
+weights are multiplied first, so the result is exactly symmetric.  The divisive path's order
+of operations is recalled from cooler's source (`bias = 1 / bias`, then
+`bias[row] * bias[col] * count`) and is UNVERIFIED: no file written by cooler itself pins it.
+Where `cooler` is importable `io.open_map` uses it instead of this class.
 """
+import contextlib
 import threading
 
 import numpy as np
@@ -71,8 +73,12 @@ class CoolFile:
         self.chromsizes = dict(zip(self.chromnames, (int(v) for v in self._g["chroms/length"].read())))
         self._chrom_offset = self._g["indexes/chrom_offset"].read().astype(np.int64)
         self._bin1_offset = None
-        self._pixel_cache = {}  # chromosome -> its mirrored pixels; the last two (two reader threads)
+        # chromosome -> its mirrored pixels.  An entry a reader holds (`hold`) is never evicted,
+        # whatever the number of reader threads; of the others the last two stay.
+        self._pixel_cache = {}
+        self._pixel_pins = {}
         self._pixel_lock = threading.Lock()
+        self.pixel_reads = 0  # times a chromosome's pixels were read and inflated (tests)
         self.binsize = a.get("bin-size")
         if not isinstance(self.binsize, int):
             st, en = self._g["bins/start"][0:1], self._g["bins/end"][0:1]
@@ -80,6 +86,31 @@ class CoolFile:
 
     def close(self):
         self._f.close()
+
+    @contextlib.contextmanager
+    def hold(self, chrom):
+        """Keeps the chromosome's pixels cached while the caller makes its fetches (balanced
+        values, then raw counts: peakachu/score_genome.py:55-56), however many other chromosomes
+        other threads read meanwhile -- with three reader threads and a cache of the last two
+        a chromosome's entry used to be gone before its second fetch (pixels read twice)."""
+        with self._pixel_lock:
+            self._pixel_pins[chrom] = self._pixel_pins.get(chrom, 0) + 1
+        try:
+            yield self
+        finally:
+            with self._pixel_lock:
+                left = self._pixel_pins[chrom] - 1
+                if left:
+                    self._pixel_pins[chrom] = left
+                else:
+                    del self._pixel_pins[chrom]
+                self._evict()
+
+    def _evict(self, keep=2):
+        """(lock held) the oldest entries nobody holds go, until `keep` of those are left."""
+        free = [k for k in self._pixel_cache if k not in self._pixel_pins]  # insertion order
+        for k in free[:max(0, len(free) - keep)]:
+            del self._pixel_cache[k]
 
     # -- metadata
     def extent(self, chrom):
@@ -153,9 +184,9 @@ class CoolFile:
         for a in out:
             a.flags.writeable = False
         with self._pixel_lock:
+            self.pixel_reads += 1
             self._pixel_cache[chrom] = out
-            while len(self._pixel_cache) > 2:  # (dicts keep insertion order: the oldest goes)
-                del self._pixel_cache[next(iter(self._pixel_cache))]
+            self._evict()
         return out
 
     @staticmethod

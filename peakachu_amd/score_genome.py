@@ -4,6 +4,7 @@ Same flags, same chromosome selection, same output; chromosomes are dealt to
 the ranks of a torch.distributed.run launch (one per GPU) and rank 0 writes
 the bedpe in the reference's order after one RCCL gather.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -25,9 +26,13 @@ def select_chromosomes(chromnames, chroms):
 def fetch_inputs(Lib, key, correct):
     """The reads of peakachu/score_genome.py:55-57 (balanced) / :63 (raw) for one chromosome."""
     if correct:
-        return (Lib.matrix(balance=correct, sparse=True).fetch(key),
-                Lib.matrix(balance=False, sparse=True).fetch(key),
-                Lib.bins().fetch(key)[correct].values)
+        # the built-in reader keeps the chromosome's pixels for the second fetch (cooler has
+        # no such notion: nullcontext)
+        hold = getattr(Lib, "hold", None)
+        with (hold(key) if hold else contextlib.nullcontext()):
+            return (Lib.matrix(balance=correct, sparse=True).fetch(key),
+                    Lib.matrix(balance=False, sparse=True).fetch(key),
+                    Lib.bins().fetch(key)[correct].values)
     return Lib.matrix(balance=False, sparse=True).fetch(key), None, None
 
 

@@ -184,6 +184,10 @@ def test_chromosomes_read_on_two_threads_and_shared_arrays():
         finally:
             del os.environ["PK_PREFETCH"]
         assert [k for k, _ in got] == names
+        # every chromosome's pixels were read ONCE per visit, whatever the number of readers
+        # (round 3: a cache of two entries under three threads lost the entry between a
+        # chromosome's balanced and raw fetch)
+        assert c.pixel_reads <= len(names), (depth, c.pixel_reads)
         for (_, (M, R, wts)), (M0, R0, w0) in zip(got, want):
             for A, B in ((M, M0), (R, R0)):
                 assert np.array_equal(A.row, B.row) and np.array_equal(A.col, B.col)
