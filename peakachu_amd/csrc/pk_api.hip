@@ -272,6 +272,8 @@ extern "C" int pk_set_option(const char *name, int64_t value)
         g_opt.forest_q_two = value != 0;
     } else if (!strcmp(name, "forest_q_help")) {
         g_opt.forest_q_help = value != 0;
+    } else if (!strcmp(name, "forest_q_rsv")) {
+        g_opt.forest_q_rsv = value != 0;
     } else if (!strcmp(name, "forest_dbg")) {
         g_opt.forest_dbg = value;
     } else if (!strcmp(name, "forest_q")) {
@@ -325,6 +327,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!strcmp(name, "forest_q_prio")) return g_opt.forest_q_prio;
     if (!strcmp(name, "forest_q_two")) return g_opt.forest_q_two;
     if (!strcmp(name, "forest_q_help")) return g_opt.forest_q_help;
+    if (!strcmp(name, "forest_q_rsv")) return g_opt.forest_q_rsv;
     if (!strcmp(name, "forest_dbg")) return g_opt.forest_dbg;
     if (!strcmp(name, "forest_q_early")) return g_opt.forest_q_early;
     return -1;

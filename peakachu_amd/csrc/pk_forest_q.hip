@@ -590,6 +590,334 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 }
 
 // ------------------------------------------------------------------------
+// forest_qr_kernel (round 4) = forest_q_kernel<4, 2, HALF1, PRUNE, false> -- 256 candidates, eight
+// trees, two waves per tree -- with the STAGING REGISTERS TAKEN AWAY FROM THE COMPILER.
+//
+// Round 3 measured (DESIGN.md 4.2 iii): the 67 wave-loads of the next tree group, issued by all
+// sixteen waves at once in front of the walk, queue up in the CU's memory pipeline and every wave
+// stands still until its own are accepted; issued from INSIDE the walk, a few levels in and one
+// SIMD position at a time, the stage is 7 % faster -- but every C++ form of that either moved the
+// eight 16-byte staging registers to scratch, doubled the register demand or slowed the walk,
+// because the compiler has to keep registers with loads in flight alive across the unrolled walk.
+// Here the kernel is compiled for 96 VGPRs (amdgpu_num_vgpr) and v96..v127 -- which a
+// 1024-thread workgroup owns anyway -- are used by inline assembly only: eight global_load_dwordx4
+// into fixed registers wherever the walk wants them, one explicit s_waitcnt vmcnt(0) behind the
+// barrier, eight ds_write_b128 from the same registers.  The compiler never sees a value in
+// them, so it neither waits for them nor moves them, and its own s_waitcnt arithmetic stays safe
+// (extra loads in flight only make its vmcnt waits conservative: loads return in order).
+// The loads carry no per-thread clamp: the image and the rank-tile buffer are padded by what a
+// register row can read past their ends (pk_q_pad_bytes).
+// ------------------------------------------------------------------------
+#define QR_REGS(X)                                                                          \
+    X(0, "v[96:99]") X(1, "v[100:103]") X(2, "v[104:107]") X(3, "v[108:111]")               \
+    X(4, "v[112:115]") X(5, "v[116:119]") X(6, "v[120:123]") X(7, "v[124:127]")
+// register q < 3 reads 16 KiB row q behind ld_b0, q >= 3 row q - 3 behind ld_b1 (a tree group: one
+// piece, ld_b1 = ld_b0 + 48 KiB; the next tile: its two rank tiles).  ONE block of assembly: as
+// separate C++ statements the compiler lays every conditional load out of line (two taken
+// branches per load); here a row that is asked for falls through.
+#define QR_LD_ROW(q, R)                                              \
+    "s_bitcmp1_b32 %[m], " #q "\n\t"                                  \
+    "s_cbranch_scc0 .Lqr" #q "_%=\n\t"                                \
+    "global_load_dwordx4 " R ", %[vo], %[p" #q "]\n"                  \
+    ".Lqr" #q "_%=:\n\t"
+#define QR_ISSUE()                                                                                         \
+    asm volatile(QR_LD_ROW(0, "v[96:99]") QR_LD_ROW(1, "v[100:103]") QR_LD_ROW(2, "v[104:107]")            \
+                 QR_LD_ROW(3, "v[108:111]") QR_LD_ROW(4, "v[112:115]") QR_LD_ROW(5, "v[116:119]")          \
+                 QR_LD_ROW(6, "v[120:123]") QR_LD_ROW(7, "v[124:127]")                                     \
+                 ::[m] "s"(__builtin_amdgcn_readfirstlane(ld_mask)), [vo] "v"(voff), [p0] "s"(ld_b0), [p1] "s"(ld_b0 + 16384),             \
+                 [p2] "s"(ld_b0 + 32768), [p3] "s"(ld_b1), [p4] "s"(ld_b1 + 16384), [p5] "s"(ld_b1 + 32768), \
+                 [p6] "s"(ld_b1 + 49152), [p7] "s"(ld_b1 + 65536)                                          \
+                 : "scc")
+#define QR_ST_GROUP(q, R)                                                                   \
+    if ((q) * 1024 < st_nu) {                                                               \
+        if (tid + (q) * 1024 < st_nu)                                                       \
+            asm volatile("ds_write_b128 %0, " R " offset:%1" ::"v"((q) < 4 ? st_a0 : st_a1), \
+                         "n"(((q) & 3) * 16384)                                             \
+                         : "memory");                                                       \
+    }
+#define QR_ST_TILE(q, R)                                                                    \
+    if ((q) < 6 && ((q) % 3) * 1024 < upt && ((q) < 3 || two)) {                            \
+        if (tid + ((q) % 3) * 1024 < upt)                                                   \
+            asm volatile("ds_write_b128 %0, " R " offset:%1" ::"v"((q) < 3 ? tl_a0 : tl_a1), \
+                         "n"(((q) % 3) * 16384)                                             \
+                         : "memory");                                                       \
+    }
+#ifndef PK_QR_AT
+#define PK_QR_AT(pos) ((pos) + 1)  // the staging loads go out behind this many PAIRS of levels
+#endif
+#ifndef PK_QR_VGPRS
+#define PK_QR_VGPRS 96
+#endif
+
+// the walk of q_walk<2, X0, HALF1, WITH_NAN, false, POS> (same levels, same priority schedule)
+// with `issue()` called once, PK_QR_AT(POS) pairs of levels in (trees of fewer than 16 levels: in
+// front of the walk)
+template <int X0, int HALF1, bool WITH_NAN, int POS, typename ISSUE>
+__device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase, unsigned lk0, unsigned lk1,
+                                        double (&v)[2], ISSUE issue)
+{
+    unsigned w[2] = {root, root};
+    int d = depth;
+    constexpr int PT[4][6] = {PK_Q_PRIO_TAB};
+    constexpr int PP = POS & 3;
+    constexpr int AT = PK_QR_AT(PP);
+#define QR_TWO(k_)                                                     \
+    do {                                                               \
+        if (AT == (k_)) issue();                                       \
+        q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);    \
+        q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);    \
+    } while (0)
+    if (d >= 16) {
+        __builtin_amdgcn_s_setprio(PT[PP][0]);
+        QR_TWO(0);
+        QR_TWO(1);
+        __builtin_amdgcn_s_setprio(PT[PP][1]);
+        QR_TWO(2);
+        QR_TWO(3);
+        __builtin_amdgcn_s_setprio(PT[PP][2]);
+        QR_TWO(4);
+        QR_TWO(5);
+        __builtin_amdgcn_s_setprio(PT[PP][3]);
+        QR_TWO(6);
+        QR_TWO(7);
+        if (AT >= 8) issue();
+        d -= 16;
+    } else {
+        issue();
+    }
+    for (; d >= 16; d -= 16) {
+        __builtin_amdgcn_s_setprio(PT[PP][0]);
+        QR_TWO(-1);
+        QR_TWO(-1);
+        __builtin_amdgcn_s_setprio(PT[PP][1]);
+        QR_TWO(-1);
+        QR_TWO(-1);
+        __builtin_amdgcn_s_setprio(PT[PP][2]);
+        QR_TWO(-1);
+        QR_TWO(-1);
+        __builtin_amdgcn_s_setprio(PT[PP][3]);
+        QR_TWO(-1);
+        QR_TWO(-1);
+    }
+    for (; d >= 4; d -= 4) {
+        __builtin_amdgcn_s_setprio(PT[PP][4]);
+        QR_TWO(-1);
+        __builtin_amdgcn_s_setprio(PT[PP][5]);
+        QR_TWO(-1);
+    }
+    for (; d >= 2; d -= 2) QR_TWO(-1);
+#undef QR_TWO
+    if (d) q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int c = 0; c < 2; c++) v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index<false>(w[c]) + 1) << 3));
+}
+
+template <int HALF1, bool PRUNE>
+__global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGPRS))) void forest_qr_kernel(
+    const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
+    int F, int dec_off, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
+    const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob, double prune_sum,
+    int dbg, long long *__restrict__ stamps)
+{
+    constexpr int THREADS = Q_THREADS;
+    constexpr int C = 256;
+    constexpr int NCH = 2;  // walks per lane of one wave
+    // v96..v127 belong to the inline assembly below (the register count of the kernel covers them)
+    asm volatile("" ::: "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
+                 "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117",
+                 "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
+    const int HB = F * 256;  // bytes of a rank tile [F][64][2] u16
+    const int upt = HB >> 4;
+    const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
+    if (!lds_at_zero && threadIdx.x == 0 && stamps) stamps[65535] = 2;
+    const char *const img_b = reinterpret_cast<const char *>(img);
+
+    const int64_t n_wg = (cn + C - 1) / C;
+    unsigned stc_n[NCH] = {}, st_n = 0;
+    bool tile_ready = false;  // (uniform) the tile of this trip is in LDS already
+    for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // (see forest_q_kernel: keeps per-trip addresses inside the trip)
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int slot = wave >> 1, sub = wave & 1;  // tree slot; which rank tile
+        const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
+        const unsigned voff = (unsigned)tid << 4;    // this thread's 16 bytes of a 16-KiB row
+        if (wg != (int64_t)blockIdx.x) __syncthreads();  // nobody reads the previous trip's flags any more
+        if (PRUNE)
+            for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
+        const int64_t cbase = wg * C;
+        if (!tile_ready) {
+            const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
+            const int halves = cbase + 128 < cn ? 2 : 1;
+            const int nu = halves * upt;
+            for (int i = tid; i < nu; i += THREADS) {
+                const int o = i << 4;
+                *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = src[i];
+            }
+        }
+        unsigned stc[NCH];
+        bool act[NCH];
+        bool any_nan = false;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int64_t loc = cbase + lane + 64 * (NCH * sub + c);
+            stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[c0 + loc] : 0);
+            act[c] = stc[c] != 0 && lds_at_zero;
+            any_nan = any_nan || stc[c] == 2;
+        }
+        const bool wave_nan = __any(any_nan);
+        const bool owner = tid < C;
+        const int64_t local = cbase + tid;
+        const bool valid = owner && local < cn;
+        const unsigned st = tile_ready ? st_n : (valid ? status[c0 + local] : 0);
+        const bool active = st != 0 && lds_at_zero;
+        const int64_t wg_next = wg + gridDim.x;
+        bool fetched = false;
+
+        // what the staging registers are asked to fetch next (uniform)
+        unsigned ld_mask;
+        const char *ld_b0, *ld_b1;
+        auto issue = [&]() __attribute__((always_inline)) { QR_ISSUE(); };
+        int4 g_cur = gtab[0];
+        int4 tt = ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree: offset, depth, root word, units
+        int st_nu = g_cur.w;                          // units of 16 B of the group in the registers
+        const unsigned st_a0 = (unsigned)img_off + voff, st_a1 = st_a0 + 65536u;
+        {   // first group: global -> registers -> LDS
+            ld_b0 = img_b + (size_t)g_cur.z * 16;
+            ld_b1 = ld_b0 + 3 * 16384;
+            ld_mask = (1u << ((st_nu + 1023) >> 10)) - 1u;
+            issue();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QR_REGS(QR_ST_GROUP)
+        }
+        __syncthreads();  // rank tiles and first group are in LDS
+
+#define QR_STAMP(slot_)                                                                  \
+    do {                                                                                 \
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && g < 32)              \
+            stamps[((tid >> 6) * 32 + g) * 5 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+        double acc = 0.0;
+        for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
+            const int t0 = g_cur.x, gt = g_cur.y;
+            const int4 g_nxt = gtab[g + 1];
+            const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];
+            QR_STAMP(0);
+            ld_mask = 0;
+            ld_b0 = ld_b1 = img_b;
+            if (g + 1 < n_grp) {  // the next group flies while this one is walked
+                ld_b0 = img_b + (size_t)g_nxt.z * 16;
+                ld_b1 = ld_b0 + 3 * 16384;
+                ld_mask = (dbg & 64) ? 0u : (1u << ((g_nxt.w + 1023) >> 10)) - 1u;  // (64: timing ablation, wrong results)
+            } else if (wg_next < n_wg && upt <= 3 * THREADS) {
+                // last group of this tile: the next tile travels global -> registers during the walk
+                // (registers 0-2 its first rank tile, 3-5 the second) with its status bytes
+                const int64_t cb = wg_next * C;
+                ld_b0 = reinterpret_cast<const char *>(qtiles + (size_t)cb * F);
+                ld_b1 = ld_b0 + HB;
+                const unsigned rows = (1u << ((upt + 1023) >> 10)) - 1u;
+                ld_mask = rows | (cb + 128 < cn ? rows << 3 : 0u);
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const int64_t loc = cb + lane + 64 * (NCH * sub + c);
+                    stc_n[c] = loc < cn ? status[c0 + loc] : 0;
+                }
+                st_n = (owner && cb + tid < cn) ? status[c0 + cb + tid] : 0;
+                fetched = true;
+            }
+            bool walk[NCH];
+            bool any_walk = false;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                walk[c] = act[c] &&
+                          (!PRUNE || *LDS_AT(lds_i32, dec_off + 4 * (lane + 64 * (NCH * sub + c))) == 0);
+                any_walk = any_walk || walk[c];
+            }
+            if (slot < gt && !(dbg & 2) && __any(any_walk)) {
+                double v[NCH];
+                const unsigned tbase = (unsigned)(img_off + tt.x);
+                const unsigned root = (unsigned)tt.z;
+                if (dbg & 256) {  // the loads in FRONT of the walk (same binary: what the placement is worth)
+                    issue();
+                    ld_mask = 0;
+                }
+#define QR_WALK_POS(X0_, NAN_, POS_) qr_walk<X0_, HALF1, NAN_, POS_>(root, tt.y, tbase, lk0, lk1, v, issue)
+#define QR_WALK(X0_, NAN_)                              \
+    do {                                                \
+        if ((wave >> 2) == 0) QR_WALK_POS(X0_, NAN_, 0); \
+        else if ((wave >> 2) == 1) QR_WALK_POS(X0_, NAN_, 1); \
+        else if ((wave >> 2) == 2) QR_WALK_POS(X0_, NAN_, 2); \
+        else QR_WALK_POS(X0_, NAN_, 3);                 \
+    } while (0)
+                if (sub) {  // the second rank tile (the tile index is an immediate offset)
+                    if (wave_nan) QR_WALK(HALF1, true);
+                    else QR_WALK(HALF1, false);
+                } else {
+                    if (wave_nan) QR_WALK(0, true);
+                    else QR_WALK(0, false);
+                }
+#undef QR_WALK
+#undef QR_WALK_POS
+#pragma unroll
+                for (int c = 0; c < NCH; c++)
+                    if (walk[c])
+                        *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * (NCH * sub + c)) * 8) = v[c];
+            } else {
+                issue();  // a wave without a walk still moves its share of the next group
+            }
+            QR_STAMP(1);
+            __syncthreads();  // every walk of the group is done
+            QR_STAMP(2);
+            // everything this wave asked for has had the whole walk to arrive
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (g + 1 < n_grp && !(dbg & 4)) {  // (dbg 4: timing ablation, wrong results)
+                st_nu = g_nxt.w;
+                QR_REGS(QR_ST_GROUP)
+            }
+            const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
+            if (owner && active && undecided) {
+                for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
+                if (PRUNE) {
+                    const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < prune_sum;
+                    if (out) {
+                        *LDS_AT(lds_i32, dec_off + 4 * tid) = 1;
+                        acc = 0.0;  // reported probability of a pruned candidate: 0
+                    } else {
+                        *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) = 1;  // still an open candidate
+                    }
+                }
+            }
+            QR_STAMP(3);
+            __syncthreads();  // next group staged; values consumed; votes cast
+            bool all_done = false;
+            if (PRUNE) {
+                all_done = *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) == 0;
+                if (tid == 0) *LDS_AT(lds_i32, dec_off + 4 * (C + ((g + 2) % 3))) = 0;
+            }
+            QR_STAMP(4);
+            g_cur = g_nxt;
+            tt = tt_nxt;
+            if (all_done) break;
+        }
+        if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
+        tile_ready = fetched;
+        if (fetched) {  // every walk of this tile is behind the last barrier: its rank tiles can go
+            // (PRUNE: a trip that ended early may not have asked for the tile at all -- fetched is
+            // only set in the last group -- or its loads are still in flight)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int64_t cb = wg_next * C;
+            const bool two = cb + 128 < cn;
+            const unsigned tl_a0 = voff, tl_a1 = voff + (unsigned)HALF1;
+            QR_REGS(QR_ST_TILE)
+        }
+    }
+#undef QR_STAMP
+}
+
+// ------------------------------------------------------------------------
 // The 64-candidate shape (more than 255 features: the wide node word), TWO rank tiles per
 // workgroup trip (round 3).
 //
@@ -921,6 +1249,8 @@ static int q_plan_build(pk_forest *f)
     f->q_n_grp = best.n_grp;
     f->q_max_group_bytes = 0;
     for (int g = 0; g < best.n_grp; g++) f->q_max_group_bytes = std::max(f->q_max_group_bytes, best.gtab[4 * g + 3] * 16);
+    // (+ pad: forest_qr_kernel's staging loads are whole 16-KiB rows, unclamped)
+    best.pairs.resize(best.pairs.size() + PK_Q_PAD_BYTES / sizeof(best.pairs[0]), make_uint2(0, 0));
     int rc = q_upload((void **)&f->q_img, best.pairs);
     if (!rc) rc = q_upload((void **)&f->q_gtab, best.gtab);
     if (!rc) rc = q_upload((void **)&f->q_ttab, best.ttab);
@@ -996,7 +1326,8 @@ int pk_forest_q_reserve(pk_device_ctx *ctx, pk_forest *f, int64_t cn)
         return PK_E_INVALID;
     }
     const int64_t n_tiles = (cn + 127) / 128;
-    const size_t qbytes = (size_t)n_tiles * f->F * 128 * sizeof(unsigned short);
+    // (+ pad: forest_qr_kernel's unclamped 16-KiB register rows read past the last tile)
+    const size_t qbytes = (size_t)n_tiles * f->F * 128 * sizeof(unsigned short) + PK_Q_PAD_BYTES;
     if (qbytes > ctx->q_tiles_bytes) {
         if (ctx->q_tiles) {
             PK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1067,7 +1398,29 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     const bool early = wpt2 && f->q_slot_bytes > 0;
     q_slot_table slots_at;
     for (int i = 0; i < 16; i++) slots_at.off[i] = L.slot_off[i];
-    if (L.ch == 4 && L.half1 == 32768) {
+    if (L.ch == 4 && wpt2 && !early && g_opt.forest_q_rsv && !(g_opt.forest_dbg & (8 | 32)) &&
+        (L.half1 == 32768 || L.half1 == 49152)) {
+        // the default shape: staging registers outside the compiler's reach, loads from inside the walk
+#define QR_LAUNCH(HALF1, PRUNE)                                                                            \
+    do {                                                                                                   \
+        int rc__ = q_set_max_lds(forest_qr_kernel<HALF1, PRUNE>, 163840);                                  \
+        if (rc__) return rc__;                                                                             \
+        hipLaunchKernelGGL((forest_qr_kernel<HALF1, PRUNE>), dim3(grid), dim3(Q_THREADS), 163840, ctx->stream, \
+                           reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab), \
+                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
+                           L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob, prune_sum,        \
+                           (int)g_opt.forest_dbg, ctx->dbg_buf);                                           \
+    } while (0)
+        const bool prune = prune_sum > -1e300;
+        if (L.half1 == 32768) {
+            if (prune) QR_LAUNCH(32768, true);
+            else QR_LAUNCH(32768, false);
+        } else {
+            if (prune) QR_LAUNCH(49152, true);
+            else QR_LAUNCH(49152, false);
+        }
+#undef QR_LAUNCH
+    } else if (L.ch == 4 && L.half1 == 32768) {
         if (early) Q_LAUNCH(4, 2, 32768, true);
         else if (wpt2) Q_LAUNCH(4, 2, 32768, false);
         else Q_LAUNCH(4, 1, 32768, false);
