@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpeakachu_hip.so")
+# PEAKACHU_HIP_LIB: another build of the same library (tools/ab.sh compares builds on one box
+# without copying anything over the product's file)
+LIB_PATH = os.environ.get("PEAKACHU_HIP_LIB") or os.path.join(_HERE, "libpeakachu_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

@@ -273,7 +273,7 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     } else if (!strcmp(name, "forest_q_help")) {
         g_opt.forest_q_help = value != 0;
     } else if (!strcmp(name, "forest_q_rsv")) {
-        g_opt.forest_q_rsv = value != 0;
+        g_opt.forest_q_rsv = value;
     } else if (!strcmp(name, "forest_dbg")) {
         g_opt.forest_dbg = value;
     } else if (!strcmp(name, "forest_q")) {

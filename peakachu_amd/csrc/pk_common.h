@@ -99,8 +99,10 @@ struct pk_options {
     int64_t forest_q_persist = 1; // rank kernel: persistent launch, this many workgroups per CU, each looping over
                                   // tiles with the next tile prefetched (3.97 -> 3.81 ms); 0 = one workgroup per tile
     int64_t forest_q_prio = 1;  // rank kernel: rotate the waves' issue priorities during the walk (4.05 -> 3.89 ms)
-    int64_t forest_q_rsv = 1;   // default shape (256 candidates x 8 trees): forest_qr_kernel -- staging registers
-                                // reserved from the compiler, staging loads issued from inside the walk
+    int64_t forest_q_rsv = 3;   // default shape (256 candidates x 8 trees): forest_qr_kernel -- staging registers
+                                // reserved from the compiler, staging loads issued from inside the walk, no
+                                // scalar tests on the walk path.  bits: 1 on (0 = forest_q_kernel); 2 the last
+                                // group of a tile also fetches the next tile's first group
     int64_t forest_q_early = 0; // two waves per tree: stage the slot's next tree as soon as both are done with it
                                 // (measured SLOWER, 4.51 vs 4.09 ms: two waves storing alone get half the LDS
                                 // store rate and hold up the walkers' reads; kept as an experiment)
@@ -271,7 +273,7 @@ __host__ __device__ inline int pk_q_cell(float x, float lo, float inv)
 }
 // rebuilds qlut from the cell of every threshold (qcell, parallel to qthr)
 void pk_q_fill_lut(pk_q_out *out, int F, const std::vector<int32_t> &qcell);
-#define PK_Q_PAD_BYTES 32768  // readable bytes behind the rank image and behind the rank tiles (forest_qr_kernel)
+#define PK_Q_PAD_BYTES 131072  // readable bytes behind the rank image and behind the rank tiles (forest_qr_kernel)
 inline int pk_q_stage_regs() { return 8; }  // uint4 staging registers per thread (1024) of forest_q_kernel
 bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L);
 int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,

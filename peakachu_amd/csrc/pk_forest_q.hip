@@ -22,6 +22,8 @@
 // (pair address), v_cmp_le_u32_sdwa (code against the word's upper half),
 // v_cndmask_b32; ds_read_u16 + ds_read_b64.  Leaf values are added in tree order
 // in float64, the sequential sum sklearn computes.
+#include <type_traits>
+
 #include "pk_common.h"
 
 namespace {
@@ -591,7 +593,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 
 // ------------------------------------------------------------------------
 // forest_qr_kernel (round 4) = forest_q_kernel<4, 2, HALF1, PRUNE, false> -- 256 candidates, eight
-// trees, two waves per tree -- with the STAGING REGISTERS TAKEN AWAY FROM THE COMPILER.
+// trees, two waves per tree -- with the STAGING REGISTERS TAKEN AWAY FROM THE COMPILER and a
+// walk path without scalar tests.
 //
 // Round 3 measured (DESIGN.md 4.2 iii): the 67 wave-loads of the next tree group, issued by all
 // sixteen waves at once in front of the walk, queue up in the CU's memory pipeline and every wave
@@ -599,75 +602,134 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 // SIMD position at a time, the stage is 7 % faster -- but every C++ form of that either moved the
 // eight 16-byte staging registers to scratch, doubled the register demand or slowed the walk,
 // because the compiler has to keep registers with loads in flight alive across the unrolled walk.
-// Here the kernel is compiled for 96 VGPRs (amdgpu_num_vgpr) and v96..v127 -- which a
-// 1024-thread workgroup owns anyway -- are used by inline assembly only: eight global_load_dwordx4
+// Here the kernel is compiled for PK_QR_VGPRS (72) VGPRs (amdgpu_num_vgpr) and v72..v127 -- which a
+// 1024-thread workgroup owns anyway -- are used by inline assembly only: global_load_dwordx4
 // into fixed registers wherever the walk wants them, one explicit s_waitcnt vmcnt(0) behind the
-// barrier, eight ds_write_b128 from the same registers.  The compiler never sees a value in
-// them, so it neither waits for them nor moves them, and its own s_waitcnt arithmetic stays safe
-// (extra loads in flight only make its vmcnt waits conservative: loads return in order).
-// The loads carry no per-thread clamp: the image and the rank-tile buffer are padded by what a
-// register row can read past their ends (pk_q_pad_bytes).
+// barrier, ds_write_b128 from the same registers.  The compiler never sees a value in them, so
+// it neither waits for them nor moves them, and its own s_waitcnt arithmetic stays safe (extra
+// loads in flight only make its vmcnt waits conservative: loads return in order).
+// v96..v127 = G0..G7, 16-KiB rows of the next tree group; v72..v95 = T0..T5, the next tile's two
+// rank tiles (three rows each).
+//
+// What the walk phase is bound by (round 4, same-box A/Bs, profiles/r04_ab_*.log): each wave's own
+// instruction stream -- four waves per SIMD, two dependent chains each, an instruction of a wave
+// issues every ~5 cycles at best.  Every scalar instruction in that stream costs like a vector one:
+// three bit tests with (taken) branches for rows a group does not have cost 1.8 %, the five tests
+// of the rows it has another 1.2 %, six more for the tile's rows 5 %.  Hence
+//   * NR rows are loaded WITHOUT tests (NR = rows of the forest's largest group, 4 or 5; a shorter
+//     group's surplus rows read what lies behind it -- the image and the rank-tile buffer are padded,
+//     PK_Q_PAD_BYTES -- and are not stored);
+//   * a wave's role (rank tile, position in its SIMD) is dispatched ONCE per kernel, not per walk:
+//     the whole persistent loop exists eight times (qr_body);
+//   * a tree of >= 16 levels is walked 16 + 4k levels (a walk that has reached its leaf stays there:
+//     up to three idle levels instead of three more loop tests).
 // ------------------------------------------------------------------------
-#define QR_REGS(X)                                                                          \
+#ifndef PK_QR_AT
+#define PK_QR_AT(pos) ((pos) + 1)  // the staging loads start behind this many PAIRS of levels
+#endif
+#ifndef PK_QR_VGPRS
+#define PK_QR_VGPRS 72
+#endif
+#ifndef PK_QR_SPREAD
+#define PK_QR_SPREAD 1             // issue slots per pair of levels from there on (0: all at once)
+#endif
+
+#define QR_LD_U(R, ptr) asm volatile("global_load_dwordx4 " R ", %0, %1" ::"v"(voff), "s"(ptr))
+// a row behind a test of its bit (the tile's rows, once per tile): the test is inside the assembly --
+// as a C++ `if` the compiler lays every conditional load out of line (two taken branches per load)
+#define QR_LD_ASM(bit, R, ptr)                                                              \
+    asm volatile("s_bitcmp1_b32 %0, " #bit "\n\t"                                           \
+                 "s_cbranch_scc0 .Lqr" #bit "_%=\n\t"                                       \
+                 "global_load_dwordx4 " R ", %1, %2\n"                                      \
+                 ".Lqr" #bit "_%=:" ::"s"(mask),                                            \
+                 "v"(voff), "s"(ptr)                                                        \
+                 : "scc")
+// issue slot S = row S of the group (rows >= NR do not exist)
+template <int S, int NR>
+__device__ __forceinline__ void qr_issue_slot(const char *gb, unsigned voff)
+{
+    if constexpr (S < NR) {
+        if constexpr (S == 0) QR_LD_U("v[96:99]", gb);
+        if constexpr (S == 1) QR_LD_U("v[100:103]", gb + 16384);
+        if constexpr (S == 2) QR_LD_U("v[104:107]", gb + 2 * 16384);
+        if constexpr (S == 3) QR_LD_U("v[108:111]", gb + 3 * 16384);
+        if constexpr (S == 4) QR_LD_U("v[112:115]", gb + 4 * 16384);
+        if constexpr (S == 5) QR_LD_U("v[116:119]", gb + 5 * 16384);
+        if constexpr (S == 6) QR_LD_U("v[120:123]", gb + 6 * 16384);
+        if constexpr (S == 7) QR_LD_U("v[124:127]", gb + 7 * 16384);
+    }
+}
+template <int LO, int HI, int NR>
+__device__ __forceinline__ void qr_issue(const char *gb, unsigned voff)
+{
+    if constexpr (LO < HI) {
+        qr_issue_slot<LO, NR>(gb, voff);
+        qr_issue<LO + 1, HI, NR>(gb, voff);
+    }
+}
+// the next tile's rows (once per tile, in front of the last group's walk); mask bits 8..13
+__device__ __forceinline__ void qr_issue_tile(unsigned tmask, const char *tb0, const char *tb1, unsigned voff)
+{
+    const unsigned mask = __builtin_amdgcn_readfirstlane(tmask);
+    QR_LD_ASM(8, "v[72:75]", tb0);
+    QR_LD_ASM(9, "v[76:79]", tb0 + 16384);
+    QR_LD_ASM(10, "v[80:83]", tb0 + 2 * 16384);
+    QR_LD_ASM(11, "v[84:87]", tb1);
+    QR_LD_ASM(12, "v[88:91]", tb1 + 16384);
+    QR_LD_ASM(13, "v[92:95]", tb1 + 2 * 16384);
+}
+#define QR_GREGS(X)                                                                         \
     X(0, "v[96:99]") X(1, "v[100:103]") X(2, "v[104:107]") X(3, "v[108:111]")               \
     X(4, "v[112:115]") X(5, "v[116:119]") X(6, "v[120:123]") X(7, "v[124:127]")
-// register q < 3 reads 16 KiB row q behind ld_b0, q >= 3 row q - 3 behind ld_b1 (a tree group: one
-// piece, ld_b1 = ld_b0 + 48 KiB; the next tile: its two rank tiles).  ONE block of assembly: as
-// separate C++ statements the compiler lays every conditional load out of line (two taken
-// branches per load); here a row that is asked for falls through.
-#define QR_LD_ROW(q, R)                                              \
-    "s_bitcmp1_b32 %[m], " #q "\n\t"                                  \
-    "s_cbranch_scc0 .Lqr" #q "_%=\n\t"                                \
-    "global_load_dwordx4 " R ", %[vo], %[p" #q "]\n"                  \
-    ".Lqr" #q "_%=:\n\t"
-#define QR_ISSUE()                                                                                         \
-    asm volatile(QR_LD_ROW(0, "v[96:99]") QR_LD_ROW(1, "v[100:103]") QR_LD_ROW(2, "v[104:107]")            \
-                 QR_LD_ROW(3, "v[108:111]") QR_LD_ROW(4, "v[112:115]") QR_LD_ROW(5, "v[116:119]")          \
-                 QR_LD_ROW(6, "v[120:123]") QR_LD_ROW(7, "v[124:127]")                                     \
-                 ::[m] "s"(__builtin_amdgcn_readfirstlane(ld_mask)), [vo] "v"(voff), [p0] "s"(ld_b0), [p1] "s"(ld_b0 + 16384),             \
-                 [p2] "s"(ld_b0 + 32768), [p3] "s"(ld_b1), [p4] "s"(ld_b1 + 16384), [p5] "s"(ld_b1 + 32768), \
-                 [p6] "s"(ld_b1 + 49152), [p7] "s"(ld_b1 + 65536)                                          \
-                 : "scc")
+#define QR_TREGS(X)                                                                         \
+    X(0, "v[72:75]") X(1, "v[76:79]") X(2, "v[80:83]") X(3, "v[84:87]") X(4, "v[88:91]") X(5, "v[92:95]")
 #define QR_ST_GROUP(q, R)                                                                   \
-    if ((q) * 1024 < st_nu) {                                                               \
+    if ((q) < NR && (q) * 1024 < st_nu) {                                                   \
         if (tid + (q) * 1024 < st_nu)                                                       \
             asm volatile("ds_write_b128 %0, " R " offset:%1" ::"v"((q) < 4 ? st_a0 : st_a1), \
                          "n"(((q) & 3) * 16384)                                             \
                          : "memory");                                                       \
     }
 #define QR_ST_TILE(q, R)                                                                    \
-    if ((q) < 6 && ((q) % 3) * 1024 < upt && ((q) < 3 || two)) {                            \
+    if (((q) % 3) * 1024 < upt && ((q) < 3 || two)) {                                       \
         if (tid + ((q) % 3) * 1024 < upt)                                                   \
             asm volatile("ds_write_b128 %0, " R " offset:%1" ::"v"((q) < 3 ? tl_a0 : tl_a1), \
                          "n"(((q) % 3) * 16384)                                             \
                          : "memory");                                                       \
     }
-#ifndef PK_QR_AT
-#define PK_QR_AT(pos) ((pos) + 1)  // the staging loads go out behind this many PAIRS of levels
-#endif
-#ifndef PK_QR_VGPRS
-#define PK_QR_VGPRS 96
-#endif
 
-// the walk of q_walk<2, X0, HALF1, WITH_NAN, false, POS> (same levels, same priority schedule)
-// with `issue()` called once, PK_QR_AT(POS) pairs of levels in (trees of fewer than 16 levels: in
-// front of the walk)
-template <int X0, int HALF1, bool WITH_NAN, int POS, typename ISSUE>
+// The walk of q_walk<2, X0, HALF1, WITH_NAN, false, POS> (same levels, same priorities) with the
+// staging loads issued from inside: issue slot s goes out in front of pair PK_QR_AT(POS) +
+// s / PK_QR_SPREAD of the first sixteen levels (what they do not reach: behind them;
+// PK_QR_SPREAD = 0: all slots in front of pair PK_QR_AT(POS)).  Trees of fewer than 16 levels:
+// everything in front of the walk.  Behind the first sixteen levels a tree is walked in blocks of
+// four (fewer than 16: in pairs): a walk that has reached its leaf stays there (pk_qimage.hip), so
+// the up to three surplus levels change nothing.
+template <int X0, int HALF1, bool WITH_NAN, int POS, int NR>
 __device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase, unsigned lk0, unsigned lk1,
-                                        double (&v)[2], ISSUE issue)
+                                        double (&v)[2], const char *gb, unsigned voff)
 {
     unsigned w[2] = {root, root};
-    int d = depth;
     constexpr int PT[4][6] = {PK_Q_PRIO_TAB};
     constexpr int PP = POS & 3;
     constexpr int AT = PK_QR_AT(PP);
+    constexpr int SP = PK_QR_SPREAD;
+    // slots [lo, hi) in front of pair k
+#define QR_SLOTS_AT(k_)                                                                          \
+    do {                                                                                         \
+        if constexpr (SP == 0) {                                                                 \
+            if constexpr (AT == (k_)) qr_issue<0, 8, NR>(gb, voff);                              \
+        } else if constexpr ((k_) >= AT && ((k_) - AT) * SP < 8) {                               \
+            qr_issue<((k_) - AT) * SP, (((k_) - AT + 1) * SP < 8 ? ((k_) - AT + 1) * SP : 8), NR>(gb, voff); \
+        }                                                                                        \
+    } while (0)
 #define QR_TWO(k_)                                                     \
     do {                                                               \
-        if (AT == (k_)) issue();                                       \
+        QR_SLOTS_AT(k_);                                               \
         q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);    \
         q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);    \
     } while (0)
-    if (d >= 16) {
+    if (__builtin_expect(depth >= 16, 1)) {
         __builtin_amdgcn_s_setprio(PT[PP][0]);
         QR_TWO(0);
         QR_TWO(1);
@@ -680,83 +742,93 @@ __device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase
         __builtin_amdgcn_s_setprio(PT[PP][3]);
         QR_TWO(6);
         QR_TWO(7);
-        if (AT >= 8) issue();
-        d -= 16;
+        // what the sixteen levels did not reach
+        constexpr int done = SP == 0 ? (AT < 8 ? 8 : 0) : (AT >= 8 ? 0 : ((8 - AT) * SP < 8 ? (8 - AT) * SP : 8));
+        qr_issue<done, 8, NR>(gb, voff);
+#undef QR_SLOTS_AT
+#define QR_SLOTS_AT(k_) do {} while (0)
+        for (int n4 = (depth - 16 + 3) >> 2; n4 > 0; n4--) {
+            __builtin_amdgcn_s_setprio(PT[PP][4]);
+            QR_TWO(-1);
+            __builtin_amdgcn_s_setprio(PT[PP][5]);
+            QR_TWO(-1);
+        }
     } else {
-        issue();
-    }
-    for (; d >= 16; d -= 16) {
+        qr_issue<0, 8, NR>(gb, voff);  // (short trees)
         __builtin_amdgcn_s_setprio(PT[PP][0]);
-        QR_TWO(-1);
-        QR_TWO(-1);
-        __builtin_amdgcn_s_setprio(PT[PP][1]);
-        QR_TWO(-1);
-        QR_TWO(-1);
-        __builtin_amdgcn_s_setprio(PT[PP][2]);
-        QR_TWO(-1);
-        QR_TWO(-1);
-        __builtin_amdgcn_s_setprio(PT[PP][3]);
-        QR_TWO(-1);
-        QR_TWO(-1);
+        for (int n2 = (depth + 1) >> 1; n2 > 0; n2--) QR_TWO(-1);
     }
-    for (; d >= 4; d -= 4) {
-        __builtin_amdgcn_s_setprio(PT[PP][4]);
-        QR_TWO(-1);
-        __builtin_amdgcn_s_setprio(PT[PP][5]);
-        QR_TWO(-1);
-    }
-    for (; d >= 2; d -= 2) QR_TWO(-1);
 #undef QR_TWO
-    if (d) q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);
+#undef QR_SLOTS_AT
     __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int c = 0; c < 2; c++) v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index<false>(w[c]) + 1) << 3));
 }
 
-template <int HALF1, bool PRUNE>
-__global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGPRS))) void forest_qr_kernel(
-    const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
-    int F, int dec_off, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
-    const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob, double prune_sum,
-    int dbg, long long *__restrict__ stamps)
+struct qr_args {
+    const char *img_b;
+    const int4 *gtab, *ttab;
+    int n_grp, T, F, dec_off, val_off, img_off;
+    const unsigned short *qtiles;
+    const uint8_t *status;
+    int64_t c0, cn;
+    double *prob;
+    double prune_sum;
+    int opt, dbg;
+    long long *stamps;
+};
+
+// the persistent loop of one wave role: X0 = LDS offset of its rank tile, POS = its position among
+// the four waves of its SIMD.  opt bits: 1 PREF0 (the last group of a tile also fetches the next
+// tile's first group: a tile change then has no exposed load)
+template <int HALF1, bool PRUNE, int NR, int X0, int POS>
+__device__ __forceinline__ void qr_body(const qr_args &A)
 {
     constexpr int THREADS = Q_THREADS;
     constexpr int C = 256;
     constexpr int NCH = 2;  // walks per lane of one wave
-    // v96..v127 belong to the inline assembly below (the register count of the kernel covers them)
-    asm volatile("" ::: "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106",
-                 "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117",
-                 "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
-    extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
+    constexpr int sub = X0 != 0;
+    const int n_grp = A.n_grp, T = A.T, F = A.F, dec_off = A.dec_off, val_off = A.val_off, img_off = A.img_off;
+    const int dbg = A.dbg;
+    long long *const stamps = A.stamps;
+    const int64_t c0 = A.c0, cn = A.cn;
+    const uint8_t *const status = A.status;
     const int HB = F * 256;  // bytes of a rank tile [F][64][2] u16
     const int upt = HB >> 4;
-    const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
-    if (!lds_at_zero && threadIdx.x == 0 && stamps) stamps[65535] = 2;
-    const char *const img_b = reinterpret_cast<const char *>(img);
+    const bool lds_ok = A.opt >= 0;  // (cleared when the dynamic LDS does not start at address 0)
+    const bool pref0 = (A.opt & 1) != 0;
 
     const int64_t n_wg = (cn + C - 1) / C;
     unsigned stc_n[NCH] = {}, st_n = 0;
-    bool tile_ready = false;  // (uniform) the tile of this trip is in LDS already
+    bool tile_ready = false;  // (uniform) the tile of this trip and its first tree group are in LDS already
     for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (see forest_q_kernel: keeps per-trip addresses inside the trip)
         const int lane = tid & 63;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int slot = wave >> 1, sub = wave & 1;  // tree slot; which rank tile
+        const int slot = wave >> 1;  // tree slot
         const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
         const unsigned voff = (unsigned)tid << 4;    // this thread's 16 bytes of a 16-KiB row
-        if (wg != (int64_t)blockIdx.x) __syncthreads();  // nobody reads the previous trip's flags any more
+        if (wg != (int64_t)blockIdx.x && !tile_ready) __syncthreads();  // nobody reads the previous trip's tile any more
         if (PRUNE)
             for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
         const int64_t cbase = wg * C;
+        int4 g_cur = A.gtab[0];
+        int4 tt = A.ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree: offset, depth, root word, units
+        int st_nu = g_cur.w;                            // units of 16 B of the group in the G registers
+        const unsigned st_a0 = (unsigned)img_off + voff, st_a1 = st_a0 + 65536u;
         if (!tile_ready) {
-            const v4u *src = reinterpret_cast<const v4u *>(qtiles + (size_t)cbase * F);
+            const v4u *src = reinterpret_cast<const v4u *>(A.qtiles + (size_t)cbase * F);
             const int halves = cbase + 128 < cn ? 2 : 1;
             const int nu = halves * upt;
             for (int i = tid; i < nu; i += THREADS) {
                 const int o = i << 4;
                 *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = src[i];
             }
+            // first group: global -> registers -> LDS
+            qr_issue<0, 8, NR>(A.img_b + (size_t)g_cur.z * 16, voff);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            QR_GREGS(QR_ST_GROUP)
         }
         unsigned stc[NCH];
         bool act[NCH];
@@ -765,7 +837,7 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
         for (int c = 0; c < NCH; c++) {
             const int64_t loc = cbase + lane + 64 * (NCH * sub + c);
             stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[c0 + loc] : 0);
-            act[c] = stc[c] != 0 && lds_at_zero;
+            act[c] = stc[c] != 0 && lds_ok;
             any_nan = any_nan || stc[c] == 2;
         }
         const bool wave_nan = __any(any_nan);
@@ -773,53 +845,39 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
         const int64_t local = cbase + tid;
         const bool valid = owner && local < cn;
         const unsigned st = tile_ready ? st_n : (valid ? status[c0 + local] : 0);
-        const bool active = st != 0 && lds_at_zero;
+        const bool active = st != 0 && lds_ok;
         const int64_t wg_next = wg + gridDim.x;
         bool fetched = false;
-
-        // what the staging registers are asked to fetch next (uniform)
-        unsigned ld_mask;
-        const char *ld_b0, *ld_b1;
-        auto issue = [&]() __attribute__((always_inline)) { QR_ISSUE(); };
-        int4 g_cur = gtab[0];
-        int4 tt = ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree: offset, depth, root word, units
-        int st_nu = g_cur.w;                          // units of 16 B of the group in the registers
-        const unsigned st_a0 = (unsigned)img_off + voff, st_a1 = st_a0 + 65536u;
-        {   // first group: global -> registers -> LDS
-            ld_b0 = img_b + (size_t)g_cur.z * 16;
-            ld_b1 = ld_b0 + 3 * 16384;
-            ld_mask = (1u << ((st_nu + 1023) >> 10)) - 1u;
-            issue();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            QR_REGS(QR_ST_GROUP)
-        }
         __syncthreads();  // rank tiles and first group are in LDS
-
+        // in-kernel stamps (tools/stamps.py) exist in builds with -DPK_QR_STAMPS only: every test of a
+        // debug flag is an instruction in the wave's stream, which is what bounds this kernel
+#ifdef PK_QR_STAMPS
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && wg != (int64_t)blockIdx.x)
+            stamps[((tid >> 6) * 32 + 31) * 5 + 4] = (long long)__builtin_amdgcn_s_memtime();
 #define QR_STAMP(slot_)                                                                  \
     do {                                                                                 \
-        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && g < 32)              \
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && g < 31)              \
             stamps[((tid >> 6) * 32 + g) * 5 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define QR_STAMP(slot_) do {} while (0)
+#endif
         double acc = 0.0;
         for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
             const int t0 = g_cur.x, gt = g_cur.y;
-            const int4 g_nxt = gtab[g + 1];
-            const int4 tt_nxt = ttab[min(g_nxt.x + slot, T - 1)];
+            const int4 g_nxt = A.gtab[g + 1];
+            const int4 tt_nxt = A.ttab[min(g_nxt.x + slot, T - 1)];
             QR_STAMP(0);
-            ld_mask = 0;
-            ld_b0 = ld_b1 = img_b;
-            if (g + 1 < n_grp) {  // the next group flies while this one is walked
-                ld_b0 = img_b + (size_t)g_nxt.z * 16;
-                ld_b1 = ld_b0 + 3 * 16384;
-                ld_mask = (dbg & 64) ? 0u : (1u << ((g_nxt.w + 1023) >> 10)) - 1u;  // (64: timing ablation, wrong results)
-            } else if (wg_next < n_wg && upt <= 3 * THREADS) {
+            // what the G registers fetch during this walk: the next group -- or, in a tile's last group,
+            // (PREF0) the first group again, for the next tile.  (Without PREF0, or without a next tile,
+            // the rows loaded then are not used: the walk's loads carry no test.)
+            const char *gb = A.img_b + (size_t)(g + 1 < n_grp ? g_nxt.z : A.gtab[0].z) * 16;
+            if (g + 1 >= n_grp && wg_next < n_wg && upt <= 3 * THREADS) {
                 // last group of this tile: the next tile travels global -> registers during the walk
-                // (registers 0-2 its first rank tile, 3-5 the second) with its status bytes
+                // (T0-2 its first rank tile, T3-5 the second) with its status bytes
                 const int64_t cb = wg_next * C;
-                ld_b0 = reinterpret_cast<const char *>(qtiles + (size_t)cb * F);
-                ld_b1 = ld_b0 + HB;
+                const char *tb0 = reinterpret_cast<const char *>(A.qtiles + (size_t)cb * F);
                 const unsigned rows = (1u << ((upt + 1023) >> 10)) - 1u;
-                ld_mask = rows | (cb + 128 < cn ? rows << 3 : 0u);
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     const int64_t loc = cb + lane + 64 * (NCH * sub + c);
@@ -827,6 +885,7 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
                 }
                 st_n = (owner && cb + tid < cn) ? status[c0 + cb + tid] : 0;
                 fetched = true;
+                qr_issue_tile((rows | (cb + 128 < cn ? rows << 3 : 0u)) << 8, tb0, tb0 + HB, voff);
             }
             bool walk[NCH];
             bool any_walk = false;
@@ -836,37 +895,18 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
                           (!PRUNE || *LDS_AT(lds_i32, dec_off + 4 * (lane + 64 * (NCH * sub + c))) == 0);
                 any_walk = any_walk || walk[c];
             }
-            if (slot < gt && !(dbg & 2) && __any(any_walk)) {
+            if (__builtin_expect(slot < gt && !(dbg & 2) && __any(any_walk), 1)) {
                 double v[NCH];
                 const unsigned tbase = (unsigned)(img_off + tt.x);
                 const unsigned root = (unsigned)tt.z;
-                if (dbg & 256) {  // the loads in FRONT of the walk (same binary: what the placement is worth)
-                    issue();
-                    ld_mask = 0;
-                }
-#define QR_WALK_POS(X0_, NAN_, POS_) qr_walk<X0_, HALF1, NAN_, POS_>(root, tt.y, tbase, lk0, lk1, v, issue)
-#define QR_WALK(X0_, NAN_)                              \
-    do {                                                \
-        if ((wave >> 2) == 0) QR_WALK_POS(X0_, NAN_, 0); \
-        else if ((wave >> 2) == 1) QR_WALK_POS(X0_, NAN_, 1); \
-        else if ((wave >> 2) == 2) QR_WALK_POS(X0_, NAN_, 2); \
-        else QR_WALK_POS(X0_, NAN_, 3);                 \
-    } while (0)
-                if (sub) {  // the second rank tile (the tile index is an immediate offset)
-                    if (wave_nan) QR_WALK(HALF1, true);
-                    else QR_WALK(HALF1, false);
-                } else {
-                    if (wave_nan) QR_WALK(0, true);
-                    else QR_WALK(0, false);
-                }
-#undef QR_WALK
-#undef QR_WALK_POS
+                if (__builtin_expect(wave_nan, 0)) qr_walk<X0, HALF1, true, POS, NR>(root, tt.y, tbase, lk0, lk1, v, gb, voff);
+                else qr_walk<X0, HALF1, false, POS, NR>(root, tt.y, tbase, lk0, lk1, v, gb, voff);
 #pragma unroll
                 for (int c = 0; c < NCH; c++)
                     if (walk[c])
                         *LDS_AT(lds_f64, val_off + (slot * C + lane + 64 * (NCH * sub + c)) * 8) = v[c];
             } else {
-                issue();  // a wave without a walk still moves its share of the next group
+                qr_issue<0, 8, NR>(gb, voff);  // a wave without a walk still moves its share
             }
             QR_STAMP(1);
             __syncthreads();  // every walk of the group is done
@@ -875,13 +915,15 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (g + 1 < n_grp && !(dbg & 4)) {  // (dbg 4: timing ablation, wrong results)
                 st_nu = g_nxt.w;
-                QR_REGS(QR_ST_GROUP)
+                QR_GREGS(QR_ST_GROUP)
             }
             const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
             if (owner && active && undecided) {
                 for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
                 if (PRUNE) {
-                    const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < prune_sum;
+                    // every remaining tree adds at most 1.0: if even that cannot lift the sum to thre*T
+                    // (1e-12 covers the rounding of at most T additions) the pixel is not reported
+                    const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < A.prune_sum;
                     if (out) {
                         *LDS_AT(lds_i32, dec_off + 4 * tid) = 1;
                         acc = 0.0;  // reported probability of a pruned candidate: 0
@@ -891,7 +933,7 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
                 }
             }
             QR_STAMP(3);
-            __syncthreads();  // next group staged; values consumed; votes cast
+            if (g + 1 < n_grp || !fetched) __syncthreads();  // next group staged; values consumed; votes cast
             bool all_done = false;
             if (PRUNE) {
                 all_done = *LDS_AT(lds_i32, dec_off + 4 * (C + (g % 3))) == 0;
@@ -902,19 +944,91 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
             tt = tt_nxt;
             if (all_done) break;
         }
-        if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
+#ifdef PK_QR_STAMPS
+#define QR_TSTAMP(k_)                                                                    \
+    do {                                                                                 \
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && fetched)             \
+            stamps[((tid >> 6) * 32 + 31) * 5 + (k_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define QR_TSTAMP(k_) do {} while (0)
+#endif
+        QR_TSTAMP(0);
+        if (valid) A.prob[c0 + local] = active ? acc / (double)T : 0.0;
+        // the next tile and (PREF0) its first group: every walk of this tile is behind barrier 1 of
+        // the last group and the sums are done, so its rank tiles and trees can go
+        const bool grp0_here = fetched && pref0;
         tile_ready = fetched;
-        if (fetched) {  // every walk of this tile is behind the last barrier: its rank tiles can go
-            // (PRUNE: a trip that ended early may not have asked for the tile at all -- fetched is
-            // only set in the last group -- or its loads are still in flight)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (fetched) {
             const int64_t cb = wg_next * C;
             const bool two = cb + 128 < cn;
             const unsigned tl_a0 = voff, tl_a1 = voff + (unsigned)HALF1;
-            QR_REGS(QR_ST_TILE)
+            QR_TREGS(QR_ST_TILE)
+            QR_TSTAMP(1);
+            st_nu = A.gtab[0].w;
+            if (!grp0_here) {  // without PREF0 the tile's first group is fetched now
+                qr_issue<0, 8, NR>(A.img_b + (size_t)A.gtab[0].z * 16, voff);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            QR_TSTAMP(2);
+            QR_GREGS(QR_ST_GROUP)
+            // (the barrier at the top of the next trip publishes the stores; PRUNE: the flags of this
+            // trip were last read before the last group's first barrier... its second: see below)
+            if (PRUNE) __syncthreads();
         }
+        QR_TSTAMP(3);
     }
+#undef QR_TSTAMP
 #undef QR_STAMP
+}
+
+template <int HALF1, bool PRUNE, int NR>
+__global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGPRS))) void forest_qr_kernel(
+    const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
+    int F, int dec_off, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
+    const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob, double prune_sum,
+    int opt, int dbg, long long *__restrict__ stamps)
+{
+    // v72..v127 belong to the inline assembly (the register count of the kernel covers them)
+    asm volatile("" ::: "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83",
+                 "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96",
+                 "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108",
+                 "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119",
+                 "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // addressed absolutely from 0
+    const bool lds_at_zero = (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) char *)lds == 0u;
+    if (!lds_at_zero && threadIdx.x == 0 && stamps) stamps[65535] = 2;
+    qr_args A;
+    A.img_b = reinterpret_cast<const char *>(img);
+    A.gtab = gtab;
+    A.ttab = ttab;
+    A.n_grp = n_grp;
+    A.T = T;
+    A.F = F;
+    A.dec_off = dec_off;
+    A.val_off = val_off;
+    A.img_off = img_off;
+    A.qtiles = qtiles;
+    A.status = status;
+    A.c0 = c0;
+    A.cn = cn;
+    A.prob = prob;
+    A.prune_sum = prune_sum;
+    A.opt = lds_at_zero ? (opt & 0x7fffffff) : -1;
+    A.dbg = dbg;
+    A.stamps = stamps;
+    // the role of this wave, once: rank tile = wave & 1, position among the waves of its SIMD = wave >> 2
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (((wave >> 2) << 1) | (wave & 1)) {
+    case 0: qr_body<HALF1, PRUNE, NR, 0, 0>(A); break;
+    case 1: qr_body<HALF1, PRUNE, NR, HALF1, 0>(A); break;
+    case 2: qr_body<HALF1, PRUNE, NR, 0, 1>(A); break;
+    case 3: qr_body<HALF1, PRUNE, NR, HALF1, 1>(A); break;
+    case 4: qr_body<HALF1, PRUNE, NR, 0, 2>(A); break;
+    case 5: qr_body<HALF1, PRUNE, NR, HALF1, 2>(A); break;
+    case 6: qr_body<HALF1, PRUNE, NR, 0, 3>(A); break;
+    default: qr_body<HALF1, PRUNE, NR, HALF1, 3>(A); break;
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -1398,27 +1512,36 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     const bool early = wpt2 && f->q_slot_bytes > 0;
     q_slot_table slots_at;
     for (int i = 0; i < 16; i++) slots_at.off[i] = L.slot_off[i];
-    if (L.ch == 4 && wpt2 && !early && g_opt.forest_q_rsv && !(g_opt.forest_dbg & (8 | 32)) &&
-        (L.half1 == 32768 || L.half1 == 49152)) {
+    // rows of 16 KiB of the largest group: forest_qr_kernel loads that many without looking
+    const int rows = (f->q_max_group_bytes + 16383) / 16384;
+    if (L.ch == 4 && wpt2 && !early && (g_opt.forest_q_rsv & 1) && !(g_opt.forest_dbg & (8 | 32)) &&
+        (L.half1 == 32768 || L.half1 == 49152) && rows <= 5) {
         // the default shape: staging registers outside the compiler's reach, loads from inside the walk
-#define QR_LAUNCH(HALF1, PRUNE)                                                                            \
+#define QR_LAUNCH(HALF1, PRUNE, NR)                                                                        \
     do {                                                                                                   \
-        int rc__ = q_set_max_lds(forest_qr_kernel<HALF1, PRUNE>, 163840);                                  \
+        int rc__ = q_set_max_lds(forest_qr_kernel<HALF1, PRUNE, NR>, 163840);                              \
         if (rc__) return rc__;                                                                             \
-        hipLaunchKernelGGL((forest_qr_kernel<HALF1, PRUNE>), dim3(grid), dim3(Q_THREADS), 163840, ctx->stream, \
+        hipLaunchKernelGGL((forest_qr_kernel<HALF1, PRUNE, NR>), dim3(grid), dim3(Q_THREADS), 163840, ctx->stream, \
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab), \
                            f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
                            L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob, prune_sum,        \
-                           (int)g_opt.forest_dbg, ctx->dbg_buf);                                           \
+                           (int)(g_opt.forest_q_rsv >> 1), (int)g_opt.forest_dbg, ctx->dbg_buf);          \
     } while (0)
+#define QR_LAUNCH_NR(HALF1, PRUNE)                                  \
+    do {                                                            \
+        if (rows <= 4) QR_LAUNCH(HALF1, PRUNE, 4);                  \
+        else QR_LAUNCH(HALF1, PRUNE, 5);                            \
+    } while (0)
+        // forest_q_rsv bits: 1 on, 2 PREF0 (the next tile's first group prefetched with the tile)
         const bool prune = prune_sum > -1e300;
         if (L.half1 == 32768) {
-            if (prune) QR_LAUNCH(32768, true);
-            else QR_LAUNCH(32768, false);
+            if (prune) QR_LAUNCH_NR(32768, true);
+            else QR_LAUNCH_NR(32768, false);
         } else {
-            if (prune) QR_LAUNCH(49152, true);
-            else QR_LAUNCH(49152, false);
+            if (prune) QR_LAUNCH_NR(49152, true);
+            else QR_LAUNCH_NR(49152, false);
         }
+#undef QR_LAUNCH_NR
 #undef QR_LAUNCH
     } else if (L.ch == 4 && L.half1 == 32768) {
         if (early) Q_LAUNCH(4, 2, 32768, true);

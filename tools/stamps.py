@@ -53,6 +53,8 @@ if (2 * w + 1) ** 2 > 255 and not os.environ.get("PK_STAMP_Q1"):
 buf = np.zeros(16 * 32 * 5, np.int64)
 _lib.check(L.pk_debug_read(0, buf, buf.size), "dbg")
 st = buf.reshape(16, 32, 5)
+tile = st[:, 31, :].astype(np.float64)   # forest_qr_kernel: stamps of the tile change
+st = st[:, :31, :]
 ng = int((st[0, :, 0] != 0).sum())
 nw = int((st[:, 0, 0] != 0).sum())  # waves of the workgroup (2 per tree slot)
 st = st[:nw, :ng, :].astype(np.float64)
@@ -68,6 +70,13 @@ print("  commit+accumulate   %8.0f" % commit.mean())
 print("  wait at barrier 2   %8.0f" % bar2.mean())
 print("  total per group     %8.0f ; whole workgroup %.0f cycles" % ((st[:, :, 4] - st[:, :, 0]).mean(), tot.mean()))
 print("per-wave walk means:", np.round(walk.mean(1)).astype(int).tolist())
+if tile[:, 0].all() and tile[:, 3].all():
+    # (stamp 4 is taken at the START of a trip: the one stored last belongs to the trip whose end
+    # stamps 0-3 describe only when that trip was not the workgroup's last one)
+    print("tile change (forest_qr_kernel), cycles, mean over waves: tile/group stores + barrier %.0f, last sum + prob store %.0f, "
+          "cold first group %.0f | last group's end -> tile end %.0f"
+          % ((tile[:, 1] - tile[:, 0]).mean(), (tile[:, 2] - tile[:, 1]).mean(), (tile[:, 3] - tile[:, 2]).mean(),
+             (tile[:, 3] - st[:nw, ng - 1, 4]).mean() if ng else 0))
 if os.environ.get("PK_STAMP_MATRIX"):
     np.set_printoptions(linewidth=250)
     print("walk cycles / 10 per group (rows) and wave (columns); * = slowest")
