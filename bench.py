@@ -117,7 +117,19 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, gpu_pixels=None, target_s=15.0):
+def cpu_model():
+    """The host CPU as /proc/cpuinfo names it (BASELINE.md 4 wants the model next to the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, gpu_pixels=None, target_s=15.0, target_1t_s=5.0):
     """The CPU oracle (a port of the reference's algorithm, bit-exact against
     its golden vectors) timed on this box's host cores on a strided sample of
     the same candidate list.  When the sample is the whole list, its scored
@@ -138,10 +150,20 @@ def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, gpu_pixels=None, target_
         if dt >= 0.6 * target_s or xs.size >= N:
             break
         m = int(min(N, xs.size * min(10.0, 1.1 * target_s / max(dt, 1e-3))))
-    out = dict(value=xs.size / dt, unit="candidates/s", cores=cores, kind="port",
+    out = dict(value=xs.size / dt, unit="candidates/s", cores=cores, kind="port", cpu_model=cpu_model(),
                sample="every %d-th candidate of the workload (%d of %d), %.1f s wall, "
                       "oracle/pk_oracle.c pko_score_mt with OpenMP over candidates"
                       % (stride, xs.size, N, dt))
+    # BASELINE.md 4's `cpu-1t`: the same restatement on ONE thread (the reference is single-threaded:
+    # peakachu/score_genome.py:46), on a smaller strided sample sized from the rate just measured
+    m1 = int(max(2000, min(N, out["value"] / max(cores, 1) * target_1t_s)))
+    s1 = max(1, N // m1)
+    x1, y1 = x[::s1], y[::s1]
+    t0 = time.perf_counter()
+    onp.score(Mf, exp_arr, w, fod, thre, x1, y1, batch=batch, threads=1)
+    d1 = time.perf_counter() - t0
+    out["cpu_1t"] = dict(value=x1.size / d1, unit="candidates/s", cores=1,
+                         sample="every %d-th candidate (%d of %d), %.1f s wall, one thread" % (s1, x1.size, N, d1))
     if gpu_pixels is not None and xs.size == N:
         # rows / columns as integers, probability and signal bit for bit
         out["pixels_equal"] = bool(
@@ -168,12 +190,12 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_rooflines(dom, launches_per_step_live):
+def pmc_rooflines(dom, launches_per_step_live, pmc_file="pmc.json"):
     """HBM traffic and the two binding rooflines of the dominant kernel from the committed
     PMC passes (profiles/pmc.json, made by tools/pmc.sh + tools/make_traffic.py).  Every
     figure can be recomputed from that file; `stale` tells whether the kernel sources
     have changed since it was measured."""
-    path = os.path.join(ROOT, "profiles", "pmc.json")
+    path = os.path.join(ROOT, "profiles", pmc_file)
     if not os.path.exists(path):
         return None, None, None
     try:
@@ -184,7 +206,7 @@ def pmc_rooflines(dom, launches_per_step_live):
     except Exception:
         return None, None, None
     stale = P.get("source_sha") != source_sha()
-    note = "profiles/pmc.json (sources %s)" % ("CHANGED since: stale" if stale else "unchanged")
+    note = "profiles/%s (sources %s)" % (pmc_file, "CHANGED since: stale" if stale else "unchanged")
     traffic = None if stale else d.get("hbm_bytes_per_launch")
     issue = {"bound": "valu issue", "valu_wave_insts_per_launch": c.get("SQ_INSTS_VALU"),
              "cycles_per_inst": 4, "simds": 1024, "cycles_per_launch": cyc,
@@ -209,10 +231,13 @@ def pmc_rooflines(dom, launches_per_step_live):
     return traffic, issue, lds
 
 
-def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, steps):
+def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, steps, pmc_file=None):
     """One of the non-headline BASELINE.json configurations, measured the same way in the same
     process (device-resident candidates, pk_score_run, HIP-event kernel times), a few steps
-    only: so that the driver's record carries them too, not only the builder's logs."""
+    only: so that the driver's record carries them too, not only the builder's logs.  Its
+    `roofline` object is the headline's, for this leg's dominant kernel: algorithmic bytes over
+    the kernel's HIP-event time, `traffic` and the LDS / VALU fractions from the leg's own tracked
+    PMC summary (profiles/<pmc_file>, tools/pmc_legs.sh), null when the kernels changed since."""
     from peakachu_amd import _lib
     F = (2 * w + 1) ** 2
     fo = load_forest(forest_spec, w, F)
@@ -238,13 +263,27 @@ def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, step
     value = x.size * steps / el
     dom = max(("extract", "quant", "forest"), key=lambda k: kern[k][0])
     dom_ms, dom_n = kern[dom]
+    achieved = float(x.size) * steps * b_alg(F) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = issue = lds = None
+    if pmc_file and dom_n:
+        traffic, issue, lds = pmc_rooflines(dom, dom_n / steps, pmc_file)
+    fst = fo.stats()
     return {"workload": "%s: synthetic %dx%d (%d-bin band), w=%d, %d-tree RF%s" % (
-                name, n, n, band, w, fo.T, " (untrained random trees)" if (forest_spec or "").startswith("random:") else ""),
+                name, n, n, band, w, fo.T, " (untrained random trees)" if (forest_spec or "").startswith("random:")
+                else " (fitted: %.0f nodes per tree)" % fst["nodes_per_tree_mean"]),
             "value": value, "unit": "candidates/s", "steps": steps, "ms_per_step": el / steps * 1e3,
             "candidates": int(x.size), "scored_pixels": int(n_out),
             "kernel_ms_per_step": {k: v[0] / steps for k, v in kern.items()},
-            "roofline_frac_dominant_kernel": (float(x.size) * steps * b_alg(F) / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                                             if dom_ms > 0 else None,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "alg_bytes_per_candidate": b_alg(F),
+                         "avg_launch_ms": dom_ms / dom_n if dom_n else None, "launches": dom_n,
+                         "candidates_per_launch": float(x.size) * steps / dom_n if dom_n else None,
+                         "lds_array_busy_frac": lds and lds.get("frac_array_busy"),
+                         "lds_issue_slots_frac": lds and lds.get("frac_issue_slots"),
+                         "valu_issue_frac": issue and issue.get("frac"),
+                         "counters": (issue or {}).get("source") or ("no tracked PMC summary (profiles/%s)" % pmc_file)},
+            "roofline_frac_dominant_kernel": achieved / HBM_PEAK_GBS,
             "whole_path_frac": value * b_alg(F) / 1e9 / HBM_PEAK_GBS}
 
 
@@ -252,13 +291,11 @@ def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher: run the same command under
     torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) as a child process and
     hand back its exit code (3 = the RCCL communicator could not be built)."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # (--standalone: the launcher picks its own rendezvous port -- no port is chosen here and
+    # handed over, which another process could have taken in between)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+           "--nnodes=1", "--nproc-per-node", str(n), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
     env.setdefault("OMP_NUM_THREADS", "1")
@@ -314,11 +351,13 @@ def main():
                     help="rehearsal only: all ranks use device 0 and the RCCL gather is skipped "
                          "(RCCL refuses two ranks on one GPU); the result is not a valid measurement")
     ap.add_argument("--no-extra-configs", action="store_true",
-                    help="skip the short legs on the other BASELINE.json shapes (w=6 / 300-bin band with the "
-                         "trained forest; w=11 x 500 random trees) that the default single-GPU run appends")
-    ap.add_argument("--busy-seconds", type=float, default=2.5,
-                    help="untimed scoring loop after the timed region, so that an outside GPU-activity "
-                         "sampler sees the device working (0 = off)")
+                    help="skip the short legs on the other single-GPU BASELINE.json shapes (w=6 / 300-bin band; "
+                         "configs[3]: 60 000 bins, 800-bin band; configs[4]: w=11 x 500 trees, fitted and random) "
+                         "that the default single-GPU run appends")
+    ap.add_argument("--busy-seconds", type=float, default=0.0,
+                    help="opt-in: an UNTIMED scoring loop of this many seconds after the timed region, so that "
+                         "an outside GPU-activity sampler sees the device working; it never touches `value` "
+                         "(single GPU only)")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value")
     a = ap.parse_args()
 
@@ -466,7 +505,7 @@ def main():
     # untimed: the timed region can be a fraction of a second (the driver fixes --steps), too
     # short for a 1 Hz GPU-activity sampler; keep the same scoring loop running for >= 2 s
     busy_steps = 0
-    if a.busy_seconds > 0:
+    if a.busy_seconds > 0 and world == 1:
         t_b = time.perf_counter()
         while time.perf_counter() - t_b < a.busy_seconds:
             cd.run(hm, hf, w, a.thre, a.batch)
@@ -503,20 +542,39 @@ def main():
             r_pcie = hm.score(hf, w, a.thre, x, y, batch=a.batch)
         sync()
         p_el = time.perf_counter() - t0
+        n_local_rate = int(x.size) * a.steps / elapsed
         pcie = {"value": int(x.size) * p_steps / p_el, "unit": "candidates/s", "steps": p_steps,
                 "ms_per_step": p_el / p_steps * 1e3, "scored_pixels": int(r_pcie[0].size),
-                "note": "pk_score with host buffers: candidate upload (8 B each), per-call device "
-                        "allocations and result download included; NOT the headline value"}
+                "frac_of_device_resident": (int(x.size) * p_steps / p_el) / (n_local_rate or 1.0),
+                "note": "SURVEY 8d's literal metric: pk_score with HOST coordinate and result buffers -- upload "
+                        "of the candidates (8 B each, chunk by chunk behind the kernels, checked on the device) "
+                        "and download of the scored pixels inside the timed region; `value` is the same pass "
+                        "over a device-resident list"}
 
     # extra, not the headline: the other single-GPU shapes of BASELINE.json, a few steps each
     extras = None
     if (world == 1 and not a.no_extra_configs and w == 5 and a.n == 30000 and a.band == 200 and a.stride == 1
             and not a.forest and not a.opt):
         extras = []
-        for name, kw in (("w6 (the released 5/10 kb models' window)", dict(n=30000, band=300, w=6, upper=300, forest_spec=None)),
-                         ("configs[4]", dict(n=8000, band=200, w=11, upper=200, forest_spec="random:500:20"))):
+        w11_fitted = os.path.join(ROOT, "peakachu_amd", "data", "forest_w11_t500.npz")
+        legs = [("w6 (the released 5/10 kb models' window)",
+                 dict(n=30000, band=300, w=6, upper=300, forest_spec=None, steps=5, pmc_file="pmc_w6.json")),
+                ("configs[3] (5 kb map: 2x bins, upper = 800 bins)",
+                 dict(n=60000, band=800, w=5, upper=800, forest_spec=None, steps=3, pmc_file="pmc_5kb.json")),
+                # SURVEY 8d's stress forest: RandomForestClassifier(500, max_depth=20) FITTED on buildmatrix
+                # features (tools/make_forest.py -w 11 -T 500), and the untrained random trees of rounds 1-3
+                ("configs[4] (fitted forest)",
+                 dict(n=8000, band=200, w=11, upper=200, forest_spec=w11_fitted, steps=5, pmc_file="pmc_w11.json")),
+                ("configs[4] (random trees: second stress leg)",
+                 dict(n=8000, band=200, w=11, upper=200, forest_spec="random:500:20", steps=5,
+                      pmc_file="pmc_w11_random.json"))]
+        for name, kw in legs:
+            if kw["forest_spec"] == w11_fitted and not os.path.exists(w11_fitted):
+                extras.append({"workload": name, "error": "peakachu_amd/data/forest_w11_t500.npz is missing "
+                                                          "(tools/make_forest.py -w 11 -T 500)"})
+                continue
             try:
-                extras.append(extra_config(L, dev, name, thre=a.thre, batch=a.batch, steps=5, **kw))
+                extras.append(extra_config(L, dev, name, thre=a.thre, batch=a.batch, **kw))
             except Exception as e:  # reported, never fatal for the headline
                 extras.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
 

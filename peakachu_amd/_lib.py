@@ -134,6 +134,10 @@ def last_error():
     return load().pk_last_error().decode("utf-8", "replace")
 
 
+# error codes of include/peakachu_hip.h
+PK_OK, PK_E_INVALID, PK_E_NODEVICE, PK_E_HIP, PK_E_NOMEM, PK_E_UNSUPPORTED, PK_E_COMM = 0, -1, -2, -3, -4, -5, -6
+
+
 def check(rc, what):
     if rc != 0:
         raise PeakachuHipError("%s failed (%d): %s" % (what, rc, last_error()))

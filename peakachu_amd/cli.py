@@ -65,8 +65,18 @@ def getargs(argv=None):
 
 def run(argv=None):
     args, commands = getargs(argv)
-    if commands[0] not in ("-h", "--help"):
-        args.func(args)
+    if commands[0] in ("-h", "--help"):
+        return
+    if args.subcommands == "score_genome" and argv is None:
+        # the command line as the reference documents it, on a box with several GPUs: one copy of
+        # this command per GPU (children; decided before anything has touched HIP), chromosomes
+        # dealt to them.  PK_DEVICES=<n> limits the fan-out, PK_NO_SPAWN=1 switches it off; under a
+        # launcher that has set WORLD_SIZE this process IS a rank.
+        from . import launch
+        n = launch.wanted_ranks()
+        if n > 1:
+            raise SystemExit(launch.spawn(n))
+    args.func(args)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 // pk_api.hip -- host side of the C ABI declared in include/peakachu_hip.h:
 // handle lifetime, forest packing, the chunked extract -> forest pipeline and
 // the result compaction.  Everything runs on one HIP stream per device; no
-// torch, no CPU fallback.
+// deep-learning framework underneath, no CPU fallback.
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -1125,6 +1125,28 @@ static int classify_coords(int32_t n, int w, int64_t N, const int32_t *x, const 
     return any;
 }
 
+// pk_score's coordinates are checked where they arrive (the host-side pass over 2 x 22 MB cost
+// more than a millisecond in front of every call: a fifth of the scoring itself).  A coordinate
+// outside 0 <= x <= y < n -- the contract of the fast extractors -- is replaced by (0, 0) (a window
+// off the matrix, dropped by getwindow's mask: nothing can read out of bounds) and the first
+// offender is recorded in word 65533 of the context's diagnostic buffer as 2^62 - index; pk_score_run
+// reads the word with the result and refuses the call.
+__global__ void coords_sanitize_kernel(int32_t *__restrict__ x, int32_t *__restrict__ y, int64_t cn, int32_t n,
+                                       int64_t base, unsigned long long *__restrict__ err)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cn; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t xi = x[i], yi = y[i];
+        if (xi < 0 || yi < xi || yi >= n) {
+            x[i] = 0;
+            y[i] = 0;
+            atomicMax(err, (1ull << 62) - (unsigned long long)(base + i));
+        }
+    }
+}
+
+#ifndef PK_FIRST_UPLOAD
+#define PK_FIRST_UPLOAD 262144  // candidates of pk_score's first upload chunk (the only exposed one); doubling after
+#endif
 static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands *cd, int w,
                         double prune_sum)
 {
@@ -1155,6 +1177,8 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         // stream, ahead of the event the extractor's stream waits for
         PK_HIP(hipMemcpyAsync(cd->x, cd->h_x, (size_t)cd->N * 4, hipMemcpyHostToDevice, ctx->stream));
         PK_HIP(hipMemcpyAsync(cd->y, cd->h_y, (size_t)cd->N * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(coords_sanitize_kernel, dim3(1024), dim3(256), 0, ctx->stream, cd->x, cd->y, cd->N, m->n,
+                           (int64_t)0, reinterpret_cast<unsigned long long *>(ctx->dbg_buf + 65533));
     }
     if (overlap) {
         // whatever precedes on the main stream (uploads) must be visible to the extractor
@@ -1169,7 +1193,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     const bool stream_coords = cd->h_x != nullptr && !overlap && cd->N > 0;
     auto span = [&](int64_t k_) -> int64_t {  // candidates of chunk k_
         if (!stream_coords) return chunk;
-        int64_t sz = (int64_t)262144 << (k_ < 8 ? k_ : 8);
+        int64_t sz = (int64_t)PK_FIRST_UPLOAD << (k_ < 8 ? k_ : 8);
         sz = (sz + blk - 1) / blk * blk;
         return sz < chunk ? sz : chunk;
     };
@@ -1191,7 +1215,12 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         float *tiles = ctx->fea_tiles + (size_t)buf * tile_floats;
         if (overlap && k >= 2)  // forest(k-2) must be done with this buffer
             PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[buf], 0));
-        if (stream_coords) PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[k & 1], 0));
+        if (stream_coords) {
+            PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[k & 1], 0));
+            hipLaunchKernelGGL(coords_sanitize_kernel, dim3((unsigned)((cn + 2047) / 2048 < 1024 ? (cn + 2047) / 2048 : 1024)),
+                               dim3(256), 0, ctx->stream, cd->x + c0, cd->y + c0, cn, m->n, c0,
+                               reinterpret_cast<unsigned long long *>(ctx->dbg_buf + 65533));
+        }
         // rank kernels: the float tiles are an intermediate of this chunk only (extractor ->
         // quantizer); made and consumed piece by piece through the start of the buffer they
         // never have to leave the Infinity Cache
@@ -1268,10 +1297,22 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
     if (rc) return rc;
     PK_HIP(hipMemcpyAsync(&cd->n_out, cd->n_out_dev, sizeof(int64_t), hipMemcpyDeviceToHost,
                           ctx->stream));
-    long long err = 0;
-    PK_HIP(hipMemcpyAsync(&err, ctx->dbg_buf + 65535, sizeof(long long), hipMemcpyDeviceToHost,
-                          ctx->stream));
+    // words 65533 (first coordinate outside pk_score's contract, see coords_sanitize_kernel), 65534
+    // (a sink that keeps the kernels' warm-up loads alive) and 65535 (the forest kernels' error word)
+    // of the diagnostic buffer
+    long long dbg3[3] = {0, 0, 0};
+    PK_HIP(hipMemcpyAsync(dbg3, ctx->dbg_buf + 65533, sizeof(dbg3), hipMemcpyDeviceToHost, ctx->stream));
     PK_HIP(hipStreamSynchronize(ctx->stream));
+    const long long err = dbg3[2];
+    if (dbg3[0]) {
+        PK_HIP(hipMemset(ctx->dbg_buf + 65533, 0, sizeof(long long)));
+        const long long i = (long long)((1ull << 62) - (unsigned long long)dbg3[0]);
+        if (cd->h_x && i >= 0 && i < cd->N)
+            pk_set_error("pk_score: coordinate %lld = (%d, %d) violates 0 <= x <= y < n=%d", i, cd->h_x[i], cd->h_y[i], m->n);
+        else
+            pk_set_error("pk_score: coordinate %lld violates 0 <= x <= y < n=%d", i, m->n);
+        return PK_E_INVALID;
+    }
     if (err) {
         PK_HIP(hipMemset(ctx->dbg_buf + 65535, 0, sizeof(long long)));
         pk_set_error("forest kernel raised its error word (%lld): 1 = LDS ring wait timed out, "
@@ -1322,8 +1363,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         pk_set_error("pk_score: bad arguments");
         return PK_E_INVALID;
     }
-    int rc = check_coords("pk_score", m->n, N, x, y);
-    if (rc) return rc;
+    int rc = PK_OK;
     // the device-side candidate list of the host-buffer convenience call is kept per device
     // and reused while it is large enough: nine allocations per call cost more than the
     // upload of the coordinates
@@ -1339,6 +1379,9 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         cd->h_y = y;
         deferred = true;
     } else {
+        // (a new list is uploaded whole by pk_cands_create: checked on the host, once)
+        rc = check_coords("pk_score", m->n, N, x, y);
+        if (rc) return rc;
         if (cd) pk_cands_destroy(cd);
         ctx->score_cands = nullptr;
         ctx->score_cands_cap = 0;

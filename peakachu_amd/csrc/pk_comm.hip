@@ -14,6 +14,7 @@
 #include <mutex>
 
 #include "pk_common.h"
+#include "pk_comm_protocol.h"
 
 extern std::recursive_mutex g_api_mu;
 #define PK_API_LOCK std::lock_guard<std::recursive_mutex> api_lock__(g_api_mu)
@@ -21,8 +22,8 @@ extern std::recursive_mutex g_api_mu;
 struct pk_comm {
     int device, nranks, rank;
     ncclComm_t comm;
-    int64_t *d_counts;  // device [2 * nranks]: the counts, then the ranks' status words (comm_agree)
-    int64_t *d_mine;    // device scalar: this rank's byte count (pk_comm_gatherv_bytes)
+    int64_t *d_counts;  // device [4 * nranks]: what an all-gather of up to four words per rank returns
+    int64_t *d_mine;    // device [4]: this rank's words
     // staging areas that live as long as the communicator and only ever grow: a gather is
     // part of the timed step of a multi-GPU run and must not allocate
     void *stage[2];     // [0] send bytes / root's gathered pixels, [1] root's gathered bytes
@@ -43,49 +44,60 @@ static int comm_reserve(pk_comm *c, int i, size_t bytes)
     return PK_OK;
 }
 
-#define PK_NCCL(call)                                                                  \
-    do {                                                                               \
-        ncclResult_t r__ = (call);                                                     \
-        if (r__ != ncclSuccess) {                                                      \
-            pk_set_error("%s failed: %s (%s:%d)", #call, ncclGetErrorString(r__),      \
-                         __FILE__, __LINE__);                                          \
-            return PK_E_COMM;                                                          \
-        }                                                                              \
-    } while (0)
-
 static_assert(sizeof(ncclUniqueId) == 128, "pk_comm_unique_id assumes a 128-byte id");
 
-// Every rank tells every other whether it can go through with the transfer that follows
-// (0 = yes, else its error code): a rank that cannot post its half of a send/recv pair --
-// the root without a staging area, a result larger than the caller's buffers -- must not
-// simply return, or its peers sit in ncclSend / ncclRecv for ever.  All ranks call this at
-// the same point and all take the same decision: *bad = the first rank with a non-zero
-// word (-1 if none), *code = its word.
-static int comm_agree(pk_comm *c, hipStream_t s, int local_rc, int *bad, int *code)
-{
-    const int R = c->nranks;
-    const int64_t mine = local_rc;
-    std::vector<int64_t> h((size_t)R, 0);
-    PK_HIP(hipMemcpyAsync(c->d_mine, &mine, 8, hipMemcpyHostToDevice, s));
-    PK_NCCL(ncclAllGather(c->d_mine, c->d_counts + R, 1, ncclInt64, c->comm, s));
-    PK_HIP(hipMemcpyAsync(h.data(), c->d_counts + R, 8 * (size_t)R, hipMemcpyDeviceToHost, s));
-    PK_HIP(hipStreamSynchronize(s));
-    *bad = -1;
-    *code = 0;
-    for (int r = 0; r < R; r++)
-        if (h[(size_t)r] != 0) {
-            *bad = r;
-            *code = (int)h[(size_t)r];
-            break;
-        }
-    return PK_OK;
-}
+// The protocol (pk_comm_protocol.h: who tells whom what before anybody sends) over RCCL and HIP.
+struct rccl_fabric {
+    pk_comm *c;
+    hipStream_t s;
+    int rank() const { return c->rank; }
+    int nranks() const { return c->nranks; }
+    int nccl(ncclResult_t r, const char *what)
+    {
+        if (r == ncclSuccess) return PK_OK;
+        pk_set_error("%s failed: %s", what, ncclGetErrorString(r));
+        return PK_E_COMM;
+    }
+    int hip(hipError_t e, const char *what)
+    {
+        if (e == hipSuccess) return PK_OK;
+        pk_set_error("%s failed: %s", what, hipGetErrorString(e));
+        return PK_E_HIP;
+    }
+    int allgather(const int64_t *mine, int words, int64_t *all)
+    {
+        int rc = hip(hipMemcpyAsync(c->d_mine, mine, 8 * (size_t)words, hipMemcpyHostToDevice, s), "count upload");
+        if (!rc) rc = nccl(ncclAllGather(c->d_mine, c->d_counts, (size_t)words, ncclInt64, c->comm, s), "ncclAllGather");
+        if (!rc)
+            rc = hip(hipMemcpyAsync(all, c->d_counts, 8 * (size_t)words * (size_t)c->nranks, hipMemcpyDeviceToHost, s),
+                     "count download");
+        if (!rc) rc = hip(hipStreamSynchronize(s), "stream sync");
+        return rc;
+    }
+    size_t stage_cap(int i) const { return c->stage_cap[i]; }
+    int reserve(int i, size_t bytes) { return comm_reserve(c, i, bytes); }
+    char *stage(int i) { return static_cast<char *>(c->stage[i]); }
+    int copy_dd(void *dst, const void *src, size_t n) { return hip(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s), "local copy"); }
+    int upload(void *dst, const void *src, size_t n) { return hip(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s), "upload"); }
+    int download(void *dst, const void *src, size_t n) { return hip(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s), "download"); }
+    int group_begin() { return nccl(ncclGroupStart(), "ncclGroupStart"); }
+    int group_end() { return nccl(ncclGroupEnd(), "ncclGroupEnd"); }
+    int send(const void *p, size_t n, int peer) { return nccl(ncclSend(p, n, ncclUint8, peer, c->comm, s), "ncclSend"); }
+    int recv(void *p, size_t n, int peer) { return nccl(ncclRecv(p, n, ncclUint8, peer, c->comm, s), "ncclRecv"); }
+    int sync() { return hip(hipStreamSynchronize(s), "stream sync"); }
+    template <typename... A>
+    void error(const char *fmt, A... a) { pk_set_error(fmt, a...); }
+};
 
 extern "C" int pk_comm_unique_id(uint8_t id[128])
 {
     if (!id) return PK_E_INVALID;
     ncclUniqueId u;
-    PK_NCCL(ncclGetUniqueId(&u));
+    ncclResult_t r = ncclGetUniqueId(&u);
+    if (r != ncclSuccess) {
+        pk_set_error("ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+        return PK_E_COMM;
+    }
     memcpy(id, &u, 128);
     return PK_OK;
 }
@@ -116,8 +128,8 @@ extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8
         delete c;
         return nullptr;
     }
-    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * 2 * (size_t)nranks) != hipSuccess ||
-        hipMalloc((void **)&c->d_mine, sizeof(int64_t)) != hipSuccess) {
+    if (hipMalloc((void **)&c->d_counts, sizeof(int64_t) * 4 * (size_t)nranks) != hipSuccess ||
+        hipMalloc((void **)&c->d_mine, sizeof(int64_t) * 4) != hipSuccess) {
         pk_set_error("pk_comm_create: device allocation failed");
         ncclCommDestroy(c->comm);
         delete c;
@@ -149,110 +161,10 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
     }
     pk_device_ctx *ctx = pk_ctx(c->device);
     if (!ctx) return PK_E_NODEVICE;
-    hipStream_t s = ctx->stream;
-    const int R = c->nranks;
-    // 1. counts: n_out_dev holds this rank's count after pk_score_run
-    PK_NCCL(ncclAllGather(cd->n_out_dev, c->d_counts, 1, ncclInt64, c->comm, s));
-    std::vector<int64_t> h_counts((size_t)R);
-    PK_HIP(hipMemcpyAsync(h_counts.data(), c->d_counts, sizeof(int64_t) * (size_t)R,
-                          hipMemcpyDeviceToHost, s));
-    PK_HIP(hipStreamSynchronize(s));
-    int64_t total = 0;
-    for (int r = 0; r < R; r++) total += h_counts[(size_t)r];
-    if (counts)
-        for (int r = 0; r < R; r++) counts[r] = h_counts[(size_t)r];
-
-    // 2. what only the root can know -- whether the result fits the caller's buffers and its
-    // staging area could be made -- is agreed on by all ranks BEFORE anybody sends
-    const size_t t1 = ((size_t)(total > 0 ? total : 1) + 1) & ~(size_t)1;
-    int local_rc = PK_OK;
-    if (c->rank == 0) {
-        if (total > cap || (total > 0 && (!ox || !oy || !op || !osignal))) {
-            pk_set_error("pk_comm_gather_scored: %lld pixels exceed the root capacity %lld",
-                         (long long)total, (long long)cap);
-            local_rc = PK_E_INVALID;
-        } else {
-            local_rc = comm_reserve(c, 0, t1 * 24);  // one staging area [x | y | p | signal]
-        }
-    }
-    {
-        int bad = -1, code = 0;
-        const int rca = comm_agree(c, s, local_rc, &bad, &code);
-        if (rca) return rca;
-        if (bad >= 0) {
-            if (bad != c->rank)
-                pk_set_error("pk_comm_gather_scored: rank %d cannot take part in the gather (code %d); "
-                             "nothing was sent", bad, code);
-            return bad == c->rank ? local_rc : PK_E_COMM;
-        }
-    }
-
-    if (c->rank != 0) {
-        // 3. peer -> root: four typed sends in one group
-        const size_t k = (size_t)h_counts[(size_t)c->rank];
-        if (k > 0) {
-            PK_NCCL(ncclGroupStart());
-            PK_NCCL(ncclSend(cd->ox, k, ncclInt32, 0, c->comm, s));
-            PK_NCCL(ncclSend(cd->oy, k, ncclInt32, 0, c->comm, s));
-            PK_NCCL(ncclSend(cd->op, k, ncclFloat64, 0, c->comm, s));
-            PK_NCCL(ncclSend(cd->osig, k, ncclFloat64, 0, c->comm, s));
-            PK_NCCL(ncclGroupEnd());
-        }
-        PK_HIP(hipStreamSynchronize(s));
-        return PK_OK;
-    }
-
-    // root: 8-byte aligned parts of the staging area
-    int32_t *gx = static_cast<int32_t *>(c->stage[0]), *gy = gx + t1;
-    double *gp = reinterpret_cast<double *>(gy + t1), *gs = gp + t1;
-    int rc = PK_OK;
-    do {
-        const size_t k0 = (size_t)h_counts[0];
-        if (k0 > 0) {
-            if (hipMemcpyAsync(gx, cd->ox, k0 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-                hipMemcpyAsync(gy, cd->oy, k0 * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-                hipMemcpyAsync(gp, cd->op, k0 * 8, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-                hipMemcpyAsync(gs, cd->osig, k0 * 8, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-                pk_set_error("pk_comm_gather_scored: local copy failed");
-                rc = PK_E_HIP;
-                break;
-            }
-        }
-        ncclResult_t nr = ncclGroupStart();
-        size_t off = k0;
-        for (int r = 1; r < R && nr == ncclSuccess; r++) {
-            const size_t k = (size_t)h_counts[(size_t)r];
-            if (k == 0) continue;
-            nr = ncclRecv(gx + off, k, ncclInt32, r, c->comm, s);
-            if (nr == ncclSuccess) nr = ncclRecv(gy + off, k, ncclInt32, r, c->comm, s);
-            if (nr == ncclSuccess) nr = ncclRecv(gp + off, k, ncclFloat64, r, c->comm, s);
-            if (nr == ncclSuccess) nr = ncclRecv(gs + off, k, ncclFloat64, r, c->comm, s);
-            off += k;
-        }
-        ncclResult_t ne = ncclGroupEnd();
-        if (nr != ncclSuccess || ne != ncclSuccess) {
-            pk_set_error("pk_comm_gather_scored: RCCL recv failed: %s",
-                         ncclGetErrorString(nr != ncclSuccess ? nr : ne));
-            rc = PK_E_COMM;
-            break;
-        }
-        if (total > 0) {
-            const size_t t = (size_t)total;
-            if (hipMemcpyAsync(ox, gx, t * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                hipMemcpyAsync(oy, gy, t * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                hipMemcpyAsync(op, gp, t * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                hipMemcpyAsync(osignal, gs, t * 8, hipMemcpyDeviceToHost, s) != hipSuccess) {
-                pk_set_error("pk_comm_gather_scored: download failed");
-                rc = PK_E_HIP;
-                break;
-            }
-        }
-        if (hipStreamSynchronize(s) != hipSuccess) {
-            pk_set_error("pk_comm_gather_scored: stream sync failed");
-            rc = PK_E_HIP;
-        }
-    } while (0);
-    return rc;
+    rccl_fabric fb{c, ctx->stream};
+    // (cd->n_out: the host copy pk_score_run made of this rank's count)
+    return pk_proto::gather_scored(fb, cd->n_out, cd->ox, cd->oy, cd->op, cd->osig, counts, cap, ox, oy, op,
+                                   osignal);
 }
 
 extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbytes, int64_t *counts,
@@ -265,98 +177,6 @@ extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbyte
     }
     pk_device_ctx *ctx = pk_ctx(c->device);
     if (!ctx) return PK_E_NODEVICE;
-    hipStream_t s = ctx->stream;
-    const int R = c->nranks;
-    int64_t *d_mine = c->d_mine;
-    uint8_t *d_send = nullptr, *d_recv = nullptr;
-    // a rank that cannot stage its bytes still takes part in the count exchange (with a count
-    // of zero) and reports the failure in the agreement that follows
-    int local_rc = comm_reserve(c, 0, (size_t)(nbytes > 0 ? nbytes : 1));
-    if (local_rc) nbytes = 0;
-    int rc = PK_OK;
-    d_send = static_cast<uint8_t *>(c->stage[0]);
-    std::vector<int64_t> h_counts((size_t)R);
-    do {
-        if (hipMemcpyAsync(d_mine, &nbytes, 8, hipMemcpyHostToDevice, s) != hipSuccess) {
-            pk_set_error("pk_comm_gatherv_bytes: upload failed");
-            rc = PK_E_HIP;  // (the stream itself is gone: the peers will see the communicator fail)
-            break;
-        }
-        if (nbytes > 0 &&
-            hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, s) != hipSuccess) {
-            pk_set_error("pk_comm_gatherv_bytes: upload failed");
-            local_rc = PK_E_HIP;
-        }
-        ncclResult_t nr = ncclAllGather(d_mine, c->d_counts, 1, ncclInt64, c->comm, s);
-        if (nr != ncclSuccess ||
-            hipMemcpyAsync(h_counts.data(), c->d_counts, 8 * (size_t)R, hipMemcpyDeviceToHost, s) !=
-                hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            pk_set_error("pk_comm_gatherv_bytes: count exchange failed");
-            rc = PK_E_COMM;
-            break;
-        }
-        int64_t total = 0;
-        for (int r = 0; r < R; r++) total += h_counts[(size_t)r];
-        if (counts)
-            for (int r = 0; r < R; r++) counts[r] = h_counts[(size_t)r];
-        // the root's part (staging area, capacity) is settled before anybody sends
-        if (c->rank == 0 && !local_rc) {
-            if (total > cap || (total > 0 && !recv)) {
-                pk_set_error("pk_comm_gatherv_bytes: %lld bytes exceed the root capacity %lld",
-                             (long long)total, (long long)cap);
-                local_rc = PK_E_INVALID;
-            } else {
-                local_rc = comm_reserve(c, 1, (size_t)(total > 0 ? total : 1));
-            }
-        }
-        {
-            int bad = -1, code = 0;
-            rc = comm_agree(c, s, local_rc, &bad, &code);
-            if (rc) break;
-            if (bad >= 0) {
-                if (bad != c->rank)
-                    pk_set_error("pk_comm_gatherv_bytes: rank %d cannot take part in the gather (code %d); "
-                                 "nothing was sent", bad, code);
-                rc = bad == c->rank ? local_rc : PK_E_COMM;
-                break;
-            }
-        }
-        if (c->rank != 0) {
-            if (nbytes > 0) {
-                nr = ncclSend(d_send, (size_t)nbytes, ncclUint8, 0, c->comm, s);
-                if (nr != ncclSuccess) {
-                    pk_set_error("ncclSend failed: %s", ncclGetErrorString(nr));
-                    rc = PK_E_COMM;
-                    break;
-                }
-            }
-            if (hipStreamSynchronize(s) != hipSuccess) rc = PK_E_HIP;
-            break;
-        }
-        d_recv = static_cast<uint8_t *>(c->stage[1]);
-        if (nbytes > 0 &&
-            hipMemcpyAsync(d_recv, d_send, (size_t)nbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-            rc = PK_E_HIP;
-            break;
-        }
-        nr = ncclGroupStart();
-        size_t off = (size_t)h_counts[0];
-        for (int r = 1; r < R && nr == ncclSuccess; r++) {
-            const size_t k = (size_t)h_counts[(size_t)r];
-            if (k) nr = ncclRecv(d_recv + off, k, ncclUint8, r, c->comm, s);
-            off += k;
-        }
-        ncclResult_t ne = ncclGroupEnd();
-        if (nr != ncclSuccess || ne != ncclSuccess) {
-            pk_set_error("pk_comm_gatherv_bytes: RCCL recv failed");
-            rc = PK_E_COMM;
-            break;
-        }
-        if (total > 0 &&
-            hipMemcpyAsync(recv, d_recv, (size_t)total, hipMemcpyDeviceToHost, s) != hipSuccess)
-            rc = PK_E_HIP;
-        if (hipStreamSynchronize(s) != hipSuccess) rc = PK_E_HIP;
-    } while (0);
-    return rc;
+    rccl_fabric fb{c, ctx->stream};
+    return pk_proto::gatherv_bytes(fb, send, nbytes, counts, recv, cap);
 }

@@ -9,10 +9,11 @@ only the model.  Here
     blocks aligned to the reference batch size, so the per-batch rule of
     peakachu/scoreUtils.py:104-108 sees the same batches on any rank count,
   * `gather_records` moves the packed records to rank 0 -- over RCCL
-    (pk_comm_gatherv_bytes, xGMI peer->root sends) on GPUs, or over a
-    torch.distributed/gloo group on CPUs (tests).
-The host rendezvous (rank, world size, the RCCL unique id broadcast) uses
-torch.distributed's env:// init exactly as torch.distributed.run provides it.
+    (pk_comm_gatherv_bytes, xGMI peer->root sends) on GPUs, or over the host
+    rendezvous itself on CPUs (tests, PK_TRANSPORT=tcp).
+The host rendezvous (the RCCL unique id, sizes, failure messages, barriers) is
+peakachu_amd.rendezvous: TCP on 127.0.0.1, standard library only; rank and world size
+come from RANK / WORLD_SIZE as peakachu_amd.launch or an external launcher (the bench driver's, srun, mpirun) set them.
 """
 import os
 
@@ -55,65 +56,57 @@ def pack_records(chrom_id, x, y, prob, signal):
     return rec
 
 
-class GlooTransport:
-    """CPU transport for tests: torch.distributed gather of byte tensors."""
+class TcpTransport:
+    """Everything over the host rendezvous (peakachu_amd.rendezvous: TCP on 127.0.0.1, standard
+    library only).  The transport of the CPU tests, and of PK_TRANSPORT=tcp."""
 
-    def __init__(self):
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            dist.init_process_group(backend="gloo")
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+    def __init__(self, rdzv=None):
+        from .rendezvous import Rendezvous
+        self.r = rdzv or Rendezvous()
+        self.rank, self.world = self.r.rank, self.r.world
 
     def gatherv(self, payload: bytes):
-        out = [None] * self.world if self.rank == 0 else None
-        self.dist.gather_object(payload, out, dst=0)
-        return out
+        return self.r.gather(payload)
 
     def barrier(self):
-        self.dist.barrier()
+        self.r.barrier()
 
     def all_failures(self, failure):
         """Every rank passes None (fine) or a message; every rank gets the list of messages."""
-        out = [None] * self.world
-        self.dist.all_gather_object(out, failure)
-        return [m for m in out if m]
+        return [m for m in self.r.all_gather_obj(failure) if m]
 
     def close(self):
-        pass
+        self.r.close()
 
 
-class RcclTransport:
-    """GPU transport: RCCL gather-v through the C ABI (pk_comm_*).  The unique
-    id travels over the torch.distributed (gloo) rendezvous."""
+class RcclTransport(TcpTransport):
+    """GPU transport: the payload travels by RCCL gather-v through the C ABI (pk_comm_*: xGMI
+    peer -> root sends); the unique id, the sizes, failure messages and barriers over the host
+    rendezvous (a rank whose GPU failed can still say so)."""
 
-    def __init__(self, device):
-        import torch.distributed as dist
+    def __init__(self, device, rdzv=None):
         from . import _lib
-        if not dist.is_initialized():
-            dist.init_process_group(backend="gloo")
-        self.dist, self._lib = dist, _lib
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        super().__init__(rdzv)
+        self._lib = _lib
         L = _lib.require_device()
-        ids = [None]
+        buf = np.zeros(128, np.uint8)
         if self.rank == 0:
-            buf = np.zeros(128, np.uint8)
             _lib.check(L.pk_comm_unique_id(buf), "pk_comm_unique_id")
-            ids = [buf.tobytes()]
-        dist.broadcast_object_list(ids, src=0)
-        self.h = L.pk_comm_create(device, self.world, self.rank,
-                                  np.frombuffer(ids[0], np.uint8).copy())
-        if not self.h:
-            raise _lib.PeakachuHipError("pk_comm_create: " + _lib.last_error())
+        uid = self.r.broadcast(buf.tobytes())
+        self.h = L.pk_comm_create(device, self.world, self.rank, np.frombuffer(uid, np.uint8).copy())
+        # all ranks learn whether every communicator exists (a rank without one must not leave
+        # the others waiting inside RCCL)
+        errs = self.all_failures(None if self.h else "rank %d: pk_comm_create: %s" % (self.rank, _lib.last_error()))
+        if errs:
+            self.close()
+            raise _lib.PeakachuHipError("; ".join(errs))
         self._L = L
 
     def gatherv(self, payload: bytes):
         counts = np.zeros(self.world, np.int64)
         send = np.frombuffer(payload, np.uint8) if payload else np.zeros(1, np.uint8)
-        # first exchange sizes only (cap = 0 on non-root), then the data
-        sizes = [None] * self.world
-        self.dist.all_gather_object(sizes, len(payload))
-        total = int(sum(sizes))
+        # the sizes first (host side), so that rank 0 can offer a buffer of the right size
+        total = sum(self.r.all_gather_obj(len(payload)))
         recv = np.empty(max(total, 1), np.uint8) if self.rank == 0 else None
         self._lib.check(self._L.pk_comm_gatherv_bytes(
             self.h, send.ctypes.data, len(payload), counts,
@@ -127,20 +120,11 @@ class RcclTransport:
             off += int(counts[r])
         return out
 
-    def barrier(self):
-        self.dist.barrier()
-
-    def all_failures(self, failure):
-        """Every rank passes None (fine) or a message; every rank gets the list of messages
-        (over the host rendezvous: a rank whose GPU failed can still take part)."""
-        out = [None] * self.world
-        self.dist.all_gather_object(out, failure)
-        return [m for m in out if m]
-
     def close(self):
         if getattr(self, "h", None):
             self._L.pk_comm_destroy(self.h)
             self.h = None
+        super().close()
 
 
 def gather_records(local_records, transport):

@@ -1,8 +1,9 @@
 """`peakachu score_genome` for the MI355X path (peakachu/score_genome.py:3-84).
 
-Same flags, same chromosome selection, same output; chromosomes are dealt to
-the ranks of a torch.distributed.run launch (one per GPU) and rank 0 writes
-the bedpe in the reference's order after one RCCL gather.
+Same flags, same chromosome selection, same output.  Started as the reference documents it
+(README.md:127) on a box with several GPUs, the command runs one copy of itself per GPU
+(cli.run -> peakachu_amd.launch; a launcher that sets RANK / WORLD_SIZE works too): chromosomes are dealt
+to the ranks and rank 0 writes the bedpe in the reference's order after one RCCL gather.
 """
 import contextlib
 import os
@@ -128,9 +129,9 @@ def main(args):
 
 
 def make_transport(local_rank):
-    """RCCL on GPUs; PK_TRANSPORT=gloo selects the CPU transport (tests)."""
-    if os.environ.get("PK_TRANSPORT") == "gloo":
-        return dist.GlooTransport()
+    """RCCL on GPUs; PK_TRANSPORT=tcp sends the records over the host rendezvous (tests)."""
+    if os.environ.get("PK_TRANSPORT") == "tcp":
+        return dist.TcpTransport()
     return dist.RcclTransport(local_rank)
 
 

@@ -1,8 +1,9 @@
-"""Worker of tests/test_dist_gloo.py: one rank of a world_size-2 gloo group
-on CPUs.  Exercises the N>1 host path (chromosome dealing, candidate-block
-sharding, packing, gather to rank 0, ordered merge) with the CPU oracle as
-the per-rank scorer -- the GPU ranks run the same code with the HIP library
-and the RCCL transport instead."""
+"""Worker of tests/test_dist.py: one rank of a world_size-2 (or 3) job on CPUs, launched
+the way the driver launches bench.py or by peakachu_amd.launch.  Exercises the N>1 host
+path (chromosome dealing, candidate-block sharding, packing, gather to rank 0, ordered
+merge, failure vote) over the product's own rendezvous (peakachu_amd.rendezvous, TCP) with
+the CPU oracle as the per-rank scorer -- the GPU ranks run the same code with the HIP
+library and the RCCL transport instead."""
 import os
 import sys
 
@@ -29,7 +30,7 @@ def oracle_chromosome(lib, key, fo, w, lower, upper, thre):
 
 def main():
     out_dir = sys.argv[1]
-    tr = dist.GlooTransport()
+    tr = dist.TcpTransport()
     rank, world = tr.rank, tr.world
     np.seterr(divide="ignore", invalid="ignore")
     z = gio.load("g6_driver.npz")
@@ -54,8 +55,8 @@ def main():
         text = open(path).read() if os.path.exists(path) else ""
         ok = ok and (text == str(z["genome_raw"]))
     # ---- 1b. a failing rank is reported to every rank (score_genome leaves together)
-    fails = tr.all_failures("rank 1: boom" if rank == 1 else None)
-    ok = ok and fails == ["rank 1: boom"]
+    fails = tr.all_failures("rank %d: boom" % rank if rank == world - 1 else None)
+    ok = ok and fails == ["rank %d: boom" % (world - 1)]
     ok = ok and tr.all_failures(None) == []
     # ---- 2. one chromosome, candidate blocks cut at batch boundaries
     q = gio.load("g4_batch_quirk.npz")
@@ -75,6 +76,7 @@ def main():
         ok = ok and np.array_equal(gio.bits(a["signal"]), gio.bits(q["b_signal"]))
         open(os.path.join(out_dir, "result.txt"), "w").write("OK" if ok else "MISMATCH")
     tr.barrier()
+    tr.close()
 
 
 if __name__ == "__main__":

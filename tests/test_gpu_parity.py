@@ -472,6 +472,33 @@ def test_empty_and_edge_inputs(hip_lib):
         hm.score(hf, w, 0.5, np.array([50], np.int32), np.array([40], np.int32))
 
 
+def test_score_checks_streamed_coordinates_on_the_device(hip_lib):
+    """pk_score with host buffers: from the second call on the coordinates travel chunk by chunk
+    behind the kernels and are checked where they arrive (round 4: the host-side pass cost a fifth
+    of the call).  A coordinate outside the contract is named, nothing reads out of bounds, and the
+    next call is served as if nothing had happened."""
+    z = gio.load("g3_score_raw.npz")
+    w, upper = int(z["w"]), int(z["upper"])
+    Mf = utils.band_filter(gio.sym_matrix(z, "R"), w, upper)
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper)
+    hf = _lib.HipForest(flat(gio.forest(str(z["forest"]))))
+    reps = 700000 // z["ridx"].size + 1   # several upload chunks (the first is 262 144 candidates)
+    x = np.tile(z["ridx"].astype(np.int32), reps)
+    y = np.tile(z["cidx"].astype(np.int32), reps)
+    first = hm.score(hf, w, 0.5, x, y)          # sizes the reusable device-side list (host check)
+    again = hm.score(hf, w, 0.5, x, y)          # streamed, device check
+    assert all(np.array_equal(gio.bits(a) if a.dtype == np.float64 else a,
+                              gio.bits(b) if b.dtype == np.float64 else b) for a, b in zip(first, again))
+    for bad_at, (bx, by) in ((400000, (50, 40)), (5, (-1, 3)), (x.size - 1, (10, Mf.shape[0]))):
+        xb, yb = x.copy(), y.copy()
+        xb[bad_at], yb[bad_at] = bx, by
+        with pytest.raises(_lib.PeakachuHipError, match=r"coordinate %d = \(%d, %d\)" % (bad_at, bx, by)):
+            hm.score(hf, w, 0.5, xb, yb)
+        ok = hm.score(hf, w, 0.5, x, y)
+        assert all(np.array_equal(gio.bits(a) if a.dtype == np.float64 else a,
+                                  gio.bits(b) if b.dtype == np.float64 else b) for a, b in zip(first, ok))
+
+
 def test_chromosome_drop_in(hip_lib, tmp_path):
     """The mirror class reproduces the reference's bedpe text byte for byte."""
     from peakachu_amd import scoreUtils
@@ -610,6 +637,25 @@ def test_rccl_gather_single_rank(hip_lib):
         _lib.check(L.pk_comm_gatherv_bytes(comm, payload.ctypes.data, 1000, counts,
                                            recv.ctypes.data, 1000), "gatherv")
         assert counts[0] == 1000 and np.array_equal(recv, payload)
+        # the refusal branches (the protocol itself runs with 1..8 ranks and injected failures in
+        # tests/test_comm_protocol.py): buffers one record / one byte too small are refused with
+        # PK_E_INVALID, nothing is written, and the communicator stays in step -- the next call with
+        # the right capacity succeeds
+        gx[:] = -7
+        assert L.pk_comm_gather_scored(comm, cd.h, counts, n - 1, gx.ctypes.data, gy.ctypes.data,
+                                       gp.ctypes.data, gs.ctypes.data) == _lib.PK_E_INVALID
+        assert "exceed the root's capacity" in _lib.last_error() and (gx == -7).all()
+        assert L.pk_comm_gather_scored(comm, cd.h, counts, n, None, gy.ctypes.data,
+                                       gp.ctypes.data, gs.ctypes.data) == _lib.PK_E_INVALID
+        _lib.check(L.pk_comm_gather_scored(comm, cd.h, counts, n, gx.ctypes.data, gy.ctypes.data,
+                                           gp.ctypes.data, gs.ctypes.data), "gather after a refusal")
+        assert np.array_equal(gx, ox) and np.array_equal(gio.bits(gs), gio.bits(osig))
+        recv[:] = 0
+        assert L.pk_comm_gatherv_bytes(comm, payload.ctypes.data, 1000, counts, recv.ctypes.data, 999) == _lib.PK_E_INVALID
+        assert not recv.any()
+        _lib.check(L.pk_comm_gatherv_bytes(comm, payload.ctypes.data, 1000, counts,
+                                           recv.ctypes.data, 1000), "gatherv after a refusal")
+        assert np.array_equal(recv, payload)
     finally:
         L.pk_comm_destroy(comm)
 

@@ -39,6 +39,11 @@ def source_sha():
 
 def kclass(name):
     n = name.replace(" ", "")
+    if "forest_qr_kernel" in n:
+        # forest_qr_kernel<HALF1, PRUNE, NR>: the full evaluation is PRUNE = false
+        return "forest" if re.search(r"forest_qr_kernel<\d+,false,\d+>", n) else None
+    if "forest_q2_kernel" in n:
+        return "forest"
     if "forest_q_kernel" in n:
         # forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>: the full evaluation is PRUNE = false AND
         # EARLY = false (`<..., true, false>` -- the early-exit extra pass -- also ends in "false>")
@@ -47,7 +52,7 @@ def kclass(name):
         return "forest" if "false>" in n else None
     if "quantize_tiles_kernel" in n:
         return "quant"
-    if "extract_pair_clean_kernel" in n or "extract_pair_kernel" in n or "extract_lds_kernel" in n:
+    if "extract_" in n and "_kernel" in n:
         return "extract"
     return None
 
