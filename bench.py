@@ -515,7 +515,7 @@ def main():
     # early_exit: candidates that provably end at p <= thre stop walking; same pixels)
     early = None
     if world == 1:
-        _lib.set_option("early_exit", 1)
+        cd.set_option("early_exit", 1)   # (this candidate list's own option)
         step()
         sync()
         e_steps = min(a.steps, 20)
@@ -524,7 +524,7 @@ def main():
             n_early = step()
         sync()
         e_el = time.perf_counter() - t0
-        _lib.set_option("early_exit", 0)
+        cd.set_option("early_exit", 0)
         early = {"value": int(x.size) * e_steps / e_el, "ms_per_step": e_el / e_steps * 1e3, "steps": e_steps,
                  "scored_pixels": int(n_early), "same_pixels_as_full_evaluation": bool(n_early == n_out),
                  "note": "opt-in exact pruning at threshold %g; NOT the headline value" % a.thre}

@@ -188,10 +188,22 @@ int pk_set_gauss_taps(const double *taps5);
 int pk_get_gauss_taps(double *taps5);
 
 /* ---- tuning / measurement ------------------------------------------------ */
-/* named integer knobs ("chunk", "forest_ilp", "forest_lds", ...); returns
- * PK_E_INVALID for an unknown name */
+/* named integer knobs ("chunk", "forest_ilp", "forest_lds", ...); PK_E_INVALID for an unknown
+ * name or a value out of range.  Every handle carries its OWN set: pk_set_option sets the defaults
+ * that handles created afterwards start from (existing handles are not touched);
+ * pk_<handle>_set_option changes one handle's copy -- forest: which kernel family walks it and
+ * how (forest_*); matrix: which extractor runs (extract_*) and, for the calls that have no
+ * candidate handle (pk_score, pk_extract), the pipeline options; candidates: the pipeline
+ * options of pk_score_run (chunk, overlap, sub_chunk, early_exit).  Results never depend on
+ * them; the route does.  (The reference has no such knobs: one code path, peakachu/scoreUtils.py:95-125.) */
 int pk_set_option(const char *name, int64_t value);
 int64_t pk_get_option(const char *name);
+int pk_forest_set_option(pk_forest *, const char *name, int64_t value);
+int64_t pk_forest_get_option(pk_forest *, const char *name);
+int pk_matrix_set_option(pk_matrix *, const char *name, int64_t value);
+int64_t pk_matrix_get_option(pk_matrix *, const char *name);
+int pk_cands_set_option(pk_cands *, const char *name, int64_t value);
+int64_t pk_cands_get_option(pk_cands *, const char *name);
 /* HIP-event timing of the library's own kernels on its own stream */
 int pk_prof_enable(int on);
 int pk_prof_reset(void);

@@ -67,6 +67,12 @@ SIGNATURES = {
     "pk_get_gauss_taps": (C.c_int, [_f64p]),
     "pk_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "pk_get_option": (C.c_int64, [C.c_char_p]),
+    "pk_forest_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "pk_forest_get_option": (C.c_int64, [_vp, C.c_char_p]),
+    "pk_matrix_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "pk_matrix_get_option": (C.c_int64, [_vp, C.c_char_p]),
+    "pk_cands_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "pk_cands_get_option": (C.c_int64, [_vp, C.c_char_p]),
     "pk_prof_enable": (C.c_int, [C.c_int]),
     "pk_prof_reset": (C.c_int, []),
     "pk_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -152,10 +158,44 @@ def require_device():
 
 
 # ------------------------------------------------------------------ handles
-class HipForest:
-    """Device-resident forest (pk_forest)."""
+class _Options:
+    """Per-handle options (include/peakachu_hip.h: every handle carries its own set; pk_set_option
+    only changes the defaults of handles created afterwards).  `options` may hold names of any
+    handle kind: each handle takes the ones that concern it (forest_* -> forests, extract_* ->
+    matrices, chunk / overlap / sub_chunk / early_exit -> candidate lists and, for the calls
+    without a list, matrices)."""
+    _KIND = None  # "forest" | "matrix" | "cands"
 
-    def __init__(self, flat, device=0):
+    @staticmethod
+    def concerns(kind, name):
+        if name.startswith("forest_"):
+            return kind == "forest" or (name == "forest_lds" and kind == "matrix")
+        if name.startswith("extract_"):
+            return kind == "matrix"
+        if name == "chunk":
+            return True
+        return kind in ("cands", "matrix")  # overlap, sub_chunk, early_exit
+
+    def set_option(self, name, value):
+        check(getattr(self._L, "pk_%s_set_option" % self._KIND)(self.h, name.encode(), int(value)),
+              "pk_%s_set_option(%s)" % (self._KIND, name))
+        return self
+
+    def get_option(self, name):
+        return getattr(self._L, "pk_%s_get_option" % self._KIND)(self.h, name.encode())
+
+    def set_options(self, options):
+        for k, v in (options or {}).items():
+            if self.concerns(self._KIND, k):
+                self.set_option(k, v)
+        return self
+
+
+class HipForest(_Options):
+    """Device-resident forest (pk_forest)."""
+    _KIND = "forest"
+
+    def __init__(self, flat, device=0, options=None):
         L = require_device()
         self._L = L
         self.T, self.F = int(flat.T), int(flat.F)
@@ -171,6 +211,7 @@ class HipForest:
         if not self.h:
             raise PeakachuHipError("pk_forest_create: " + last_error())
         self.device = device
+        self.set_options(options)
 
     def info(self):
         T, F, d = C.c_int(), C.c_int(), C.c_int()
@@ -237,10 +278,11 @@ class HipCsr:
     __del__ = close
 
 
-class HipMatrix:
+class HipMatrix(_Options):
     """Device-resident band matrix + expected vector (pk_matrix)."""
+    _KIND = "matrix"
 
-    def __init__(self, indptr, indices, data, n, exp_arr, dlo, dhi, device=0):
+    def __init__(self, indptr, indices, data, n, exp_arr, dlo, dhi, device=0, options=None):
         L = require_device()
         self._L = L
         exp_arr = np.ascontiguousarray(exp_arr, np.float64)
@@ -254,6 +296,7 @@ class HipMatrix:
         if not self.h:
             raise PeakachuHipError("pk_matrix_create: " + last_error())
         self.n, self.dlo, self.dhi, self.device = int(n), int(dlo), int(dhi), device
+        self.set_options(options)
 
     @classmethod
     def _wrap(cls, L, h, n, device):
@@ -312,8 +355,9 @@ class HipMatrix:
     __del__ = close
 
 
-class HipCands:
+class HipCands(_Options):
     """Device-resident candidate list and per-candidate outputs (pk_cands)."""
+    _KIND = "cands"
 
     @classmethod
     def from_band(cls, raw_matrix, lower, upper, bg, kstar=None, weights=None, mustar=None):
@@ -344,7 +388,7 @@ class HipCands:
         check(self._L.pk_cands_fetch(self.h, x, y), "pk_cands_fetch")
         return x[:self.N], y[:self.N]
 
-    def __init__(self, x, y, device=0):
+    def __init__(self, x, y, device=0, options=None):
         L = require_device()
         self._L = L
         x = np.ascontiguousarray(x, np.int32)
@@ -355,6 +399,7 @@ class HipCands:
         if not self.h:
             raise PeakachuHipError("pk_cands_create: " + last_error())
         self.n_out = 0
+        self.set_options(options)
 
     def set_prune(self, on=True):
         """Exact early termination for this list's runs (same scored pixels)."""

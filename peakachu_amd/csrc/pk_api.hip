@@ -228,71 +228,73 @@ extern "C" int pk_get_gauss_taps(double *taps5)
     return PK_OK;
 }
 
-extern "C" int pk_set_option(const char *name, int64_t value)
+// Options live in every handle (pk_forest / pk_matrix / pk_cands ::opt); pk_set_option sets the
+// DEFAULTS new handles start from, pk_<handle>_set_option one handle's own copy.  (Rounds 1-3 had one
+// process-wide set: a knob left set by one caller changed every other caller of the process.)
+static int opt_assign(pk_options &o, const char *name, int64_t value)
 {
-    PK_API_LOCK;
     if (!name) return PK_E_INVALID;
     if (!strcmp(name, "chunk")) {
         if (value < 64) return PK_E_INVALID;
-        g_opt.chunk = value;
+        o.chunk = value;
     } else if (!strcmp(name, "forest_ilp")) {
         if (value != 1 && value != 2 && value != 4 && value != 8) return PK_E_INVALID;
-        g_opt.forest_ilp = value;
+        o.forest_ilp = value;
     } else if (!strcmp(name, "forest_lds")) {
         if (value < 0) return PK_E_INVALID;
-        g_opt.forest_lds = value;
+        o.forest_lds = value;
     } else if (!strcmp(name, "overlap")) {
-        g_opt.overlap = value != 0;
+        o.overlap = value != 0;
     } else if (!strcmp(name, "sub_chunk")) {
         if (value < 0) return PK_E_INVALID;
-        g_opt.sub_chunk = value;
+        o.sub_chunk = value;
     } else if (!strcmp(name, "forest_warm")) {
         if (value < 0) return PK_E_INVALID;
-        g_opt.forest_warm = value;
+        o.forest_warm = value;
     } else if (!strcmp(name, "extract_clean")) {
-        g_opt.extract_clean = value != 0;
+        o.extract_clean = value != 0;
     } else if (!strcmp(name, "extract_pair")) {
-        g_opt.extract_pair = value != 0;
+        o.extract_pair = value != 0;
     } else if (!strcmp(name, "extract_row16")) {
-        g_opt.extract_row16 = value != 0;
+        o.extract_row16 = value != 0;
     } else if (!strcmp(name, "forest_slots")) {
         if (value < 0 || value == 1 || value > 16) return PK_E_INVALID;
-        g_opt.forest_slots = value;
+        o.forest_slots = value;
     } else if (!strcmp(name, "forest_pipe")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
-        g_opt.forest_pipe = value;
+        o.forest_pipe = value;
     } else if (!strcmp(name, "forest_pipe_slots")) {
         if (value != 0 && (value < 4 || value > 8)) return PK_E_INVALID;
-        g_opt.forest_pipe_slots = value;
+        o.forest_pipe_slots = value;
     } else if (!strcmp(name, "early_exit")) {
-        g_opt.early_exit = value != 0;
+        o.early_exit = value != 0;
     } else if (!strcmp(name, "forest_l2_tile")) {
-        g_opt.forest_l2_tile = value != 0;
+        o.forest_l2_tile = value != 0;
     } else if (!strcmp(name, "forest_q_two")) {
-        g_opt.forest_q_two = value != 0;
+        o.forest_q_two = value != 0;
     } else if (!strcmp(name, "forest_q_help")) {
-        g_opt.forest_q_help = value != 0;
+        o.forest_q_help = value != 0;
     } else if (!strcmp(name, "forest_q_rsv")) {
-        g_opt.forest_q_rsv = value;
+        o.forest_q_rsv = value;
     } else if (!strcmp(name, "forest_dbg")) {
-        g_opt.forest_dbg = value;
+        o.forest_dbg = value;
     } else if (!strcmp(name, "forest_q")) {
-        g_opt.forest_q = value != 0;
+        o.forest_q = value != 0;
     } else if (!strcmp(name, "forest_q_ch")) {
         if (value != 0 && value != 1 && value != 2 && value != 4) return PK_E_INVALID;
-        g_opt.forest_q_ch = value;
+        o.forest_q_ch = value;
     } else if (!strcmp(name, "forest_q_persist")) {
         if (value < -4096 || value > 8) return PK_E_INVALID;
-        g_opt.forest_q_persist = value;
+        o.forest_q_persist = value;
     } else if (!strcmp(name, "forest_q_prio")) {
-        g_opt.forest_q_prio = value != 0;
+        o.forest_q_prio = value != 0;
     } else if (!strcmp(name, "forest_q_early")) {
-        g_opt.forest_q_early = value != 0;
+        o.forest_q_early = value != 0;
     } else if (!strcmp(name, "forest_q_wpt")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
-        g_opt.forest_q_wpt = value;
+        o.forest_q_wpt = value;
     } else if (!strcmp(name, "forest_img")) {
-        g_opt.forest_img = value != 0;
+        o.forest_img = value != 0;
     } else {
         pk_set_error("unknown option '%s'", name);
         return PK_E_INVALID;
@@ -300,38 +302,71 @@ extern "C" int pk_set_option(const char *name, int64_t value)
     return PK_OK;
 }
 
+static int64_t opt_read(const pk_options &o, const char *name)
+{
+    if (!name) return -1;
+    if (!strcmp(name, "chunk")) return o.chunk;
+    if (!strcmp(name, "forest_ilp")) return o.forest_ilp;
+    if (!strcmp(name, "forest_lds")) return o.forest_lds;
+    if (!strcmp(name, "forest_slots")) return o.forest_slots;
+    if (!strcmp(name, "extract_pair")) return o.extract_pair;
+    if (!strcmp(name, "extract_row16")) return o.extract_row16;
+    if (!strcmp(name, "extract_clean")) return o.extract_clean;
+    if (!strcmp(name, "forest_warm")) return o.forest_warm;
+    if (!strcmp(name, "overlap")) return o.overlap;
+    if (!strcmp(name, "sub_chunk")) return o.sub_chunk;
+    if (!strcmp(name, "forest_pipe")) return o.forest_pipe;
+    if (!strcmp(name, "forest_l2_tile")) return o.forest_l2_tile;
+    if (!strcmp(name, "early_exit")) return o.early_exit;
+    if (!strcmp(name, "forest_pipe_slots")) return o.forest_pipe_slots;
+    if (!strcmp(name, "forest_img")) return o.forest_img;
+    if (!strcmp(name, "forest_q")) return o.forest_q;
+    if (!strcmp(name, "forest_q_ch")) return o.forest_q_ch;
+    if (!strcmp(name, "forest_q_wpt")) return o.forest_q_wpt;
+    if (!strcmp(name, "forest_q_persist")) return o.forest_q_persist;
+    if (!strcmp(name, "forest_q_prio")) return o.forest_q_prio;
+    if (!strcmp(name, "forest_q_two")) return o.forest_q_two;
+    if (!strcmp(name, "forest_q_help")) return o.forest_q_help;
+    if (!strcmp(name, "forest_q_rsv")) return o.forest_q_rsv;
+    if (!strcmp(name, "forest_dbg")) return o.forest_dbg;
+    if (!strcmp(name, "forest_q_early")) return o.forest_q_early;
+    return -1;
+}
+
+extern "C" int pk_set_option(const char *name, int64_t value)
+{
+    PK_API_LOCK;
+    return opt_assign(g_opt, name, value);
+}
+
 extern "C" int64_t pk_get_option(const char *name)
 {
     if (!name) return -1;
-    if (!strcmp(name, "chunk")) return g_opt.chunk;
-    if (!strcmp(name, "forest_ilp")) return g_opt.forest_ilp;
-    if (!strcmp(name, "forest_lds")) return g_opt.forest_lds;
-    if (!strcmp(name, "forest_slots")) return g_opt.forest_slots;
-    if (!strcmp(name, "extract_pair")) return g_opt.extract_pair;
-    if (!strcmp(name, "extract_row16")) return g_opt.extract_row16;
-    if (!strcmp(name, "extract_clean")) return g_opt.extract_clean;
-    if (!strcmp(name, "forest_warm")) return g_opt.forest_warm;
     if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
     if (!strcmp(name, "stat_extract_general")) return g_stat_extract_general;
-    if (!strcmp(name, "overlap")) return g_opt.overlap;
-    if (!strcmp(name, "sub_chunk")) return g_opt.sub_chunk;
-    if (!strcmp(name, "forest_pipe")) return g_opt.forest_pipe;
-    if (!strcmp(name, "forest_l2_tile")) return g_opt.forest_l2_tile;
-    if (!strcmp(name, "early_exit")) return g_opt.early_exit;
-    if (!strcmp(name, "forest_pipe_slots")) return g_opt.forest_pipe_slots;
-    if (!strcmp(name, "forest_img")) return g_opt.forest_img;
-    if (!strcmp(name, "forest_q")) return g_opt.forest_q;
-    if (!strcmp(name, "forest_q_ch")) return g_opt.forest_q_ch;
-    if (!strcmp(name, "forest_q_wpt")) return g_opt.forest_q_wpt;
-    if (!strcmp(name, "forest_q_persist")) return g_opt.forest_q_persist;
-    if (!strcmp(name, "forest_q_prio")) return g_opt.forest_q_prio;
-    if (!strcmp(name, "forest_q_two")) return g_opt.forest_q_two;
-    if (!strcmp(name, "forest_q_help")) return g_opt.forest_q_help;
-    if (!strcmp(name, "forest_q_rsv")) return g_opt.forest_q_rsv;
-    if (!strcmp(name, "forest_dbg")) return g_opt.forest_dbg;
-    if (!strcmp(name, "forest_q_early")) return g_opt.forest_q_early;
-    return -1;
+    return opt_read(g_opt, name);
 }
+
+extern "C" int pk_forest_set_option(pk_forest *f, const char *name, int64_t value)
+{
+    PK_API_LOCK;
+    return f ? opt_assign(f->opt, name, value) : PK_E_INVALID;
+}
+extern "C" int64_t pk_forest_get_option(pk_forest *f, const char *name) { return f ? opt_read(f->opt, name) : -1; }
+
+extern "C" int pk_matrix_set_option(pk_matrix *m, const char *name, int64_t value)
+{
+    PK_API_LOCK;
+    return m ? opt_assign(m->opt, name, value) : PK_E_INVALID;
+}
+extern "C" int64_t pk_matrix_get_option(pk_matrix *m, const char *name) { return m ? opt_read(m->opt, name) : -1; }
+
+extern "C" int pk_cands_set_option(pk_cands *c, const char *name, int64_t value)
+{
+    PK_API_LOCK;
+    return c ? opt_assign(c->opt, name, value) : PK_E_INVALID;
+}
+extern "C" int64_t pk_cands_get_option(pk_cands *c, const char *name) { return c ? opt_read(c->opt, name) : -1; }
 
 extern "C" int pk_debug_read(int device, int64_t *out, int64_t n)
 {
@@ -898,6 +933,7 @@ extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, co
     if (!ctx) return nullptr;
     pk_cands *c = new pk_cands();
     memset(c, 0, sizeof(*c));
+    c->opt = g_opt;  // (the memset took the defaults with it)
     c->device = device;
     c->N = N;
     const size_t n1 = (size_t)(N > 0 ? N : 1);
@@ -981,6 +1017,7 @@ static pk_cands *cands_alloc(int device, int64_t N)
 {
     pk_cands *c = new pk_cands();
     memset(c, 0, sizeof(*c));
+    c->opt = g_opt;  // (the memset took the defaults with it)
     c->device = device;
     c->N = N;
     const size_t n1 = (size_t)(N > 0 ? N : 1);
@@ -1156,13 +1193,17 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         pk_set_error("w=%d: feature tile does not fit LDS", w);
         return PK_E_UNSUPPORTED;
     }
-    int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
+    if (cd->opt.chunk < 64) {
+        pk_set_error("candidate list without options (chunk = %lld): internal error", (long long)cd->opt.chunk);
+        return PK_E_INVALID;
+    }
+    int64_t chunk = (cd->opt.chunk + blk - 1) / blk * blk;
     if (chunk > cd->N) chunk = (cd->N + blk - 1) / blk * blk;
     const size_t tile_floats = (size_t)chunk * F;
-    const bool overlap = g_opt.overlap != 0;
+    const bool overlap = cd->opt.overlap != 0;
     int rc = pk_ctx_reserve_tiles(ctx, (overlap ? 2 : 1) * tile_floats * sizeof(float));
     if (rc) return rc;
-    if ((((w == 5 || w == 6) && g_opt.extract_pair) || (w == 11 && g_opt.extract_row16)) && g_opt.extract_clean) {
+    if ((((w == 5 || w == 6) && m->opt.extract_pair) || (w == 11 && m->opt.extract_row16)) && m->opt.extract_clean) {
         rc = pk_matrix_prepare_norm(ctx, m);
         if (rc) return rc;
     }
@@ -1224,7 +1265,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         // rank kernels: the float tiles are an intermediate of this chunk only (extractor ->
         // quantizer); made and consumed piece by piece through the start of the buffer they
         // never have to leave the Infinity Cache
-        int64_t sub = (g_opt.sub_chunk + blk - 1) / blk * blk;
+        int64_t sub = (cd->opt.sub_chunk + blk - 1) / blk * blk;
         const bool pieces = !overlap && sub > 0 && sub < cn && f->plan_kind == 2 && f->q_state == 1 &&
                             blk == (f->q_ch == 1 ? 128 : 128 * PK_Q_FTILE);
         if (pieces) {
@@ -1290,7 +1331,7 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
     }
     // optional exact early termination (option early_exit): only meaningful for thre >= 0
     const double prune_sum =
-        ((g_opt.early_exit || cd->prune) && thre >= 0.0) ? thre * (double)f->T : -INFINITY;
+        ((cd->opt.early_exit || cd->prune) && thre >= 0.0) ? thre * (double)f->T : -INFINITY;
     int rc = run_pipeline(ctx, m, f, cd, w, prune_sum);
     if (rc) return rc;
     rc = pk_launch_compact(ctx, m, cd, thre, batch);
@@ -1390,6 +1431,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         ctx->score_cands = cd;
         ctx->score_cands_cap = N;
     }
+    cd->opt = m->opt;  // (a call without a candidate handle: the matrix handle's pipeline options)
     rc = pk_score_run(m, f, cd, w, thre, batch, n_out);
     if (deferred) {
         cd->h_x = cd->h_y = nullptr;  // borrowed for this call only
@@ -1417,7 +1459,7 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     pk_device_ctx *ctx = pk_ctx(m->device);
     if (!ctx) return PK_E_NODEVICE;
     const int F = (2 * w + 1) * (2 * w + 1);
-    int blk = pk_forest_tile_width(F);
+    int blk = pk_forest_tile_width(F, m->opt);
     if (blk <= 0) blk = 64;
     pk_cands *cd = pk_cands_create(m->device, N, x, y);
     if (!cd) return PK_E_HIP;
@@ -1428,8 +1470,8 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     std::vector<double> h_rows((size_t)chunk * F);
     std::vector<uint8_t> h_status((size_t)chunk);
     rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
-    if (!rc && (((w == 5 || w == 6) && g_opt.extract_pair) || (w == 11 && g_opt.extract_row16)) &&
-        g_opt.extract_clean)
+    if (!rc && (((w == 5 || w == 6) && m->opt.extract_pair) || (w == 11 && m->opt.extract_row16)) &&
+        m->opt.extract_clean)
         rc = pk_matrix_prepare_norm(ctx, m);
     if (!rc) {  // the staging rows live in the context and only ever grow: no allocation per call
         const size_t need = (size_t)chunk * F * sizeof(double);
@@ -1492,7 +1534,7 @@ extern "C" int pk_predict(pk_forest *f, int64_t N, const float *fea32, double *p
         pk_set_error("pk_predict: F=%d does not fit an LDS tile", F);
         return PK_E_UNSUPPORTED;
     }
-    int64_t chunk = (g_opt.chunk + blk - 1) / blk * blk;
+    int64_t chunk = (f->opt.chunk + blk - 1) / blk * blk;
     if (chunk > N) chunk = (N + blk - 1) / blk * blk;
     int rc = pk_ctx_reserve_tiles(ctx, (size_t)chunk * F * sizeof(float));
     if (rc) return rc;

@@ -109,7 +109,7 @@ struct pk_options {
     int64_t forest_img = 1;     // LDS-image forest kernel (fixed-depth walks, absolute LDS addresses)
                                 // when every tree fits; 0 = the grouped preorder kernel
 };
-extern pk_options g_opt;
+extern pk_options g_opt;  // the DEFAULTS of new handles (pk_set_option); no launch path reads it directly
 // launches of the two-lane extractor since load, by kernel (read-only options
 // "stat_extract_clean" / "stat_extract_general": lets tests see which one ran)
 extern int64_t g_stat_extract_clean, g_stat_extract_general;
@@ -159,6 +159,8 @@ struct pk_prof_scope {
 #define PK_KIND_ONE 3u
 
 struct pk_forest {
+    pk_options opt = g_opt;  // this handle's options: the process defaults (pk_set_option) at its creation,
+                             // then whatever pk_forest_set_option changed -- another handle never sees it
     int device;
     int T, F;
     int64_t n_nodes;       // slots in `nodes`
@@ -303,6 +305,8 @@ int pk_forest_stage_flags(pk_forest *f, int region_words);
 // Diagonal-major dense band: cell (r, r+k), dlo <= k <= dhi, lives at
 // band[(k - dlo) * ld + r]; everything else reads 0.
 struct pk_matrix {
+    pk_options opt = g_opt;  // (see pk_forest::opt) extractor options; pipeline options of the calls that
+                             // have no candidate handle (pk_score, pk_extract)
     int device;
     int32_t n, dlo, dhi;
     int64_t ld;            // row pitch in doubles (n rounded up to 64)
@@ -329,6 +333,8 @@ struct pk_csr {
 };
 
 struct pk_cands {
+    pk_options opt = g_opt;  // (see pk_forest::opt) pipeline options of pk_score_run: chunk, overlap, sub_chunk,
+                             // early_exit
     int device;
     int64_t N;
     int32_t *x, *y;        // device, candidate coordinates
@@ -374,7 +380,7 @@ int pk_launch_forest(pk_device_ctx *, pk_forest *, const float *tiles, int blk,
 // or 2 if row i holds a NaN
 int pk_launch_tile_rows(pk_device_ctx *, const float *d_rows, int64_t N, int F, float *tiles,
                         int blk, uint8_t *d_status);
-int pk_forest_tile_width(int F);  // candidates per feature tile for F features
+int pk_forest_tile_width(int F, const pk_options &o);  // candidates per feature tile for F features
 
 int pk_launch_compact(pk_device_ctx *, const pk_matrix *, pk_cands *, double thre,
                       int64_t batch);

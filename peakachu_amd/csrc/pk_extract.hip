@@ -1231,11 +1231,11 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
         hipLaunchKernelGGL((extract_lds_kernel<0, true>), dim3(grid), dim3(64 * GEN_WAVES), lds, st, w,
                            m->band, m->ld, m->dlo, m->dhi, m->n, m->exp_arr, m->exp_len, d_x, d_y, c0,
                            cn, tiles, blk, d_status, fea64_rows);
-    } else if ((w == 5 || w == 6) && g_opt.extract_pair) {
+    } else if ((w == 5 || w == 6) && m->opt.extract_pair) {
         const unsigned grid = (unsigned)((cn + 31) / 32);
         const int F = (2 * w + 1) * (2 * w + 1);
         // the clean kernel addresses the bands and the tile buffer with 32-bit offsets
-        const bool clean = m->norm != nullptr && m->clean && g_opt.extract_clean != 0 &&
+        const bool clean = m->norm != nullptr && m->clean && m->opt.extract_clean != 0 &&
                            ((size_t)((cn + blk - 1) / blk) * blk * F * sizeof(float) < (1ull << 31)) &&
                            (blk % 32 == 0) && m->ld < (1 << 20);
         (clean ? g_stat_extract_clean : g_stat_extract_general)++;
@@ -1281,8 +1281,8 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
         const int F = (2 * w + 1) * (2 * w + 1);
         // w = 11 on a clean matrix: four register-blocked windows per wave (32-bit offsets, as
         // the clean w = 5 / 6 kernel)
-        const bool row16 = w == 11 && g_opt.extract_row16 != 0 && m->norm != nullptr && m->clean &&
-                           g_opt.extract_clean != 0 && m->ld < (1 << 20) && blk % 4 == 0 &&
+        const bool row16 = w == 11 && m->opt.extract_row16 != 0 && m->norm != nullptr && m->clean &&
+                           m->opt.extract_clean != 0 && m->ld < (1 << 20) && blk % 4 == 0 &&
                            ((size_t)((cn + blk - 1) / blk) * blk * F * sizeof(float) < (1ull << 33));
         if (row16) {
             g_stat_extract_clean++;

@@ -631,11 +631,11 @@ int set_max_lds(KernelT k, size_t bytes)
 
 // Candidates per feature tile: as many 64-lane waves as fit F*4 bytes each in
 // the 160 KiB LDS of a CU (keeping 4 KiB spare), at most 256.
-int pk_forest_tile_width(int F)
+int pk_forest_tile_width(int F, const pk_options &o)
 {
     // LDS-streamed trees: 128-candidate tiles, provided a useful tree buffer
     // (>= 32 KiB) is left beside the tile
-    if (g_opt.forest_lds > 0 && (size_t)F * 4 * LDS_C + 8192 + 32768 <= (size_t)160 * 1024)
+    if (o.forest_lds > 0 && (size_t)F * 4 * LDS_C + 8192 + 32768 <= (size_t)160 * 1024)
         return LDS_C;
     int blk = (int)((156 * 1024) / ((size_t)F * 4)) / 64 * 64;
     if (blk > 256) blk = 256;
@@ -666,7 +666,7 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
     do {                                                                                      \
         const size_t val_bytes = (size_t)((SLOTS) + ((PRUNE) ? 1 : 0)) * LDS_C * sizeof(double); \
         size_t room = (size_t)160 * 1024 - fea_bytes - val_bytes - 2 * sizeof(uint2);        \
-        if ((size_t)g_opt.forest_lds * 1024 < room) room = (size_t)g_opt.forest_lds * 1024;   \
+        if ((size_t)f->opt.forest_lds * 1024 < room) room = (size_t)f->opt.forest_lds * 1024;   \
         const size_t pf_cap = (size_t)LDS_C * (SLOTS) * 6 * 16; /* THREADS * PF * 16 B */      \
         if (room > pf_cap) room = pf_cap;                                                     \
         const int tree_words = (int)(room / sizeof(uint2)) & ~1;                              \
@@ -678,8 +678,8 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
         hipLaunchKernelGGL((forest_lds_kernel<SLOTS, PRUNE>), dim3(grid), dim3(LDS_C *(SLOTS)), \
                            lds, ctx->stream, f->nodes, f->root, f->big_roff, f->grp, f->n_grp, \
                            f->T, f->F, tiles, d_status, c0, cn, d_prob, tree_words,           \
-                           (int)g_opt.forest_dbg, ctx->dbg_buf, prune_sum,                    \
-                           g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm);  \
+                           (int)f->opt.forest_dbg, ctx->dbg_buf, prune_sum,                    \
+                           f->opt.forest_warm == 1 ? ctx->cu_count : (int)f->opt.forest_warm);  \
     } while (0)
 #define PK_LAUNCH_LDS(SLOTS)                                                                  \
     do {                                                                                      \
@@ -694,7 +694,7 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
         hipLaunchKernelGGL(forest_pipe_kernel<SS>, dim3(grid), dim3(LDS_C * (SS)), lds,       \
                            ctx->stream, f->nodes, f->root, f->big_roff, f->tree_staged, f->T, \
                            f->F, tiles, d_status, c0, cn, d_prob, region_words,               \
-                           (int)g_opt.forest_dbg, ctx->dbg_buf + 65535);                      \
+                           (int)f->opt.forest_dbg, ctx->dbg_buf + 65535);                      \
     } while (0)
 
 // The barrier-free pipeline needs a private region per slot that holds the
@@ -712,7 +712,7 @@ static int pipe_shape(pk_forest *f, size_t fea_bytes, int *slots, int *region_wo
     if (s > 8) s = 8;
     *slots = s;
     *region_words = rw;
-    return g_opt.forest_pipe >= 2 ? s >= 4 : s >= 8;
+    return f->opt.forest_pipe >= 2 ? s >= 4 : s >= 8;
 }
 
 int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int blk,
@@ -728,14 +728,14 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
     pk_prof_scope prof(ctx, PK_K_FOREST);
     const unsigned grid = (unsigned)((cn + blk - 1) / blk);
     const size_t fea_bytes = (size_t)f->F * blk * sizeof(float);
-    const int ilp = (int)g_opt.forest_ilp;
+    const int ilp = (int)f->opt.forest_ilp;
     int pslots = 0, region_words = 0;
-    if (blk == LDS_C && g_opt.forest_lds > 0 && g_opt.forest_pipe && !(prune_sum > -1e300) &&
+    if (blk == LDS_C && f->opt.forest_lds > 0 && f->opt.forest_pipe && !(prune_sum > -1e300) &&
         pipe_shape(f, fea_bytes, &pslots, &region_words)) {
         int rc = pk_forest_stage_flags(f, region_words - 2);
         if (rc) return rc;
-        if (g_opt.forest_pipe_slots >= 4 && g_opt.forest_pipe_slots < pslots)
-            pslots = (int)g_opt.forest_pipe_slots;
+        if (f->opt.forest_pipe_slots >= 4 && f->opt.forest_pipe_slots < pslots)
+            pslots = (int)f->opt.forest_pipe_slots;
         const size_t lds = fea_bytes + (size_t)PIPE_R * LDS_C * sizeof(double) + 256 +
                            (size_t)pslots * region_words * sizeof(uint2);
         switch (pslots) {
@@ -745,8 +745,8 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         case 7: PK_LAUNCH_PIPE(7); break;
         default: PK_LAUNCH_PIPE(8); break;
         }
-    } else if (blk == LDS_C && g_opt.forest_lds > 0) {
-        int slots = (int)g_opt.forest_slots;
+    } else if (blk == LDS_C && f->opt.forest_lds > 0) {
+        int slots = (int)f->opt.forest_slots;
         if (slots == 0) {
             // auto: as many slots as average trees fit beside the tile (a slot without a tree
             // idles its two waves): 8 at F = 121, 7 at F = 169 (measured 1.5 % better than 8)
@@ -762,7 +762,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         case 7: PK_LAUNCH_LDS(7); break;
         default: PK_LAUNCH_LDS(8); break;
         }
-    } else if (blk < LDS_C && (!g_opt.forest_l2_tile || fea_bytes > (size_t)156 * 1024)) {
+    } else if (blk < LDS_C && (!f->opt.forest_l2_tile || fea_bytes > (size_t)156 * 1024)) {
         // large F (w = 11): no LDS, features from the L2-resident tile
         const unsigned g2 = (unsigned)((cn + 255) / 256);
         switch (ilp) {

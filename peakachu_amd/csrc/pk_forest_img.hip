@@ -254,7 +254,7 @@ static int img_plan(pk_forest *f)
     pk_img_layout bestL;
     int best_slots = 0;
     double best_score = 0.0;
-    const int forced = (int)g_opt.forest_slots;
+    const int forced = (int)f->opt.forest_slots;
     for (int slots = 2; slots <= 8; slots++) {
         if (slots == 3) continue;  // not instantiated
         if (forced && slots != forced) continue;
@@ -297,7 +297,7 @@ static int img_plan(pk_forest *f)
 int pk_forest_plan_blk(pk_forest *f)
 {
     f->plan_kind = 0;
-    if (g_opt.forest_q && g_opt.forest_lds > 0) {
+    if (f->opt.forest_q && f->opt.forest_lds > 0) {
         const int rc = pk_forest_q_plan(f);
         if (rc == PK_OK) {
             f->plan_kind = 2;
@@ -305,13 +305,13 @@ int pk_forest_plan_blk(pk_forest *f)
         }
         if (rc != PK_E_UNSUPPORTED) return 0;  // error already set
     }
-    if (!g_opt.forest_img || g_opt.forest_lds <= 0) return pk_forest_tile_width(f->F);
-    if (f->img_state != 0 && f->img_opt_slots != g_opt.forest_slots) {
+    if (!f->opt.forest_img || f->opt.forest_lds <= 0) return pk_forest_tile_width(f->F, f->opt);
+    if (f->img_state != 0 && f->img_opt_slots != f->opt.forest_slots) {
         img_free(f);
         f->img_state = 0;
     }
     if (f->img_state == 0) {
-        f->img_opt_slots = g_opt.forest_slots;
+        f->img_opt_slots = f->opt.forest_slots;
         const int rc = img_plan(f);
         f->img_state = rc == PK_OK ? 1 : -1;
         if (rc != PK_OK) img_free(f);
@@ -320,7 +320,7 @@ int pk_forest_plan_blk(pk_forest *f)
         f->plan_kind = 1;
         return 64;
     }
-    return pk_forest_tile_width(f->F);
+    return pk_forest_tile_width(f->F, f->opt);
 }
 
 #define IMG_LAUNCH_P(SLOTS, PRUNE)                                                             \
@@ -331,8 +331,8 @@ int pk_forest_plan_blk(pk_forest *f)
                            163840, ctx->stream, reinterpret_cast<const v4u *>(f->img), reinterpret_cast<const int4 *>(f->img_gtab), \
                            f->img_n_grp, f->img_troot, f->img_tdepth, f->T, f->F, L.lenA, L.B0, \
                            tiles, d_status, c0, cn, d_prob, prune_sum,                         \
-                           g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm,    \
-                           (int)g_opt.forest_dbg, ctx->dbg_buf);                               \
+                           f->opt.forest_warm == 1 ? ctx->cu_count : (int)f->opt.forest_warm,    \
+                           (int)f->opt.forest_dbg, ctx->dbg_buf);                               \
     } while (0)
 #define IMG_LAUNCH(SLOTS)                                                                      \
     do {                                                                                       \

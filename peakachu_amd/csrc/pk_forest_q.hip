@@ -1283,7 +1283,7 @@ static int q_plan_build(pk_forest *f)
 {
     const int F = f->F, T = f->T;
     if (F > 1023 || f->h_tree_off.empty()) return PK_E_UNSUPPORTED;
-    int ch = (int)g_opt.forest_q_ch;
+    int ch = (int)f->opt.forest_q_ch;
     // 256 candidates per workgroup while two rank tiles of 256 B per feature fit 64 KiB of
     // offsets, 128 up to 255 features (the narrow word's feature byte), 64 candidates and the
     // wide word beyond (w = 11: 529 features)
@@ -1295,10 +1295,10 @@ static int q_plan_build(pk_forest *f)
     pk_q_layout bestL;
     int best_slots = 0;
     double best_score = 0.0;
-    const int forced = (int)g_opt.forest_slots;
+    const int forced = (int)f->opt.forest_slots;
     // (4 walks per lane: at most 8 trees per group, so that two waves can share a tree and
     // all 16 walk; measured faster than 9 trees on 9 of 16 waves)
-    const int max_slots = (ch == 4 && g_opt.forest_q_wpt != 1) ? 8 : 16;
+    const int max_slots = (ch == 4 && f->opt.forest_q_wpt != 1) ? 8 : 16;
     bool built = false;
     std::vector<int32_t> best_gtab, best_ttab;
     int best_n_grp = 0;
@@ -1339,7 +1339,7 @@ static int q_plan_build(pk_forest *f)
     // tree in position s of any group; each wave stages half a tree from 6 registers
     // (<= 6 KiB per half).  Only taken when it does not cost a tree per group.
     int slot_bytes = 0;
-    if (best_slots && ch == 4 && best_slots <= 8 && g_opt.forest_q_wpt != 1 && g_opt.forest_q_early &&
+    if (best_slots && ch == 4 && best_slots <= 8 && f->opt.forest_q_wpt != 1 && f->opt.forest_q_early &&
         pk_q_max_tree_bytes(best) <= 2 * 6 * 64 * 16) {
         pk_q_layout L2;
         if (pk_q_make_layout(F, best_slots, ch, &L2)) {
@@ -1394,16 +1394,16 @@ static int q_plan_build(pk_forest *f)
 
 int pk_forest_q_plan(pk_forest *f)
 {
-    if (f->q_state != 0 && (f->q_opt_slots != g_opt.forest_slots || f->q_opt_ch != g_opt.forest_q_ch ||
-                            f->q_opt_wpt != g_opt.forest_q_wpt || f->q_opt_early != g_opt.forest_q_early)) {
+    if (f->q_state != 0 && (f->q_opt_slots != f->opt.forest_slots || f->q_opt_ch != f->opt.forest_q_ch ||
+                            f->q_opt_wpt != f->opt.forest_q_wpt || f->q_opt_early != f->opt.forest_q_early)) {
         q_free(f);
         f->q_state = 0;
     }
     if (f->q_state == 0) {
-        f->q_opt_slots = g_opt.forest_slots;
-        f->q_opt_ch = g_opt.forest_q_ch;
-        f->q_opt_wpt = g_opt.forest_q_wpt;
-        f->q_opt_early = g_opt.forest_q_early;
+        f->q_opt_slots = f->opt.forest_slots;
+        f->q_opt_ch = f->opt.forest_q_ch;
+        f->q_opt_wpt = f->opt.forest_q_wpt;
+        f->q_opt_early = f->opt.forest_q_early;
         const int rc = q_plan_build(f);
         f->q_state = rc == PK_OK ? 1 : -1;
         if (rc != PK_OK) q_free(f);
@@ -1423,8 +1423,8 @@ int pk_forest_q_plan(pk_forest *f)
                            L.val_off, L.img_off, slots_at, ctx->q_tiles, d_status, c0,         \
                            cn, d_prob,                                                         \
                            prune_sum,                                                          \
-                           persist ? (int)grid : g_opt.forest_warm == 1 ? ctx->cu_count : (int)g_opt.forest_warm, \
-                           (int)g_opt.forest_dbg | (g_opt.forest_q_prio ? 0 : 32), ctx->dbg_buf);  \
+                           persist ? (int)grid : f->opt.forest_warm == 1 ? ctx->cu_count : (int)f->opt.forest_warm, \
+                           (int)f->opt.forest_dbg | (f->opt.forest_q_prio ? 0 : 32), ctx->dbg_buf);  \
     } while (0)
 #define Q_LAUNCH(CH, WPT, HALF1, EARLY)                                                        \
     do {                                                                                       \
@@ -1503,18 +1503,18 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     unsigned grid = (unsigned)((cn + C - 1) / C);
     // persistent launch: forest_q_persist workgroups per CU, each looping over tiles (a negative
     // value = exactly that many workgroups in all: tests)
-    const unsigned want = g_opt.forest_q_persist > 0 ? (unsigned)(ctx->cu_count * g_opt.forest_q_persist)
-                                                     : (unsigned)(-g_opt.forest_q_persist);
-    const bool persist = g_opt.forest_q_persist != 0 && grid > want;
+    const unsigned want = f->opt.forest_q_persist > 0 ? (unsigned)(ctx->cu_count * f->opt.forest_q_persist)
+                                                     : (unsigned)(-f->opt.forest_q_persist);
+    const bool persist = f->opt.forest_q_persist != 0 && grid > want;
     if (persist) grid = want;
     // two waves per tree when the groups leave half the waves without one
-    const bool wpt2 = L.ch == 4 && f->q_slots <= 8 && g_opt.forest_q_wpt != 1;
+    const bool wpt2 = L.ch == 4 && f->q_slots <= 8 && f->opt.forest_q_wpt != 1;
     const bool early = wpt2 && f->q_slot_bytes > 0;
     q_slot_table slots_at;
     for (int i = 0; i < 16; i++) slots_at.off[i] = L.slot_off[i];
     // rows of 16 KiB of the largest group: forest_qr_kernel loads that many without looking
     const int rows = (f->q_max_group_bytes + 16383) / 16384;
-    if (L.ch == 4 && wpt2 && !early && (g_opt.forest_q_rsv & 1) && !(g_opt.forest_dbg & (8 | 32)) &&
+    if (L.ch == 4 && wpt2 && !early && (f->opt.forest_q_rsv & 1) && !(f->opt.forest_dbg & (8 | 32)) &&
         (L.half1 == 32768 || L.half1 == 49152) && rows <= 5) {
         // the default shape: staging registers outside the compiler's reach, loads from inside the walk
 #define QR_LAUNCH(HALF1, PRUNE, NR)                                                                        \
@@ -1525,7 +1525,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab), \
                            f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
                            L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob, prune_sum,        \
-                           (int)(g_opt.forest_q_rsv >> 1), (int)g_opt.forest_dbg, ctx->dbg_buf);          \
+                           (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg, ctx->dbg_buf);          \
     } while (0)
 #define QR_LAUNCH_NR(HALF1, PRUNE)                                  \
     do {                                                            \
@@ -1553,19 +1553,19 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         else Q_LAUNCH(4, 1, 49152, false);
     } else if (L.ch == 2) {
         Q_LAUNCH(2, 1, 32768, false);
-    } else if (L.ch == 1 && g_opt.forest_q_two && !(prune_sum > -1e300) && cn > 64 && f->F <= 639 &&
+    } else if (L.ch == 1 && f->opt.forest_q_two && !(prune_sum > -1e300) && cn > 64 && f->F <= 639 &&
                f->q_max_group_bytes <= 6 * 16384) {
         // two rank tiles per trip (see forest_q2_kernel); the waves that walk load their share of
         // the next group behind the first walk (option forest_q_help, on)
-        const int late_below = g_opt.forest_q_help ? f->q_slots : 0;
+        const int late_below = f->opt.forest_q_help ? f->q_slots : 0;
         int rc2 = q_set_max_lds(forest_q2_kernel, 163840);
         if (rc2) return rc2;
         unsigned grid2 = (unsigned)((cn + 127) / 128);
-        if (g_opt.forest_q_persist != 0 && grid2 > want) grid2 = want;
+        if (f->opt.forest_q_persist != 0 && grid2 > want) grid2 = want;
         hipLaunchKernelGGL(forest_q2_kernel, dim3(grid2), dim3(Q_THREADS), 163840, ctx->stream,
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab),
                            f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.val_off, L.img_off,
-                           ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)g_opt.forest_dbg, late_below);
+                           ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)f->opt.forest_dbg, late_below);
     } else if (L.ch == 1) {
         Q_LAUNCH(1, 1, 32768, false);
     } else {

@@ -88,24 +88,18 @@ def main():
             opts["forest_q"] = 0
         if F > 255 and rng.random() < 0.4:  # the wide word: one tile or two per trip, walkers loading early or late
             opts[str(rng.choice(["forest_q_two", "forest_q_help"]))] = 0
-        old = {k: L.pk_get_option(k.encode()) for k in opts}
+        L.pk_prof_enable(1); L.pk_prof_reset()
         try:
-            for k, v in opts.items():
-                _lib.set_option(k, v)
-            L.pk_prof_enable(1); L.pk_prof_reset()
-            try:
-                p = _lib.HipForest(ff).predict(X)
-            except _lib.PeakachuHipError as e:
-                if F > 1023 or "unsupported" in str(e).lower() or "does not fit" in str(e).lower():
-                    print("case %3d F=%4d T=%3d nodes<=%4d depth=%2d N=%5d %s: refused (%s)" % (
-                        case, F, T, max_nodes, depth, N, opts, str(e)[:70]))
-                    continue
-                raise
-            used_rank = _lib.prof_get("quant")[1] > 0
+            p = _lib.HipForest(ff, options=opts).predict(X)   # (options are this handle's own)
+        except _lib.PeakachuHipError as e:
             L.pk_prof_enable(0)
-        finally:
-            for k, v in old.items():
-                _lib.set_option(k, v)
+            if F > 1023 or "unsupported" in str(e).lower() or "does not fit" in str(e).lower():
+                print("case %3d F=%4d T=%3d nodes<=%4d depth=%2d N=%5d %s: refused (%s)" % (
+                    case, F, T, max_nodes, depth, N, opts, str(e)[:70]))
+                continue
+            raise
+        used_rank = _lib.prof_get("quant")[1] > 0
+        L.pk_prof_enable(0)
         paths["rank" if used_rank else "other"] += 1
         ok = np.array_equal(p.view(np.uint64), ref.view(np.uint64))
         print("case %3d F=%4d T=%3d nodes<=%4d depth=%2d comb=%d miss=%.1f N=%5d %s: %s %s" % (

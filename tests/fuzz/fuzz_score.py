@@ -93,16 +93,9 @@ def main():
             opts["extract_row16"] = 0
         if rng.random() < 0.15:
             opts["early_exit"] = 1
-        old = {k: L.pk_get_option(k.encode()) for k in opts}
-        try:
-            for k, v in opts.items():
-                _lib.set_option(k, v)
-            hm = hip_matrix(Mf, e, w, upper)
-            hf = _lib.HipForest(flat(fo))
-            ox, oy, op, osig = hm.score(hf, w, thre, x, y, batch=batch)
-        finally:
-            for k, v in old.items():
-                _lib.set_option(k, v)
+        hm = hip_matrix(Mf, e, w, upper, options=opts)   # (options are the handles' own)
+        hf = _lib.HipForest(flat(fo), options=opts)
+        ox, oy, op, osig = hm.score(hf, w, thre, x, y, batch=batch)
         rx, ry, rp, rs = onp.score(Mf, e, w, fo, thre, x, y, batch=batch, threads=8)
         ok = (np.array_equal(ox, rx) and np.array_equal(oy, ry)
               and np.array_equal(op.view(np.uint64), rp.view(np.uint64))

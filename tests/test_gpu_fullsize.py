@@ -30,6 +30,25 @@ def digest(*arrs):
     return h.hexdigest()
 
 
+class handle_options:
+    """`with handle_options(opts, hm, hf):` -- the options that concern each of these (shared)
+    handles, for the block; afterwards the handles are back at the process defaults.  No test
+    touches a process-wide option (round 4: options are per handle)."""
+
+    def __init__(self, opts, *handles):
+        self.opts, self.handles = dict(opts), handles
+
+    def __enter__(self):
+        for h in self.handles:
+            h.set_options(self.opts)
+        return self
+
+    def __exit__(self, *exc):
+        L = _lib.load()
+        for h in self.handles:
+            h.set_options({k: L.pk_get_option(k.encode()) for k in self.opts})
+
+
 def random_forest(F, T, seed, depth=14, p_split=0.8):
     from test_gpu_parity import random_forest_arrays
     return random_forest_arrays(F, T, seed, depth=depth)
@@ -72,11 +91,7 @@ def test_config2_properties(config2):
     assert np.all(op > 0.5) and np.all(st[order_in_input] == 1)
     assert np.array_equal(gio.bits(pr[order_in_input]), gio.bits(op))
     # invariance to chunking and kernel variant
-    old = {k: _lib.load().pk_get_option(k.encode())
-           for k in ("chunk", "forest_slots", "forest_lds", "forest_pipe", "forest_pipe_slots",
-                     "extract_pair", "overlap", "sub_chunk", "forest_img", "forest_q", "forest_q_ch",
-                     "forest_q_persist")}
-    try:
+    if True:
         for opts in (dict(chunk=65536), dict(chunk=1000003), dict(forest_slots=12), dict(forest_q_ch=2),
                      dict(forest_q_ch=2, forest_slots=7), dict(forest_q_persist=0), dict(forest_q_persist=2),
                      dict(forest_q_persist=-7), dict(forest_q_persist=1, chunk=65536),
@@ -87,19 +102,13 @@ def test_config2_properties(config2):
                      dict(forest_q=0, forest_img=0, forest_pipe=2, forest_pipe_slots=4),
                      dict(forest_lds=0), dict(extract_pair=0), dict(overlap=1), dict(overlap=1, chunk=65536),
                      dict(sub_chunk=262144), dict(sub_chunk=100000, chunk=1000000)):
-            for k, v in opts.items():
-                _lib.set_option(k, v)
-            cd2 = _lib.HipCands(x, y)
-            assert cd2.run(c["hm"], c["hf"], w, 0.5) == n1
-            assert digest(*cd2.fetch()) == base, opts
-            st2, pr2 = cd2.fetch_all()
-            assert np.array_equal(st2, st) and np.array_equal(gio.bits(pr2), gio.bits(pr))
-            cd2.close()
-            for k, v in old.items():
-                _lib.set_option(k, v)
-    finally:
-        for k, v in old.items():
-            _lib.set_option(k, v)
+            with handle_options(opts, c["hm"], c["hf"]):
+                cd2 = _lib.HipCands(x, y, options=opts)
+                assert cd2.run(c["hm"], c["hf"], w, 0.5) == n1
+                assert digest(*cd2.fetch()) == base, opts
+                st2, pr2 = cd2.fetch_all()
+                assert np.array_equal(st2, st) and np.array_equal(gio.bits(pr2), gio.bits(pr))
+                cd2.close()
     # invariance to sharding into batch-aligned blocks (the 8-GPU split)
     parts = []
     for lo, hi in dist.block_ranges(x.size, 8, 100000):
@@ -144,14 +153,14 @@ def test_config4_full_parity_trained_forest(hip_lib):
     assert np.array_equal(gio.bits(pr), gio.bits(pr_ref))
 
 
-def _full_parity(w, n, band, upper, fo, thre=0.5, seed=0, min_cands=0):
+def _full_parity(w, n, band, upper, fo, thre=0.5, seed=0, min_cands=0, options=None):
     """The whole candidate list of a bench.py workload on the GPU and through the oracle (all
     host cores): scored pixels, per-candidate status and probability, bit for bit."""
     import bench
     Mf, e, x, y, upper = bench.build_workload(seed, n, band, w, 6, upper)
-    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, n, e, -2 * w + 1, upper + 2 * w - 1)
-    hf = _lib.HipForest(fo)
-    cd = _lib.HipCands(x, y)
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, n, e, -2 * w + 1, upper + 2 * w - 1, options=options)
+    hf = _lib.HipForest(fo, options=options)
+    cd = _lib.HipCands(x, y, options=options)
     n1 = cd.run(hm, hf, w, thre)
     ox, oy, op, osig = cd.fetch()
     st, pr = cd.fetch_all()
@@ -184,12 +193,7 @@ def test_config5_full_parity_at_bench_size(hip_lib):
     # the two-tile kernel with every thread staging its share of a group (no helper waves), and the
     # one-tile kernel (what Chromosome.score's pruned runs use), on the same workload
     for name in ("forest_q_help", "forest_q_two"):
-        old = _lib.load().pk_get_option(name.encode())
-        try:
-            _lib.set_option(name, 0)
-            assert _full_parity(11, 8000, 200, 200, fo, min_cands=1_400_000) == (n_cand, n_pix)
-        finally:
-            _lib.set_option(name, old)
+        assert _full_parity(11, 8000, 200, 200, fo, min_cands=1_400_000, options={name: 0}) == (n_cand, n_pix)
 
 
 @pytest.mark.parametrize("w,T,n,band,upper,stride", [(6, 100, 20000, 300, 300, 7),
@@ -217,14 +221,10 @@ def test_other_configs_sampled_parity(hip_lib, w, T, n, band, upper, stride):
     out = cd.fetch()
     st, pr = cd.fetch_all()
     assert n1 > 0 and st.sum() > x.size // 2
-    old = _lib.load().pk_get_option(b"forest_lds")
-    try:
-        _lib.set_option("forest_lds", 0)
+    with handle_options({"forest_lds": 0}, hm, hf):
         cd2 = _lib.HipCands(x, y)
         assert cd2.run(hm, hf, w, thre) == n1
         assert digest(*cd2.fetch()) == digest(*out)
-    finally:
-        _lib.set_option("forest_lds", old)
     rng = np.random.default_rng(w)
     sel = np.sort(rng.choice(x.size, min(x.size, 3000), replace=False))
     fea, keep = onp.extract(Mf, e, w, x[sel], y[sel])
@@ -263,14 +263,10 @@ def test_early_exit_same_pixels(config2, thre):
     n1 = cd.run(c["hm"], c["hf"], w, thre)
     base = digest(*cd.fetch())
     st, pr = cd.fetch_all()
-    _lib.set_option("early_exit", 1)
-    try:
-        cd2 = _lib.HipCands(x, y)
-        assert cd2.run(c["hm"], c["hf"], w, thre) == n1
-        assert digest(*cd2.fetch()) == base
-        st2, pr2 = cd2.fetch_all()
-    finally:
-        _lib.set_option("early_exit", 0)
+    cd2 = _lib.HipCands(x, y, options={"early_exit": 1})
+    assert cd2.run(c["hm"], c["hf"], w, thre) == n1
+    assert digest(*cd2.fetch()) == base
+    st2, pr2 = cd2.fetch_all()
     assert np.array_equal(st2, st)
     same = gio.bits(pr2) == gio.bits(pr)
     assert np.all(same | (pr2 == 0.0))
@@ -310,16 +306,12 @@ def test_clean_and_general_extractor_agree_on_config2(config2):
     c = config2
     out = {}
     for clean in (1, 0):
-        _lib.set_option("extract_clean", clean)
-        try:
-            M = c["Mf"]
-            hm = _lib.HipMatrix(M.indptr, M.indices, M.data, M.shape[0], c["e"], -2 * c["w"] + 1,
-                                200 + 2 * c["w"] - 1)
-            cd = _lib.HipCands(c["x"], c["y"])
-            cd.run(hm, c["hf"], c["w"], 0.5)
-            out[clean] = digest(*cd.fetch(), *cd.fetch_all())
-        finally:
-            _lib.set_option("extract_clean", 1)
+        M = c["Mf"]
+        hm = _lib.HipMatrix(M.indptr, M.indices, M.data, M.shape[0], c["e"], -2 * c["w"] + 1,
+                            200 + 2 * c["w"] - 1, options={"extract_clean": clean})
+        cd = _lib.HipCands(c["x"], c["y"])
+        cd.run(hm, c["hf"], c["w"], 0.5)
+        out[clean] = digest(*cd.fetch(), *cd.fetch_all())
     assert out[0] == out[1]
 
 
@@ -344,18 +336,15 @@ def test_clean_extractor_bitwise_equals_general_on_balanced_values(hip_lib, conf
     L = _lib.load()
     got = {}
     for clean in (1, 0):
-        _lib.set_option("extract_clean", clean)
         before = L.pk_get_option(b"stat_extract_clean")
-        try:
-            hm = _lib.HipMatrix(B.indptr, B.indices, B.data, B.shape[0], e, -2 * w + 1, 200 + 2 * w - 1)
-            parts = []
-            for s0 in range(0, x.size, 150_000):          # bounded host memory
-                f64, _, keep = hm.extract(w, x[s0:s0 + 150_000], y[s0:s0 + 150_000])
-                parts.append((hashlib.sha256(f64.tobytes()).hexdigest(), keep.size,
-                              hashlib.sha256(keep.tobytes()).hexdigest()))
-            got[clean] = parts
-        finally:
-            _lib.set_option("extract_clean", 1)
+        hm = _lib.HipMatrix(B.indptr, B.indices, B.data, B.shape[0], e, -2 * w + 1, 200 + 2 * w - 1,
+                            options={"extract_clean": clean})
+        parts = []
+        for s0 in range(0, x.size, 150_000):          # bounded host memory
+            f64, _, keep = hm.extract(w, x[s0:s0 + 150_000], y[s0:s0 + 150_000])
+            parts.append((hashlib.sha256(f64.tobytes()).hexdigest(), keep.size,
+                          hashlib.sha256(keep.tobytes()).hexdigest()))
+        got[clean] = parts
         assert (L.pk_get_option(b"stat_extract_clean") > before) == (clean == 1)
     assert got[0] == got[1]
     assert sum(p[1] for p in got[1]) > 300_000

@@ -17,10 +17,11 @@ def flat(fo):
                       fo["thr"], fo["miss_left"], fo["p1"])
 
 
-def hip_matrix(Mf, exp_arr, w, upper):
+def hip_matrix(Mf, exp_arr, w, upper, options=None):
+    """(options: this handle's own -- no test sets a process-wide option any more, round 4)"""
     Mf = utils.canonical_csr(Mf)
     return _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], exp_arr,
-                          -2 * w + 1, upper + 2 * w - 1)
+                          -2 * w + 1, upper + 2 * w - 1, options=options)
 
 
 @pytest.mark.parametrize("pair", [1, 0])
@@ -29,14 +30,10 @@ def hip_matrix(Mf, exp_arr, w, upper):
 def test_extract_golden(hip_lib, name, pair):
     """Both extract kernels for w=5/6 (two lanes per candidate, one lane per
     candidate) and the LDS kernel for w=11."""
-    _lib.set_option("extract_pair", pair)
-    try:
-        _extract_golden(name)
-    finally:
-        _lib.set_option("extract_pair", 1)
+    _extract_golden(name, pair)
 
 
-def _extract_golden(name):
+def _extract_golden(name, pair=1):
     z = gio.load(name)
     L = _lib.load()
     clean0 = L.pk_get_option(b"stat_extract_clean")
@@ -49,12 +46,12 @@ def _extract_golden(name):
     assert gio.digest(Mf) == str(z["Mf_sha"])
     ok = z["x"] <= z["y"]
     x, y = z["x"][ok], z["y"][ok]
-    hm = hip_matrix(Mf, z["exp_arr"], w, upper)
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper, options={"extract_pair": pair})
     f64, f32, keep = hm.extract(w, x, y, want64=True, want32=True)
     assert np.array_equal(np.stack([x[keep], y[keep]], 1), z["clist"])
     assert np.array_equal(gio.bits(f64), gio.bits(z["fea"]))
     assert np.array_equal(f32, z["fea"].astype(np.float32))
-    if int(z["w"]) in (5, 6) and L.pk_get_option(b"extract_pair") and "balanced" in name:
+    if int(z["w"]) in (5, 6) and hm.get_option("extract_pair") and "balanced" in name:
         # balanced (float, ~1e-3) values still qualify for the pre-divided band
         assert L.pk_get_option(b"stat_extract_clean") > clean0
 
@@ -119,23 +116,11 @@ def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img, q):
     codes, 4-byte nodes, 2 or 4 walks per lane) with automatic and forced shapes."""
     z = gio.load("g2_forest_%s.npz" % tag)
     X = gio.load("g2_forest_plain.npz")["X"]
-    old = {k: _lib.load().pk_get_option(k.encode())
-           for k in ("forest_ilp", "forest_lds", "forest_slots", "forest_pipe", "forest_pipe_slots",
-                     "forest_img", "forest_q", "forest_q_ch")}
-    _lib.set_option("forest_img", img)
-    _lib.set_option("forest_q", 1 if q else 0)
-    _lib.set_option("forest_q_ch", q - 1 if q > 1 else 0)
-    _lib.set_option("forest_ilp", ilp)
-    _lib.set_option("forest_lds", lds)
-    _lib.set_option("forest_slots", slots)
-    _lib.set_option("forest_pipe", 2 if pipe else 0)
-    _lib.set_option("forest_pipe_slots", pipe if pipe >= 4 else 0)
-    try:
-        hf = _lib.HipForest(flat(gio.forest(z)))
-        p = hf.predict(X)
-    finally:
-        for k, v in old.items():
-            _lib.set_option(k, v)
+    hf = _lib.HipForest(flat(gio.forest(z)), options={
+        "forest_img": img, "forest_q": 1 if q else 0, "forest_q_ch": q - 1 if q > 1 else 0, "forest_ilp": ilp,
+        "forest_lds": lds, "forest_slots": slots, "forest_pipe": 2 if pipe else 0,
+        "forest_pipe_slots": pipe if pipe >= 4 else 0})
+    p = hf.predict(X)
     assert np.array_equal(gio.bits(p), gio.bits(z["p"]))
 
 
@@ -184,12 +169,7 @@ def test_old_sklearn_pickle_on_device(hip_lib, tag, name, q):
     from peakachu_amd.forest import load_model
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "old_sklearn_rf.npz"))
     ff = load_model(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
-    old = _lib.load().pk_get_option(b"forest_q")
-    _lib.set_option("forest_q", q)
-    try:
-        p = _lib.HipForest(ff).predict(z["X"])
-    finally:
-        _lib.set_option("forest_q", old)
+    p = _lib.HipForest(ff, options={"forest_q": q}).predict(z["X"])
     assert np.array_equal(gio.bits(p), gio.bits(z["p_" + tag]))
 
 
@@ -225,15 +205,7 @@ def test_forest_threshold_edges(hip_lib, name, opts):
     X[10, :] = 0.0
     X[11, :] = 1.0
     ref = onp.predict(fo, X)
-    old = {k: _lib.load().pk_get_option(k.encode()) for k in opts}
-    try:
-        for k, v in opts.items():
-            _lib.set_option(k, v)
-        hf = _lib.HipForest(ff)
-        p = hf.predict(X)
-    finally:
-        for k, v in old.items():
-            _lib.set_option(k, v)
+    p = _lib.HipForest(ff, options=opts).predict(X)
     assert np.array_equal(gio.bits(p), gio.bits(ref))
 
 
@@ -261,16 +233,7 @@ def test_forest_q_modes(hip_lib, name, opts):
     X[300, :] = np.nan
     X[2998, 0] = np.nan
     ref = onp.predict(fo, X)
-    keys = [k for k in opts if k != "early_exit"]
-    old = {k: _lib.load().pk_get_option(k.encode()) for k in keys}
-    try:
-        for k in keys:
-            _lib.set_option(k, opts[k])
-        hf = _lib.HipForest(ff)
-        p = hf.predict(X)
-    finally:
-        for k, v in old.items():
-            _lib.set_option(k, v)
+    p = _lib.HipForest(ff, options={k: v for k, v in opts.items() if k != "early_exit"}).predict(X)
     assert np.array_equal(gio.bits(p), gio.bits(ref))
 
 
@@ -305,19 +268,14 @@ def test_forest_wide_format(hip_lib, F, with_miss, opts):
     X[300, :] = np.nan
     X[1300, F - 1] = np.nan
     ref = onp.predict(fo, X)
-    old = {k: _lib.load().pk_get_option(k.encode()) for k in opts}
+    L = _lib.load()
+    L.pk_prof_enable(1)
+    L.pk_prof_reset()
     try:
-        for k, v in opts.items():
-            _lib.set_option(k, v)
-        L = _lib.load()
-        L.pk_prof_enable(1)
-        L.pk_prof_reset()
-        p = _lib.HipForest(ff).predict(X)
+        p = _lib.HipForest(ff, options=opts).predict(X)
         quant_launches = _lib.prof_get("quant")[1]
-        L.pk_prof_enable(0)
     finally:
-        for k, v in old.items():
-            _lib.set_option(k, v)
+        L.pk_prof_enable(0)
     assert np.array_equal(gio.bits(p), gio.bits(ref))
     # the rank path (its quantizer) ran exactly when the forest fits the wide word
     assert (quant_launches > 0) == (not with_miss and opts.get("forest_q", 1) != 0)
@@ -400,24 +358,16 @@ def test_score_twice_with_other_coordinates(hip_lib, opts):
     Mf = utils.band_filter(M, w, upper)
     x, y = synth.all_band_pixels(Mf, w + 1, upper)
     fo = gio.forest("g2_forest_plain.npz")
-    hm = hip_matrix(Mf, exp_arr, w, upper)
-    hf = _lib.HipForest(flat(fo))
-    L = _lib.load()
-    old = {k: L.pk_get_option(k.encode()) for k in opts}
-    for k, v in opts.items():
-        _lib.set_option(k, v)
-    try:
-        lists = [(x, y), (x[1::3].copy(), y[1::3].copy()), (x[::-1][: x.size // 2].copy(), y[::-1][: x.size // 2].copy()),
-                 (x[5:6].copy(), y[5:6].copy()), (x, y)]
-        for xs, ys in lists:
-            got = hm.score(hf, w, 0.3, xs, ys, batch=1000)
-            ref = onp.score(Mf, exp_arr, w, fo, 0.3, xs, ys, batch=1000, threads=8)
-            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
-            assert np.array_equal(gio.bits(got[2]), gio.bits(ref[2]))
-            assert np.array_equal(gio.bits(got[3]), gio.bits(ref[3]))
-    finally:
-        for k, v in old.items():
-            _lib.set_option(k, v)
+    hm = hip_matrix(Mf, exp_arr, w, upper, options=opts)  # (pk_score has no candidate handle: the matrix's options)
+    hf = _lib.HipForest(flat(fo), options=opts)
+    lists = [(x, y), (x[1::3].copy(), y[1::3].copy()), (x[::-1][: x.size // 2].copy(), y[::-1][: x.size // 2].copy()),
+             (x[5:6].copy(), y[5:6].copy()), (x, y)]
+    for xs, ys in lists:
+        got = hm.score(hf, w, 0.3, xs, ys, batch=1000)
+        ref = onp.score(Mf, exp_arr, w, fo, 0.3, xs, ys, batch=1000, threads=8)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        assert np.array_equal(gio.bits(got[2]), gio.bits(ref[2]))
+        assert np.array_equal(gio.bits(got[3]), gio.bits(ref[3]))
 
 
 def random_forest_arrays(F, T, seed, depth=9):
@@ -497,6 +447,50 @@ def test_score_checks_streamed_coordinates_on_the_device(hip_lib):
         ok = hm.score(hf, w, 0.5, x, y)
         assert all(np.array_equal(gio.bits(a) if a.dtype == np.float64 else a,
                                   gio.bits(b) if b.dtype == np.float64 else b) for a, b in zip(first, ok))
+
+
+def test_options_belong_to_their_handle(hip_lib):
+    """Round 4: every handle carries its own options (rounds 1-3 had one process-wide set, and a
+    knob left set by one caller changed every other caller).  Two matrices and two forests with
+    different options, used alternately in one process, each take their own route -- and give the
+    same bits; a changed process default reaches only handles created afterwards."""
+    L = hip_lib
+    z = gio.load("g3_score_raw.npz")
+    w, upper = int(z["w"]), int(z["upper"])
+    Mf = utils.band_filter(gio.sym_matrix(z, "R"), w, upper)
+    x, y = z["ridx"].astype(np.int32), z["cidx"].astype(np.int32)
+    m_clean = hip_matrix(Mf, z["exp_arr"], w, upper)
+    m_general = hip_matrix(Mf, z["exp_arr"], w, upper, options={"extract_clean": 0})
+    assert (m_clean.get_option("extract_clean"), m_general.get_option("extract_clean")) == (1, 0)
+    feats = []
+    for m, want_clean in ((m_clean, True), (m_general, False), (m_clean, True), (m_general, False)):
+        before = (L.pk_get_option(b"stat_extract_clean"), L.pk_get_option(b"stat_extract_general"))
+        feats.append(m.extract(w, x, y)[0])
+        ran_clean = L.pk_get_option(b"stat_extract_clean") > before[0]
+        ran_general = L.pk_get_option(b"stat_extract_general") > before[1]
+        assert (ran_clean, ran_general) == (want_clean, not want_clean)
+    assert all(np.array_equal(gio.bits(feats[0]), gio.bits(f)) for f in feats[1:])
+    fo = flat(gio.forest(str(z["forest"])))
+    f_rank, f_float = _lib.HipForest(fo), _lib.HipForest(fo, options={"forest_q": 0})
+    X = feats[0].astype(np.float32)
+    probs = []
+    for f, want_rank in ((f_rank, True), (f_float, False), (f_rank, True)):
+        L.pk_prof_enable(1)
+        L.pk_prof_reset()
+        probs.append(f.predict(X))
+        assert (_lib.prof_get("quant")[1] > 0) == want_rank   # the rank quantizer ran only for its handle
+        L.pk_prof_enable(0)
+    assert all(np.array_equal(gio.bits(probs[0]), gio.bits(p)) for p in probs[1:])
+    # the process default: for handles made AFTER the change, and only those
+    old = L.pk_get_option(b"forest_q")
+    try:
+        _lib.set_option("forest_q", 0)
+        assert f_rank.get_option("forest_q") == 1
+        assert _lib.HipForest(fo).get_option("forest_q") == 0
+    finally:
+        _lib.set_option("forest_q", old)
+    assert L.pk_forest_set_option(f_rank.h, b"no_such_option", 1) == _lib.PK_E_INVALID
+    assert L.pk_cands_set_option(None, b"chunk", 4096) == _lib.PK_E_INVALID
 
 
 def test_chromosome_drop_in(hip_lib, tmp_path):
@@ -703,19 +697,10 @@ def test_giant_tree_side_table(hip_lib, lds, pipe, img, q):
     X[5, :] = np.nan
     X[11, rng.integers(0, F, 40)] = np.nan
     ref = onp.predict(fo, X)
-    old = {k: _lib.load().pk_get_option(k.encode())
-           for k in ("forest_lds", "forest_pipe", "forest_img", "forest_q")}
-    _lib.set_option("forest_q", q)      # q=1: the tree exceeds the rank format -> falls back
-    _lib.set_option("forest_lds", lds)
-    _lib.set_option("forest_pipe", pipe)
-    _lib.set_option("forest_img", img)  # img=1: the tree does not fit the LDS -> falls back
-    try:
-        hf = _lib.HipForest(flat(fo))
-        info = hf.info()
-        p = hf.predict(X)
-    finally:
-        for k, v in old.items():
-            _lib.set_option(k, v)
+    # q=1: the tree exceeds the rank format -> falls back; img=1: the tree does not fit the LDS -> falls back
+    hf = _lib.HipForest(flat(fo), options={"forest_q": q, "forest_lds": lds, "forest_pipe": pipe, "forest_img": img})
+    info = hf.info()
+    p = hf.predict(X)
     assert info["n_nodes"] > 30000
     assert np.array_equal(gio.bits(p), gio.bits(ref))
 
@@ -917,13 +902,9 @@ def test_extract_unnormalised_when_exp_arr_too_short(hip_lib, w):
     x, y = x[sel][::3], y[sel][::3]
     Mc = utils.canonical_csr(Mf)
     for pair in (1, 0):
-        _lib.set_option("extract_pair", pair)
-        try:
-            hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e_short, -2 * w + 1,
-                                upper + 2 * w - 1)
-            f64, _, keep = hm.extract(w, x, y)
-        finally:
-            _lib.set_option("extract_pair", 1)
+        hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e_short, -2 * w + 1,
+                            upper + 2 * w - 1, options={"extract_pair": pair})
+        f64, _, keep = hm.extract(w, x, y)
         fea, keep_ref = onp.extract(Mf, e_short, w, x, y)
         assert np.array_equal(keep, keep_ref) and keep.size > 50
         assert np.array_equal(gio.bits(f64), gio.bits(fea))
@@ -971,14 +952,10 @@ def test_clean_extractor_and_its_fallback(hip_lib, w, poison):
     got = {}
     L = _lib.load()
     for clean in (1, 0):
-        _lib.set_option("extract_clean", clean)
         before = (L.pk_get_option(b"stat_extract_clean"), L.pk_get_option(b"stat_extract_general"))
-        try:
-            hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e, -2 * w + 1,
-                                upper + 2 * w - 1)
-            got[clean] = hm.extract(w, x, y)
-        finally:
-            _lib.set_option("extract_clean", 1)
+        hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e, -2 * w + 1,
+                            upper + 2 * w - 1, options={"extract_clean": clean})
+        got[clean] = hm.extract(w, x, y)
         ran_clean = L.pk_get_option(b"stat_extract_clean") > before[0]
         ran_general = L.pk_get_option(b"stat_extract_general") > before[1]
         # the clean kernel runs exactly when it is allowed and the matrix is unpoisoned

@@ -23,8 +23,9 @@ for opts in (sys.argv[1:] or [""]):
     old = {}
     for kv in filter(None, opts.split(",")):
         k, v = kv.split("=")
-        old[k] = L.pk_get_option(k.encode())
-        _lib.set_option(k, int(v))
+        old[k] = L.pk_get_option(k.encode())   # (the process default: what the handles go back to)
+        for h in (hm, hf, cd):                  # options are per handle: each takes what concerns it
+            h.set_options({k: int(v)})
     cd.run(hm, hf, w, 0.5)
     L.pk_prof_enable(1); L.pk_prof_reset()
     steps = 5
@@ -33,5 +34,5 @@ for opts in (sys.argv[1:] or [""]):
     r = {k: _lib.prof_get(k)[0] / steps for k in ("extract", "quant", "forest", "compact")}
     L.pk_prof_enable(0)
     print("%-40s" % opts, " ".join("%s %.3f" % kv for kv in r.items()), " total %.3f ms  -> %.0f M/s" % (sum(r.values()), x.size / sum(r.values()) / 1e3))
-    for k, v in old.items():
-        _lib.set_option(k, v)
+    for h in (hm, hf, cd):
+        h.set_options(old)

@@ -26,9 +26,9 @@ hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -2 * w + 1, 
 hf = _lib.HipForest(fo)
 cd = _lib.HipCands(x, y)
 cd.run(hm, hf, w, 0.5)
-_lib.set_option("forest_dbg", 16 | dbg_extra)
+hf.set_option("forest_dbg", 16 | dbg_extra)   # (in-kernel stamps: builds with -DPK_QR_STAMPS, tools/build_variant.sh)
 cd.run(hm, hf, w, 0.5)
-_lib.set_option("forest_dbg", 0)
+hf.set_option("forest_dbg", 0)
 if (2 * w + 1) ** 2 > 255 and not os.environ.get("PK_STAMP_Q1"):
     # the two-tile kernel of the wide format (forest_q2_kernel): eight stamps per group
     buf = np.zeros(16 * 32 * 8, np.int64)
