@@ -255,18 +255,22 @@ int pk_comm_gatherv_bytes(pk_comm *, const void *send, int64_t nbytes, int64_t *
  * `ch` | 0x100 asks for fixed tree slots (the early-staging mode of the kernel).
  * layout8 (32 ints) = {half-tile bytes, walks per lane | second tile's offset << 8, flag
  * area offset, value area offset, image offset, image capacity, slots, F, total bytes of the
- * fixed tree slots or 0, then 17 slot offsets}; qoff = F+1 offsets into qthr (per feature the
- * sorted distinct float32 thresholds); qlut = [F][4096] lookup cells (thresholds in
- * lower cells | thresholds in the cell << 16), qpar = [F][2] (lower end, cells per unit); pairs = the trees' 8-byte child pairs; gtab = 4 ints per
- * group (first tree, trees, offset and size in 16-byte units); ttab = 4 ints per tree
- * (byte offset inside its group, levels to walk, root word, 0). */
+ * fixed tree slots or 0, then 17 slot offsets, then [26] = R, the ROWS of a rank tile: the F
+ * features plus one virtual feature per further 2 047 distinct thresholds of a feature}; qsrc = per
+ * row the float feature it is quantized from (rows 0..F-1: themselves); qoff = R+1 offsets into
+ * qthr (per row its sorted distinct float32 thresholds); qlut = [R][4096] lookup cells (thresholds
+ * in lower cells | thresholds in the cell << 16), qpar = [R][2] (lower end, cells per unit) -- the
+ * caller's qoff / qlut / qpar / qsrc hold cap_rows rows; pairs = the trees' 8-byte child pairs;
+ * gtab = 4 ints per group (first tree, trees, offset and size in 16-byte units); ttab = 4 ints per
+ * tree (byte offset inside its group, levels to walk | wide word: the tree's split << 16, root word,
+ * 16-byte units). */
 int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, const int32_t *left,
                            const int32_t *right, const int32_t *feat, const double *thr,
                            const uint8_t *miss_left, const double *p1, int slots, int ch,
                            int32_t *layout8, int32_t *qoff, int64_t cap_thr, float *qthr,
                            uint32_t *qlut, float *qpar, int64_t cap_pairs, uint64_t *pairs,
                            int64_t *n_pairs, int64_t cap_groups, int32_t *gtab,
-                           int32_t *n_groups, int32_t *ttab);
+                           int32_t *n_groups, int32_t *ttab, int32_t cap_rows, int32_t *qsrc);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,8 @@ struct pk_forest {
     // rank image (forest_q_kernel): 0 = not tried, 1 = built, -1 = does not apply
     int q_state = 0;
     int q_slots = 0, q_ch = 0, q_n_grp = 0;
+    int q_F = 0;           // rows of a rank tile: F + the virtual features (pk_q_tables)
+    int32_t *q_src = nullptr;  // device [q_F]: the float feature a row is quantized from
     int q_slot_bytes = 0;  // > 0: fixed tree slots, early staging
     int64_t q_opt_slots = -1, q_opt_ch = -1, q_opt_wpt = -1, q_opt_early = -1;
     int q_max_group_bytes = 0;     // the largest tree group of the rank image
@@ -240,6 +242,7 @@ int pk_launch_forest_img(pk_device_ctx *, pk_forest *f, const float *tiles, cons
 
 // ---- rank image (pk_qimage.hip builds it, pk_forest_q.hip quantizes tiles and walks it) ----
 #define PK_Q_CELLS 4096
+#define PK_Q_MAX_RANK 2047  // thresholds per rank-tile row (11-bit rank field); a feature with more is split
 #define PK_Q_FTILE 8   // 128-candidate tiles per float32 tile handed to the quantizer
 struct pk_q_layout {
     int F, slots, ch;   // ch = 64-candidate blocks per workgroup: 2 (128 candidates), 4 (256), or 1 (64
@@ -253,8 +256,11 @@ struct pk_q_layout {
     int slot_off[17];   //      img_off + slot_off[s]; slot_bytes = slot_off[slots] = their total size
 };
 struct pk_q_out {
-    std::vector<float> qthr;      // per feature: sorted distinct float32 thresholds, laid end to end
-    std::vector<int32_t> qoff;    // F+1 offsets into qthr
+    int Fq = 0;                   // rows of the rank tile: the features + the virtual ones (pk_q_tables)
+    std::vector<int32_t> qsrc;    // [Fq] the float feature a row is quantized from
+    std::vector<int32_t> qfirst;  // [F] first virtual row of a feature with more than PK_Q_MAX_RANK thresholds, or -1
+    std::vector<float> qthr;      // per row: sorted distinct float32 thresholds, laid end to end
+    std::vector<int32_t> qoff;    // Fq+1 offsets into qthr
     std::vector<uint32_t> qlut;   // [F][PK_Q_CELLS]: thresholds below the cell | thresholds in it << 16
     std::vector<float> qpar;      // [F][2]: lower end of the cells, cells per unit
     std::vector<uint2> pairs;     // tree images (8-byte child pairs), tree after tree
@@ -278,6 +284,11 @@ void pk_q_fill_lut(pk_q_out *out, int F, const std::vector<int32_t> &qcell);
 #define PK_Q_PAD_BYTES 131072  // readable bytes behind the rank image and behind the rank tiles (forest_qr_kernel)
 inline int pk_q_stage_regs() { return 8; }  // uint4 staging registers per thread (1024) of forest_q_kernel
 bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L);
+int pk_q_tables(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *feat,
+                const double *thr, pk_q_out *out);
+int pk_q_trees(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
+               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1, bool wide,
+               pk_q_out *out);
 int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
                const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
                const pk_q_layout &L, pk_q_out *out);

@@ -95,13 +95,15 @@ __global__ void q_cells_kernel(const float *__restrict__ qthr, const int32_t *__
 }
 
 __global__ __launch_bounds__(256) void quantize_tiles_kernel(
-    const float *__restrict__ tiles, int64_t n_tiles, int F, const float *__restrict__ qthr,
-    const int32_t *__restrict__ qoff, const unsigned *__restrict__ qlut,
+    const float *__restrict__ tiles, int64_t n_tiles, int Fs, int F, const int32_t *__restrict__ qsrc,
+    const float *__restrict__ qthr, const int32_t *__restrict__ qoff, const unsigned *__restrict__ qlut,
     const float *__restrict__ qpar, unsigned short *__restrict__ qtiles, int tile64)
 {
+    // Fs rows in a float tile, F >= Fs rows in a rank tile: row f is made from float feature qsrc[f]
+    // (a feature with more than 2 047 thresholds has virtual features behind the real ones)
     __shared__ float thr[2048];  // n <= 2047 entries + padding
     __shared__ unsigned lut[PK_Q_CELLS];
-    const int f = blockIdx.x;
+    const int f = blockIdx.x, fs = qsrc[f];
     const int o = qoff[f], n = qoff[f + 1] - o;
     for (int i = threadIdx.x; i < 2048; i += 256) thr[i] = i < n ? qthr[o + i] : __builtin_inff();
     for (int i = threadIdx.x; i < PK_Q_CELLS; i += 256) lut[i] = qlut[(size_t)f * PK_Q_CELLS + i];
@@ -118,9 +120,9 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     for (int64_t t = ((int64_t)blockIdx.y * 4 + wave) * 4; t < n_tiles; t += (int64_t)gridDim.y * 16) {
         // float tiles: groups of 8 (1024 candidates per feature row) or, tile64 (wide forests,
         // whose one-window-per-wave extractor stores a feature at a time), single 128-tiles
-        const float *src = tile64 ? tiles + ((size_t)t * F + f) * 128 + lane
-                                  : tiles + ((size_t)(t >> 3) * F + f) * (128 * PK_Q_FTILE) + (size_t)(t & 7) * 128 + lane;
-        const int kstride = tile64 ? F * 128 : 128;  // floats between consecutive tiles of this feature
+        const float *src = tile64 ? tiles + ((size_t)t * Fs + fs) * 128 + lane
+                                  : tiles + ((size_t)(t >> 3) * Fs + fs) * (128 * PK_Q_FTILE) + (size_t)(t & 7) * 128 + lane;
+        const int kstride = tile64 ? Fs * 128 : 128;  // floats between consecutive tiles of this feature
         float x[8];
         unsigned code[8];
 #pragma unroll
@@ -175,7 +177,7 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
     unsigned xv[CH];
     u64 pr[CH];
     // one walk per lane = the 64-candidate tile [F][64] u16 and the wide node word (10-bit
-    // feature, 11-bit pair index, no NaN-goes-left bit: a NaN code is above every rank)
+    // feature, 11-bit pair index; "NaN goes left" = the pair lies at or beyond the tree's split, lk1)
     constexpr bool WIDE = CH == 1;
 #pragma unroll
     for (int c = 0; c < CH; c++) {
@@ -188,7 +190,11 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         bool gl = xv[c] <= (w[c] >> 16);  // rank(x) <= rank(threshold); the bits below cannot flip it
-        if (WITH_NAN && !WIDE) gl = gl | ((xv[c] == 0xFFFFu) & ((w[c] & (1u << 20)) != 0));
+        // NaN goes left where the node says so: bit 20 of the narrow word; the wide word has no bit to
+        // spare: its nodes that send NaN left have their child pairs at or beyond the tree's `split`
+        // (pk_qimage.hip), handed in through lk1 (a one-walk lane has no second code offset)
+        if (WITH_NAN)
+            gl = gl | ((xv[c] == 0xFFFFu) & (WIDE ? ((w[c] >> 10) & 0x7FFu) >= lk1 : (w[c] & (1u << 20)) != 0));
         if (ALL_LEFT) gl = gl | (xv[c] < 0x10000u);  // timing ablation: every lane takes the same path
         w[c] = gl ? (unsigned)pr[c] : (unsigned)(pr[c] >> 32);
     }
@@ -478,7 +484,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
                 const unsigned tbase = (unsigned)(EARLY ? img_off + slots_at.off[min(slot, 15)] : img_off + tt.x);
                 const unsigned root = (unsigned)tt.z;
                 // lanes without a live candidate walk along (their values are not stored)
-#define Q_WALK_POS(X0_, NAN_, POS_) q_walk<NCH, X0_, HALF1, NAN_, false, POS_>(root, tt.y, tbase, lk0, lk1, v)
+#define Q_WALK_POS(X0_, NAN_, POS_) \
+    q_walk<NCH, X0_, HALF1, NAN_, false, POS_>(root, tt.y & 0xFFFF, tbase, lk0, CH == 1 ? (unsigned)tt.y >> 16 : lk1, v)
 #define Q_WALK(X0_, NAN_)                              \
     do {                                               \
         if (dbg & 32) Q_WALK_POS(X0_, NAN_, -1);       \
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
                     if (wave_nan) Q_WALK(HALF1, true);
                     else Q_WALK(HALF1, false);
                 } else {
-                    if (dbg & 8) q_walk<NCH, 0, HALF1, false, true>(root, tt.y, tbase, lk0, lk1, v);  // wrong results
+                    if (dbg & 8) q_walk<NCH, 0, HALF1, false, true>(root, tt.y & 0xFFFF, tbase, lk0, lk1, v);  // wrong results
                     else if (wave_nan) Q_WALK(0, true);
                     else Q_WALK(0, false);
                 }
@@ -1108,8 +1115,11 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         }
         // lane's candidate in either tile; thread tid < 128 owns candidate cbase + tid (ordered sum)
         const int64_t la = cbase + lane, lb = cbase + 64 + lane;
-        const bool act_a = lds_at_zero && la < cn && status[c0 + la] != 0;
-        const bool act_b = lds_at_zero && lb < cn && status[c0 + lb] != 0;
+        const unsigned st_a = la < cn ? status[c0 + la] : 0, st_b = lb < cn ? status[c0 + lb] : 0;
+        const bool act_a = lds_at_zero && st_a != 0;
+        const bool act_b = lds_at_zero && st_b != 0;
+        // (uniform) a wave with a NaN feature among its candidates walks with the NaN rule
+        const bool nan_a = __any(st_a == 2), nan_b = __any(st_b == 2);
         const bool owner = tid < 128;
         const bool valid = owner && cbase + tid < cn;
         const bool active = valid && lds_at_zero && status[c0 + cbase + tid] != 0;
@@ -1180,7 +1190,10 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
                 // walk the tile in LDS; thread tid owns candidate (tile `cur`, lane tid & 63)
                 if (slot < gt) {  // (lanes without a live candidate walk along: their values are not stored)
                     double v[1];
-                    q_walk<1, 0, 32768, false, false, -1>((unsigned)tt.z, tt.y, tbase, lk0, lk0 + 2u, v);
+                    // (tt.y: levels to walk | the tree's split << 16)
+                    if (cur ? nan_b : nan_a)
+                        q_walk<1, 0, 32768, true, false, -1>((unsigned)tt.z, tt.y & 0xFFFF, tbase, lk0, (unsigned)tt.y >> 16, v);
+                    else q_walk<1, 0, 32768, false, false, -1>((unsigned)tt.z, tt.y & 0xFFFF, tbase, lk0, 0u, v);
                     if (cur ? act_b : act_a) *LDS_AT(lds_f64, val_off + (slot * 64 + lane) * 8) = v[0];
                 }
                 Q2_STAMP(half ? 5 : 1);
@@ -1251,11 +1264,11 @@ int q_set_max_lds(KernelT k, size_t bytes)
 
 void q_free(pk_forest *f)
 {
-    void *ptrs[] = {f->q_img, f->q_gtab, f->q_ttab, f->q_off, f->q_thr, f->q_par, f->q_lut};
+    void *ptrs[] = {f->q_img, f->q_gtab, f->q_ttab, f->q_off, f->q_thr, f->q_par, f->q_lut, f->q_src};
     for (void *p : ptrs)
         if (p) hipFree(p);
     f->q_img = nullptr;
-    f->q_gtab = f->q_ttab = f->q_off = nullptr;
+    f->q_gtab = f->q_ttab = f->q_off = f->q_src = nullptr;
     f->q_thr = f->q_par = nullptr;
     f->q_lut = nullptr;
     delete f->q_layout;
@@ -1283,15 +1296,23 @@ static int q_plan_build(pk_forest *f)
 {
     const int F = f->F, T = f->T;
     if (F > 1023 || f->h_tree_off.empty()) return PK_E_UNSUPPORTED;
-    int ch = (int)f->opt.forest_q_ch;
-    // 256 candidates per workgroup while two rank tiles of 256 B per feature fit 64 KiB of
-    // offsets, 128 up to 255 features (the narrow word's feature byte), 64 candidates and the
-    // wide word beyond (w = 11: 529 features)
-    if (ch == 0) ch = F <= 192 ? 4 : F <= 255 ? 2 : 1;
-    if ((ch == 4 && F > 192) || (ch == 2 && F > 255)) return PK_E_UNSUPPORTED;
-    // tables and trees once (they do not depend on the layout), then only the grouping
-    // is tried for every slot count
+    // the rank tables first: they say how many ROWS the rank tile has (Fq = the features + the virtual
+    // features of those with more than 2 047 thresholds, pk_qimage.hip), and the shape follows from that
     pk_q_out best;
+    int rc = pk_q_tables(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_feat.data(), f->h_thr.data(), &best);
+    if (rc) return rc;
+    const int Fq = best.Fq;
+    int ch = (int)f->opt.forest_q_ch;
+    // 256 candidates per workgroup while two rank tiles of 256 B per row fit 64 KiB of
+    // offsets, 128 up to 255 rows (the narrow word's feature byte), 64 candidates and the
+    // wide word beyond (w = 11: 529 features)
+    if (ch == 0) ch = Fq <= 192 ? 4 : Fq <= 255 ? 2 : 1;
+    if ((ch == 4 && Fq > 192) || (ch == 2 && Fq > 255)) return PK_E_UNSUPPORTED;
+    rc = pk_q_trees(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(), f->h_feat.data(),
+                    f->h_thr.data(), f->h_miss.empty() ? nullptr : f->h_miss.data(), f->h_p1.data(), ch == 1, &best);
+    if (rc) return rc;  // the forest does not fit the format at all, or is malformed
+    // tables and trees exist once (they do not depend on the layout); only the grouping is tried
+    // for every slot count
     pk_q_layout bestL;
     int best_slots = 0;
     double best_score = 0.0;
@@ -1299,23 +1320,13 @@ static int q_plan_build(pk_forest *f)
     // (4 walks per lane: at most 8 trees per group, so that two waves can share a tree and
     // all 16 walk; measured faster than 9 trees on 9 of 16 waves)
     const int max_slots = (ch == 4 && f->opt.forest_q_wpt != 1) ? 8 : 16;
-    bool built = false;
     std::vector<int32_t> best_gtab, best_ttab;
     int best_n_grp = 0;
     for (int slots = 2; slots <= max_slots; slots++) {  // slots = trees per group at most
         if (forced && slots != forced) continue;
         pk_q_layout L;
-        if (!pk_q_make_layout(F, slots, ch, &L)) continue;
-        int rc;
-        if (!built) {
-            rc = pk_q_build(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(),
-                            f->h_feat.data(), f->h_thr.data(),
-                            f->h_miss.empty() ? nullptr : f->h_miss.data(), f->h_p1.data(), L, &best);
-            built = rc == PK_OK || (rc == PK_E_UNSUPPORTED && !best.toff.empty());
-            if (!built) return rc;  // the forest does not fit the format at all, or is malformed
-        } else {
-            rc = pk_q_group(&best, L);
-        }
+        if (!pk_q_make_layout(Fq, slots, ch, &L)) continue;
+        rc = pk_q_group(&best, L);
         if (rc == PK_E_UNSUPPORTED) continue;
         if (rc) return rc;
         // a group costs about the same whatever it holds: trees per group is the figure of
@@ -1342,7 +1353,7 @@ static int q_plan_build(pk_forest *f)
     if (best_slots && ch == 4 && best_slots <= 8 && f->opt.forest_q_wpt != 1 && f->opt.forest_q_early &&
         pk_q_max_tree_bytes(best) <= 2 * 6 * 64 * 16) {
         pk_q_layout L2;
-        if (pk_q_make_layout(F, best_slots, ch, &L2)) {
+        if (pk_q_make_layout(Fq, best_slots, ch, &L2)) {
             pk_q_fixed_slots(best, best_slots, &L2);
             if (L2.slot_bytes <= L2.cap && pk_q_group(&best, L2) == PK_OK) {
                 bestL = L2;
@@ -1360,12 +1371,14 @@ static int q_plan_build(pk_forest *f)
     f->q_slots = best_slots;
     f->q_slot_bytes = slot_bytes;
     f->q_ch = ch;
+    f->q_F = Fq;
     f->q_n_grp = best.n_grp;
     f->q_max_group_bytes = 0;
     for (int g = 0; g < best.n_grp; g++) f->q_max_group_bytes = std::max(f->q_max_group_bytes, best.gtab[4 * g + 3] * 16);
     // (+ pad: forest_qr_kernel's staging loads are whole 16-KiB rows, unclamped)
     best.pairs.resize(best.pairs.size() + PK_Q_PAD_BYTES / sizeof(best.pairs[0]), make_uint2(0, 0));
-    int rc = q_upload((void **)&f->q_img, best.pairs);
+    rc = q_upload((void **)&f->q_img, best.pairs);
+    if (!rc) rc = q_upload((void **)&f->q_src, best.qsrc);
     if (!rc) rc = q_upload((void **)&f->q_gtab, best.gtab);
     if (!rc) rc = q_upload((void **)&f->q_ttab, best.ttab);
     if (!rc) rc = q_upload((void **)&f->q_off, best.qoff);
@@ -1379,15 +1392,15 @@ static int q_plan_build(pk_forest *f)
         std::vector<int32_t> cells(best.qthr.size(), 0);
         PK_HIP(hipMalloc((void **)&d_cells, cells.size() * sizeof(int32_t)));
         PK_HIP(hipMemset(d_cells, 0, cells.size() * sizeof(int32_t)));
-        hipLaunchKernelGGL(q_cells_kernel, dim3((unsigned)F), dim3(256), 0, 0, f->q_thr, f->q_off, f->q_par,
-                           F, d_cells);
+        hipLaunchKernelGGL(q_cells_kernel, dim3((unsigned)Fq), dim3(256), 0, 0, f->q_thr, f->q_off, f->q_par,
+                           Fq, d_cells);
         hipError_t e = hipMemcpy(cells.data(), d_cells, cells.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
         hipFree(d_cells);
         if (e != hipSuccess) {
             pk_set_error("forest rank image: reading the lookup cells back failed: %s", hipGetErrorString(e));
             return PK_E_HIP;
         }
-        pk_q_fill_lut(&best, F, cells);
+        pk_q_fill_lut(&best, Fq, cells);
     }
     return q_upload((void **)&f->q_lut, best.qlut);
 }
@@ -1419,7 +1432,7 @@ int pk_forest_q_plan(pk_forest *f)
         hipLaunchKernelGGL((forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>), dim3(grid), dim3(Q_THREADS), \
                            163840, ctx->stream, reinterpret_cast<const v4u *>(f->q_img),       \
                            reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp,              \
-                           reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
+                           reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->q_F, L.dec_off,   \
                            L.val_off, L.img_off, slots_at, ctx->q_tiles, d_status, c0,         \
                            cn, d_prob,                                                         \
                            prune_sum,                                                          \
@@ -1441,7 +1454,7 @@ int pk_forest_q_reserve(pk_device_ctx *ctx, pk_forest *f, int64_t cn)
     }
     const int64_t n_tiles = (cn + 127) / 128;
     // (+ pad: forest_qr_kernel's unclamped 16-KiB register rows read past the last tile)
-    const size_t qbytes = (size_t)n_tiles * f->F * 128 * sizeof(unsigned short) + PK_Q_PAD_BYTES;
+    const size_t qbytes = (size_t)n_tiles * f->q_F * 128 * sizeof(unsigned short) + PK_Q_PAD_BYTES;
     if (qbytes > ctx->q_tiles_bytes) {
         if (ctx->q_tiles) {
             PK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1463,7 +1476,7 @@ int pk_launch_quant_q(pk_device_ctx *ctx, hipStream_t st, pk_forest *f, const fl
 {
     if (cn <= 0) return PK_OK;
     const pk_q_layout &L = *f->q_layout;
-    const int F = f->F;
+    const int F = f->q_F;  // rows of a rank tile
     const int64_t n_tiles = (cn + 127) / 128;
     pk_prof_scope prof(ctx, PK_K_QUANT, st);
     // enough blocks per feature to fill the chip, few enough that the tables are
@@ -1472,7 +1485,7 @@ int pk_launch_quant_q(pk_device_ctx *ctx, hipStream_t st, pk_forest *f, const fl
     if (split > 64) split = 64;
     if (split < 1) split = 1;
     hipLaunchKernelGGL(quantize_tiles_kernel, dim3((unsigned)F, (unsigned)split), dim3(256), 0, st, tiles,
-                       n_tiles, F, f->q_thr, f->q_off, f->q_lut, f->q_par,
+                       n_tiles, f->F, F, f->q_src, f->q_thr, f->q_off, f->q_lut, f->q_par,
                        ctx->q_tiles + (size_t)t0 * F * 128, L.ch == 1 ? 1 : 0);
     PK_HIP(hipGetLastError());
     return PK_OK;
@@ -1523,7 +1536,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         if (rc__) return rc__;                                                                             \
         hipLaunchKernelGGL((forest_qr_kernel<HALF1, PRUNE, NR>), dim3(grid), dim3(Q_THREADS), 163840, ctx->stream, \
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab), \
-                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.dec_off,   \
+                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->q_F, L.dec_off,   \
                            L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob, prune_sum,        \
                            (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg, ctx->dbg_buf);          \
     } while (0)
@@ -1553,7 +1566,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         else Q_LAUNCH(4, 1, 49152, false);
     } else if (L.ch == 2) {
         Q_LAUNCH(2, 1, 32768, false);
-    } else if (L.ch == 1 && f->opt.forest_q_two && !(prune_sum > -1e300) && cn > 64 && f->F <= 639 &&
+    } else if (L.ch == 1 && f->opt.forest_q_two && !(prune_sum > -1e300) && cn > 64 && f->q_F <= 639 &&
                f->q_max_group_bytes <= 6 * 16384) {
         // two rank tiles per trip (see forest_q2_kernel); the waves that walk load their share of
         // the next group behind the first walk (option forest_q_help, on)
@@ -1564,7 +1577,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         if (f->opt.forest_q_persist != 0 && grid2 > want) grid2 = want;
         hipLaunchKernelGGL(forest_q2_kernel, dim3(grid2), dim3(Q_THREADS), 163840, ctx->stream,
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab),
-                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->F, L.val_off, L.img_off,
+                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->q_F, L.val_off, L.img_off,
                            ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)f->opt.forest_dbg, late_below);
     } else if (L.ch == 1) {
         Q_LAUNCH(1, 1, 32768, false);

@@ -16,6 +16,8 @@
 // tiles with the tables built here; exact, not an approximation.
 //
 // Node word (32 bits):  [31:21] rank k   [20] NaN goes left   [19:8] pair   [7:0] feature
+//   (more than 255 features: the WIDE word, [31:21] rank | [20:10] pair | [9:0] feature, where
+//   "NaN goes left" is WHERE THE PAIR LIES: at or beyond the tree's `split` -- see q_emit_tree)
 //   pair = index (8-byte units, relative to the tree's first byte) of the node's
 //   child pair: the left child's word, then the right child's word.
 //   A feature code is r(x) << 5 (NaN: 0xFFFF), so `code <= (word >> 16)` is
@@ -69,13 +71,21 @@ struct q_tree {
 // number of pairs, or -1 (malformed) / -2 (does not fit the pair field).
 // Word formats (rank in bits 31..21 either way, so `code <= word >> 16` decides a split):
 //   narrow (<= 255 features): [20] NaN goes left | [19:8] pair index | [7:0] feature
-//   wide   (<= 1023 features): [20:10] pair index (trees of <= 2047 pairs) | [9:0] feature;
-//          no NaN bit -- a forest with missing_go_to_left nodes does not fit it
+//   wide   (<= 1023 features): [20:10] pair index (trees of <= 2047 pairs) | [9:0] feature.
+//          All 32 bits are taken, and forests fitted by scikit-learn >= 1.3 carry a
+//          missing_go_to_left flag on every node: the flag is WHERE the node's child pair lies --
+//          the pairs of the nodes that send NaN right come first (level by level), then, from pair
+//          index `split` on, those of the nodes that send it left (level by level), then the leaf
+//          blocks; `NaN goes left  <=>  pair index >= split`, a compare that only the walk of a wave
+//          holding NaN codes makes (round 4; rounds 2-3 sent such forests to the float kernels: 44 ms
+//          instead of 11 for the fitted 500-tree forest of configs[4]).  The four pairs of two pure
+//          leaves exist on either side of the split.  *split_out receives it (0 for the narrow word).
 int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> *out, uint32_t *root,
-                int *depth, std::string *err, bool wide)
+                int *depth, std::string *err, bool wide, int *split_out = nullptr)
 {
     const int pair_shift = wide ? 10 : 8;
     const int max_pairs = wide ? 2048 : 4096;
+    const int const_pairs = Q_CONST_PAIRS;
     const int nn = t.nn;
     std::vector<int> order, dep((size_t)nn, 0), stack;
     std::vector<uint8_t> seen((size_t)nn, 0);
@@ -109,20 +119,31 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
     // consecutive pairs lie in different LDS banks (a ds_read_b64 of 32 lanes is
     // conflict-free over 32 consecutive pairs; measured: a third of the kernel time is
     // bank conflicts when pairs are numbered in preorder).
-    int next = Q_CONST_PAIRS;
+    int next = const_pairs;
     std::vector<int> pairi((size_t)nn, -1);
+    int split = 0;  // wide: first pair index of the "NaN goes left" side
     std::vector<int> by_level(order);
     std::stable_sort(by_level.begin(), by_level.end(),
                      [&](int a, int b) { return dep[(size_t)a] < dep[(size_t)b]; });
-    for (int n : by_level) {
-        const bool pl = t.kind(t.left[n]) >= 2, pr = t.kind(t.right[n]) >= 2;
-        if (pl && pr) {
-            const int vl = t.kind(t.left[n]) - 2, vr = t.kind(t.right[n]) - 2;
-            pairi[(size_t)n] = 4 + (vl == 0 && vr == 1 ? 0 : vl == 1 && vr == 0 ? 1 : vl == 0 ? 2 : 3);
-        } else {
-            pairi[(size_t)n] = next++;
+    for (int side = 0; side < (wide ? 2 : 1); side++) {
+        if (side == 1) {
+            split = next;   // the second set of pure/pure pairs opens the "NaN goes left" side
+            next += 4;
+        }
+        for (int n : by_level) {
+            const int want = (wide && t.miss && t.miss[n]) ? 1 : 0;
+            if (wide && want != side) continue;
+            const bool pl = t.kind(t.left[n]) >= 2, pr = t.kind(t.right[n]) >= 2;
+            if (pl && pr) {
+                const int vl = t.kind(t.left[n]) - 2, vr = t.kind(t.right[n]) - 2;
+                const int combo = vl == 0 && vr == 1 ? 0 : vl == 1 && vr == 0 ? 1 : vl == 0 ? 2 : 3;
+                pairi[(size_t)n] = (side ? split : 4) + combo;
+            } else {
+                pairi[(size_t)n] = next++;
+            }
         }
     }
+    if (split_out) *split_out = split;
     std::map<uint64_t, int> vblock;  // stored leaf value bits -> pair index of its block
     std::vector<std::pair<int, double>> blocks;
     auto leaf_block = [&](int leaf) {
@@ -149,8 +170,13 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
     };
     auto word_of = [&](int v) -> uint32_t {
         if (t.left[v] == -1) return leaf_word(lblock[(size_t)v]);
-        const int f = t.feat[v];
+        int f = t.feat[v];
         const float t32 = q_floor32(t.thr[v]);
+        // the part of the feature's threshold list that holds t32: the feature's own row, or one of
+        // its virtual features (their rows follow each other from qfirst[f] on; lists are ascending)
+        for (int part = tab.qfirst[(size_t)f]; part >= 0 && part < tab.Fq && tab.qsrc[(size_t)part] == t.feat[v] &&
+                                               t32 >= tab.qthr[(size_t)tab.qoff[(size_t)part]]; part++)
+            f = part;
         const float *b = tab.qthr.data() + tab.qoff[(size_t)f], *e = tab.qthr.data() + tab.qoff[(size_t)f + 1];
         const int k = (int)(std::lower_bound(b, e, t32) - b);  // t32 is in the table by construction
         uint32_t w = ((uint32_t)k << 21) | ((uint32_t)pairi[(size_t)v] << pair_shift) | (uint32_t)f;
@@ -165,19 +191,23 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
     auto put_block = [&](int p, double v) {
         uint64_t b;
         memcpy(&b, &v, 8);
-        // (wide word: no NaN-goes-left bit keeps a NaN code at the leaf, so both ways lead back to it)
+        // (wide word: a leaf's block index carries no flag, so both ways lead back to the leaf)
         P[p] = make_uint2(leaf_word(p), wide ? leaf_word(p) : 0);
         P[p + 1] = make_uint2((uint32_t)(b & 0xffffffffu), (uint32_t)(b >> 32));
     };
     put_block(0, 0.0);
     put_block(2, 1.0);
-    P[4] = make_uint2(leaf_word(0), leaf_word(2));
-    P[5] = make_uint2(leaf_word(2), leaf_word(0));
-    P[6] = make_uint2(leaf_word(0), leaf_word(0));
-    P[7] = make_uint2(leaf_word(2), leaf_word(2));
+    {
+        const uint2 combos[4] = {make_uint2(leaf_word(0), leaf_word(2)), make_uint2(leaf_word(2), leaf_word(0)),
+                                 make_uint2(leaf_word(0), leaf_word(0)), make_uint2(leaf_word(2), leaf_word(2))};
+        for (int c = 0; c < 4; c++) {
+            P[4 + c] = combos[c];
+            if (wide) P[split + c] = combos[c];
+        }
+    }
     for (auto &bk : blocks) put_block(bk.first, bk.second);
     for (int n : order)
-        if (pairi[(size_t)n] >= Q_CONST_PAIRS)
+        if (pairi[(size_t)n] >= const_pairs && !(wide && pairi[(size_t)n] >= split && pairi[(size_t)n] < split + 4))
             P[pairi[(size_t)n]] = make_uint2(word_of(t.left[n]), word_of(t.right[n]));
     return next;
 }
@@ -265,20 +295,20 @@ void pk_q_fill_lut(pk_q_out *out, int F, const std::vector<int32_t> &qcell)
     }
 }
 
-// Rank tables + tree images + groups for one layout.  PK_E_UNSUPPORTED when the forest
-// does not fit the format (more than 2047 distinct thresholds on a feature, a tree of
-// more than 4096 pairs or larger than the LDS budget).
-int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
-               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
-               const pk_q_layout &L, pk_q_out *out)
+// Rank tables of a forest: per (virtual) feature the sorted distinct float32 thresholds, the lookup
+// cells of the quantizer, and which float feature each row of the rank tile is made from.
+// A feature with more than 2047 distinct thresholds (the rank field has 11 bits; the fitted 500-tree
+// forest of configs[4] has one with 2 284) is split: its first 2 047 thresholds stay with the feature,
+// every further 2 047 become a VIRTUAL feature appended behind the real ones -- one more row of the
+// rank tile, quantized from the same float values against its own part of the list.  A node whose
+// threshold is number k of the feature's list tests virtual feature k / 2047 with rank k % 2047:
+// exact, because the code of part c is clamp(r(x) - 2047 c, 0, 2047) by construction.  (Round 4;
+// rounds 2-3 sent such forests to the float kernels.)
+int pk_q_tables(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *feat,
+                const double *thr, pk_q_out *out)
 {
     *out = pk_q_out();
-    const bool wide = L.ch == 1;  // 64-candidate tiles: the 10-bit feature field
-    if (T <= 0 || F < 1 || F > (wide ? 1023 : 255)) return PK_E_UNSUPPORTED;
-    if (wide && miss)
-        for (int32_t v = tree_off[0]; v < tree_off[T]; v++)
-            if (miss[v] && left[v] != -1) return PK_E_UNSUPPORTED;  // no NaN-goes-left bit in the wide word
-    // rank tables
+    if (T <= 0 || F < 1 || F > 1023) return PK_E_UNSUPPORTED;
     std::vector<std::vector<float>> per((size_t)F);
     for (int t = 0; t < T; t++)
         for (int32_t v = tree_off[t]; v < tree_off[t + 1]; v++)
@@ -290,22 +320,40 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
                 if (!(thr[v] == thr[v])) return PK_E_UNSUPPORTED;  // NaN threshold
                 per[(size_t)feat[v]].push_back(q_floor32(thr[v]));
             }
-    out->qoff.assign((size_t)F + 1, 0);
+    // rows 0 .. F-1: the features' first parts; then the further parts, feature by feature
+    out->qsrc.resize((size_t)F);
+    out->qfirst.assign((size_t)F, -1);
+    std::vector<std::vector<float>> rows((size_t)F);
     for (int f = 0; f < F; f++) {
         auto &p = per[(size_t)f];
         std::sort(p.begin(), p.end());
         p.erase(std::unique(p.begin(), p.end()), p.end());  // -0.0 == 0.0: one entry
-        if (p.size() > 2047) return PK_E_UNSUPPORTED;
-        out->qoff[(size_t)f + 1] = out->qoff[(size_t)f] + (int32_t)p.size();
-        out->qthr.insert(out->qthr.end(), p.begin(), p.end());
+        out->qsrc[(size_t)f] = f;
+        rows[(size_t)f].assign(p.begin(), p.begin() + (ptrdiff_t)std::min<size_t>(p.size(), PK_Q_MAX_RANK));
+    }
+    for (int f = 0; f < F; f++) {
+        const auto &p = per[(size_t)f];
+        for (size_t o = PK_Q_MAX_RANK; o < p.size(); o += PK_Q_MAX_RANK) {
+            if (out->qfirst[(size_t)f] < 0) out->qfirst[(size_t)f] = (int32_t)rows.size();
+            out->qsrc.push_back(f);
+            rows.emplace_back(p.begin() + (ptrdiff_t)o, p.begin() + (ptrdiff_t)std::min(p.size(), o + PK_Q_MAX_RANK));
+        }
+    }
+    const int Fq = (int)rows.size();
+    if (Fq > 1023) return PK_E_UNSUPPORTED;
+    out->Fq = Fq;
+    out->qoff.assign((size_t)Fq + 1, 0);
+    for (int f = 0; f < Fq; f++) {
+        out->qoff[(size_t)f + 1] = out->qoff[(size_t)f] + (int32_t)rows[(size_t)f].size();
+        out->qthr.insert(out->qthr.end(), rows[(size_t)f].begin(), rows[(size_t)f].end());
     }
     out->qthr.push_back(0.f);
     // lookup cells for the quantizer.  cell(x) = pk_q_cell(x) is monotone in x, so every
     // threshold in a lower cell is below x and every threshold in a higher cell is not:
     // r(x) = thresholds in lower cells + those of x's own cell that are below x.
-    out->qpar.assign((size_t)F * 2, 0.f);
+    out->qpar.assign((size_t)Fq * 2, 0.f);
     std::vector<int32_t> qcell(out->qthr.size(), 0);
-    for (int f = 0; f < F; f++) {
+    for (int f = 0; f < Fq; f++) {
         const float *b = out->qthr.data() + out->qoff[(size_t)f];
         const int n = out->qoff[(size_t)f + 1] - out->qoff[(size_t)f];
         float lo = 0.f, inv = 0.f;
@@ -319,10 +367,22 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
         out->qpar[(size_t)f * 2 + 1] = inv;
         for (int i = 0; i < n; i++) qcell[(size_t)out->qoff[(size_t)f] + i] = pk_q_cell(b[i], lo, inv);
     }
-    pk_q_fill_lut(out, F, qcell);
+    pk_q_fill_lut(out, Fq, qcell);
+    return PK_OK;
+}
+
+// The tree images (they depend on the word format, not on the layout): `wide` = the 10-bit feature
+// field of the 64-candidate shape.  PK_E_UNSUPPORTED when a tree does not fit the pair field.
+int pk_q_trees(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
+               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1, bool wide,
+               pk_q_out *out)
+{
+    if (out->Fq > (wide ? 1023 : 255)) return PK_E_UNSUPPORTED;
+    out->pairs.clear();
     // tree images
     out->troot.assign((size_t)T, 0);
     out->tdepth.assign((size_t)T, 0);
+    std::vector<int32_t> tsplit((size_t)T, 0);    // wide word: first pair of the "NaN goes left" side
     std::vector<int32_t> toff((size_t)T + 1, 0);  // pairs
     for (int t = 0; t < T; t++) {
         const int32_t b = tree_off[t];
@@ -334,17 +394,35 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
         }
         std::string err;
         const int np = q_emit_tree(tv, F, *out, &out->pairs, &out->troot[(size_t)t],
-                                   &out->tdepth[(size_t)t], &err, wide);
+                                   &out->tdepth[(size_t)t], &err, wide, &tsplit[(size_t)t]);
         if (np == -1) {
             pk_set_error("forest rank image: tree %d: %s", t, err.c_str());
             return PK_E_INVALID;
         }
         if (np < 0) return PK_E_UNSUPPORTED;
         toff[(size_t)t + 1] = toff[(size_t)t] + np;
+        // (the walk's level count in the low half, the split in the high half of one table word)
+        if (out->tdepth[(size_t)t] > 0xFFFF) return PK_E_UNSUPPORTED;
+        out->tdepth[(size_t)t] |= tsplit[(size_t)t] << 16;
     }
     out->toff = toff;
     out->pairs.push_back(make_uint2(0, 0));  // the clamped staging loads stay inside
     out->pairs.push_back(make_uint2(0, 0));
+    return PK_OK;
+}
+
+// Rank tables + tree images + groups for one layout (made for out->Fq rows: pk_q_tables first when
+// the layout depends on it).  PK_E_UNSUPPORTED when the forest does not fit the format (more than
+// 1023 rank-tile rows, a tree of more pairs than the pair field counts or larger than the LDS budget).
+int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
+               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
+               const pk_q_layout &L, pk_q_out *out)
+{
+    int rc = pk_q_tables(T, F, tree_off, left, feat, thr, out);
+    if (rc) return rc;
+    if (L.F != out->Fq) return PK_E_UNSUPPORTED;  // (the layout was made for another row count)
+    rc = pk_q_trees(T, F, tree_off, left, right, feat, thr, miss, p1, L.ch == 1, out);
+    if (rc) return rc;
     return pk_q_group(out, L);
 }
 
@@ -399,8 +477,10 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
                                       int32_t *layout8 /* 32 entries */, int32_t *qoff, int64_t cap_thr, float *qthr,
                                       uint32_t *qlut, float *qpar, int64_t cap_pairs, uint64_t *pairs,
                                       int64_t *n_pairs, int64_t cap_groups, int32_t *gtab,
-                                      int32_t *n_groups, int32_t *ttab)
+                                      int32_t *n_groups, int32_t *ttab, int32_t cap_rows, int32_t *qsrc)
 {
+    // (qoff / qlut / qpar / qsrc hold cap_rows rows: the rank tile has F rows plus one per further
+    // 2 047 thresholds of a feature; layout8[26] receives the row count)
     if (T <= 0 || !tree_off || !left || !right || !feat || !thr || !p1 || !layout8 || !qoff || !qthr ||
         !qlut || !qpar || !pairs || !n_pairs || !gtab || !n_groups || !ttab) {
         pk_set_error("pk_debug_forest_qimage: bad arguments");
@@ -409,13 +489,19 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
     const bool fixed_slots = (ch & 0x100) != 0;
     ch &= 0xFF;
     pk_q_layout L;
-    if (!pk_q_make_layout(F, slots, ch, &L)) {
-        pk_set_error("pk_debug_forest_qimage: no LDS layout for F=%d, %d slots, %d walks per lane", F,
+    pk_q_out out;
+    int rc = pk_q_tables(T, F, tree_off, left, feat, thr, &out);
+    if (rc == PK_OK && (out.Fq > cap_rows || !qsrc)) {
+        pk_set_error("pk_debug_forest_qimage: %d rank-tile rows, room for %d", out.Fq, (int)cap_rows);
+        return PK_E_NOMEM;
+    }
+    if (rc == PK_OK && !pk_q_make_layout(out.Fq, slots, ch, &L)) {
+        pk_set_error("pk_debug_forest_qimage: no LDS layout for %d rows, %d slots, %d walks per lane", out.Fq,
                      slots, ch);
         return PK_E_UNSUPPORTED;
     }
-    pk_q_out out;
-    int rc = pk_q_build(T, F, tree_off, left, right, feat, thr, miss_left, p1, L, &out);
+    if (rc == PK_OK) rc = pk_q_trees(T, F, tree_off, left, right, feat, thr, miss_left, p1, L.ch == 1, &out);
+    if (rc == PK_OK) rc = pk_q_group(&out, L);
     if (fixed_slots && (rc == PK_OK || (rc == PK_E_UNSUPPORTED && !out.toff.empty()))) {
         pk_q_fixed_slots(out, slots, &L);
         rc = pk_q_group(&out, L);
@@ -432,7 +518,9 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
     int32_t lay[32] = {L.HB, L.ch | (L.half1 << 8), L.dec_off, L.val_off, L.img_off, L.cap, L.slots, L.F,
                        L.slot_bytes};
     for (int i = 0; i < 17; i++) lay[9 + i] = L.slot_off[i];
+    lay[26] = out.Fq;
     memcpy(layout8, lay, sizeof(lay));
+    memcpy(qsrc, out.qsrc.data(), out.qsrc.size() * sizeof(int32_t));
     memcpy(qoff, out.qoff.data(), out.qoff.size() * sizeof(int32_t));
     memcpy(qthr, out.qthr.data(), out.qthr.size() * sizeof(float));
     memcpy(qlut, out.qlut.data(), out.qlut.size() * sizeof(uint32_t));

@@ -32,10 +32,12 @@ def build_qimage(fo, F, slots, ch):
     T = int(len(fo["tree_off"]) - 1)
     nn = int(fo["tree_off"][-1])
     lay = np.zeros(32, np.int32)
-    qoff = np.zeros(F + 1, np.int32)
+    R = F + 64            # rows of a rank tile: F + the virtual features (room for 64 of them)
+    qoff = np.zeros(R + 1, np.int32)
     qthr = np.zeros(nn + 8, np.float32)
-    qlut = np.zeros(F * CELLS, np.uint32)
-    qpar = np.zeros(F * 2, np.float32)
+    qlut = np.zeros(R * CELLS, np.uint32)
+    qpar = np.zeros(R * 2, np.float32)
+    qsrc = np.zeros(R, np.int32)
     cap_pairs = 2 * nn + 64 * T + 64
     pairs = np.zeros(cap_pairs, np.uint64)
     npairs = C.c_int64()
@@ -48,10 +50,12 @@ def build_qimage(fo, F, slots, ch):
         np.ascontiguousarray(fo["feat"], np.int32), np.ascontiguousarray(fo["thr"], np.float64),
         np.ascontiguousarray(fo["miss_left"], np.uint8), np.ascontiguousarray(fo["p1"], np.float64),
         slots, ch, lay, qoff, qthr.size, qthr, qlut, qpar, cap_pairs, pairs, C.byref(npairs),
-        T + 4, gtab, C.byref(ng), ttab)
+        T + 4, gtab, C.byref(ng), ttab, R, qsrc)
     if rc != 0:
         return rc, _lib.last_error()
-    return 0, dict(lay=lay, qoff=qoff, qthr=qthr, qlut=qlut.reshape(F, CELLS), qpar=qpar.reshape(F, 2),
+    Fq = int(lay[26])
+    return 0, dict(lay=lay, Fq=Fq, qsrc=qsrc[:Fq], qoff=qoff[:Fq + 1], qthr=qthr,
+                   qlut=qlut[:Fq * CELLS].reshape(Fq, CELLS), qpar=qpar[:Fq * 2].reshape(Fq, 2),
                    pairs=pairs[:npairs.value], gtab=gtab[:4 * (ng.value + 2)].reshape(-1, 4),
                    n_grp=ng.value, ttab=ttab.reshape(T, 4))
 
@@ -59,15 +63,18 @@ def build_qimage(fo, F, slots, ch):
 def quantize(img, X):
     """q_code of pk_forest_q.hip, per feature column: the lookup cell settles the thresholds
     of lower cells; those of the value's own cell are compared one by one."""
-    N, F = X.shape
+    N = X.shape[0]
+    F = img["Fq"]   # rows of the rank tile: row f is made from float feature qsrc[f]
+    assert np.array_equal(img["qsrc"][:X.shape[1]], np.arange(X.shape[1])) and (img["qsrc"] < X.shape[1]).all()
     codes = np.zeros((N, F), np.uint16)
     steps = 0
     with np.errstate(invalid="ignore", over="ignore"):
         for f in range(F):
             thr = img["qthr"][img["qoff"][f]:img["qoff"][f + 1]]
             n = thr.size
+            assert n <= 2047
             lo, inv = img["qpar"][f]
-            x = X[:, f]
+            x = X[:, img["qsrc"][f]]
             cf = (x - lo) * inv                              # float32 arithmetic, like pk_q_cell
             cf = np.where(np.isnan(cf), np.float32(0), cf)   # fmaxf(NaN, 0) = 0
             cf = np.minimum(np.maximum(cf, np.float32(0)), np.float32(CELLS - 1))
@@ -93,8 +100,9 @@ def walk_qimage(img, codes, T):
     HB, ch_half1, dec_off, val_off, img_off, cap, slots, F, slot_bytes = [int(v) for v in img["lay"][:9]]
     slot_off = [int(v) for v in img["lay"][9:26]]   # slot_bytes > 0: fixed tree slots (early staging)
     ch, half1 = ch_half1 & 0xFF, ch_half1 >> 8
-    # ch = 1: 64-candidate tiles and the WIDE node word -- [20:10] pair index, [9:0] feature, no
-    # NaN-goes-left bit (a NaN code 0xFFFF is above every rank: it always goes right)
+    # ch = 1: 64-candidate tiles and the WIDE node word -- [20:10] pair index, [9:0] feature; "NaN
+    # goes left" = the node's child pair lies at or beyond the tree's split (the high half of the
+    # tree table's depth word); a NaN code 0xFFFF is above every rank: otherwise it goes right
     wide = ch == 1
     fmask, pshift, pmask = (0x3FF, 10, 0x7FF) if wide else (0xFF, 8, 0xFFF)
     assert HB == (F * 128 if wide else F * 256)
@@ -112,6 +120,8 @@ def walk_qimage(img, codes, T):
             lds[img_off // 8: img_off // 8 + 2 * nu] = img["pairs"][2 * off: 2 * (off + nu)]
         for t in range(t0, t0 + nt):
             toff, depth, root, tu = [int(v) for v in img["ttab"][t]]
+            depth, split = depth & 0xFFFF, depth >> 16
+            assert wide or split == 0
             assert toff % 16 == 0 and toff < nu * 16 and toff + tu * 16 <= nu * 16
             tbase = img_off + toff
             if slot_bytes:  # the two waves of the slot stage their halves of the tree
@@ -133,8 +143,8 @@ def walk_qimage(img, codes, T):
                 assert (ca + 8 <= (img_off + slot_off[t - t0 + 1] if slot_bytes else img_off + nu * 16)).all()
                 pr = lds[ca // 8]
                 gl = xv <= (w >> 16)
-                if not wide:
-                    gl = gl | ((xv == 0xFFFF) & ((w >> 20) & 1 != 0))
+                nan_left = (((w >> pshift) & pmask) >= split) if wide else ((w >> 20) & 1 != 0)
+                gl = gl | ((xv == 0xFFFF) & nan_left)
                 w = np.where(gl, pr & np.uint64(0xFFFFFFFF), pr >> np.uint64(32)).astype(np.uint32)
             va = tbase + (((w >> pshift) & pmask).astype(np.int64) + 1) * 8
             acc += lds[va // 8].view(np.float64)  # tree order: sklearn's sequential sum
@@ -225,23 +235,52 @@ def test_rank_image_degenerate_trees():
         assert np.array_equal(gio.bits(p), gio.bits(ref))
 
 
-def test_rank_image_limits():
-    # more than 2047 distinct thresholds on one feature: the rank format does not apply
-    n = 2100
+def _comb(n, F, f_used=0):
+    """One tree, a comb of n interior nodes on feature f_used with n distinct thresholds."""
     left = np.full(2 * n + 1, -1, np.int32)
     right = np.full(2 * n + 1, -1, np.int32)
-    feat = np.zeros(2 * n + 1, np.int32)
+    feat = np.full(2 * n + 1, f_used, np.int32)
     thr = np.zeros(2 * n + 1)
     p1 = np.zeros(2 * n + 1)
-    for i in range(n):          # a comb: node 2i has leaf 2i+1 on the left and node 2i+2 on the right
+    for i in range(n):          # node 2i has leaf 2i+1 on the left and node 2i+2 on the right
         left[2 * i] = 2 * i + 1
         right[2 * i] = 2 * i + 2
         thr[2 * i] = i / n
-        p1[2 * i + 1] = i % 2
-    fo = dict(tree_off=np.array([0, 2 * n + 1], np.int32), left=left, right=right, feat=feat, thr=thr,
-              miss_left=np.zeros(2 * n + 1, np.uint8), p1=p1)
-    rc, msg = build_qimage(fo, 4, 4, 2)
-    assert rc != 0 and "rank format" in msg
+        p1[2 * i + 1] = (i % 7) / 7.0
+    p1[2 * n] = 0.875
+    return dict(tree_off=np.array([0, 2 * n + 1], np.int32), left=left, right=right, feat=feat, thr=thr,
+                miss_left=np.zeros(2 * n + 1, np.uint8), p1=p1)
+
+
+def test_rank_image_limits():
+    # more than 2047 distinct thresholds on one feature (the rank field has 11 bits): rounds 2-3
+    # refused such a forest; round 4 splits the feature -- its thresholds beyond the first 2 047 become
+    # a VIRTUAL feature, one more row of the rank tile quantized from the same values -- and the
+    # walk decides every split like the float compare (the fitted 500-tree forest of configs[4] has
+    # a feature with 2 284 thresholds)
+    n = 2100
+    fo = _comb(n, 4, f_used=2)
+    rc, img = build_qimage(fo, 4, 4, 2)
+    assert rc == 0, img
+    assert img["Fq"] == 5 and list(img["qsrc"]) == [0, 1, 2, 3, 2]
+    assert list(np.diff(img["qoff"])) == [0, 0, 2047, 0, n - 2047]
+    rng = np.random.default_rng(3)
+    X = rng.random((300, 4)).astype(np.float32)
+    t32 = fo["thr"][::2][:n].astype(np.float32)
+    for k in range(200):        # on thresholds of either part and one ulp beside them, around the seam too
+        t = t32[(2040 + k) % n if k < 20 else (k * 37) % n]
+        X[50 + k, 2] = [t, np.nextafter(t, np.float32(-np.inf)), np.nextafter(t, np.float32(np.inf))][k % 3]
+    X[7, 2] = np.nan
+    X[8, :] = np.nan
+    codes, _ = quantize(img, X)
+    assert codes.shape[1] == 5
+    p = walk_qimage(img, codes, 1)
+    assert np.array_equal(gio.bits(p), gio.bits(onp.predict(fo, X)))
+    # what still does not fit: more rows than the feature field counts (narrow 255, wide 1023)
+    rc, msg = build_qimage(_comb(n, 255), 255, 4, 2)
+    assert rc != 0 and "256 rows" in msg
+    rc, msg = build_qimage(_comb(n, 1023), 1023, 2, 1)
+    assert rc != 0
     # malformed forests are errors, not "unsupported"
     bad = dict(tree_off=np.array([0, 3], np.int32), left=np.array([1, 0, -1], np.int32),
                right=np.array([2, 2, -1], np.int32), feat=np.zeros(3, np.int32), thr=np.zeros(3),
@@ -297,9 +336,27 @@ def test_wide_word_forests(F, slots):
     codes, _ = quantize(img, X)
     p = walk_qimage(img, codes, 12)
     assert np.array_equal(gio.bits(p), gio.bits(onp.predict(fo, X)))
-    # the narrow word cannot hold these features; missing_go_to_left does not fit the wide one
+    # the narrow word cannot hold these features
     assert build_qimage(fo, F, 4, 2)[0] != 0
-    fo2 = dict(fo)
-    fo2["miss_left"] = fo["miss_left"].copy()
-    fo2["miss_left"][0] = 1
-    assert build_qimage(fo2, F, slots, 1)[0] != 0
+    # missing_go_to_left nodes (every forest fitted by scikit-learn >= 1.3 has them): the flag is where
+    # the node's child pair lies, below or beyond the tree's split (round 4; rounds 2-3 refused such
+    # forests).  Every third node,
+    # all nodes, and a random half; NaN cells and all-NaN rows take the flagged ways
+    X[5, ::3] = np.nan
+    X[6, 1::2] = np.nan
+    for pattern in ("third", "all", "random"):
+        fo2 = dict(fo)
+        m = np.zeros_like(fo["miss_left"])
+        if pattern == "third":
+            m[::3] = 1
+        elif pattern == "all":
+            m[:] = 1
+        else:
+            m[:] = np.random.default_rng(F).integers(0, 2, m.size)
+        fo2["miss_left"] = m
+        rc, img2 = build_qimage(fo2, F, slots, 1)
+        assert rc == 0, img2
+        codes2, _ = quantize(img2, X)
+        p2 = walk_qimage(img2, codes2, 12)
+        assert np.array_equal(gio.bits(p2), gio.bits(onp.predict(fo2, X))), pattern
+    assert not np.array_equal(gio.bits(p2), gio.bits(p))   # (the flags did change some NaN row's way)

@@ -183,9 +183,21 @@ def test_w6_full_parity_trained_forest(hip_lib):
     assert n_pix > 1000
 
 
+def test_config5_full_parity_fitted_forest(hip_lib):
+    """configs[4] on the forest SURVEY 8d names: RandomForestClassifier(500 trees, max_depth 20) FITTED
+    on buildmatrix features (peakachu/trainUtils.py:50-57; tools/make_forest.py -w 11 -T 500 ->
+    peakachu_amd/data/forest_w11_t500.npz), exactly as bench.py's configs[4] leg runs it: 23 x 23
+    windows, 529 features, all 1.42 M candidates against the oracle."""
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w11_t500.npz"))
+    assert fo.T == 500 and fo.F == 529
+    n_cand, n_pix = _full_parity(11, 8000, 200, 200, fo, min_cands=1_400_000)
+    assert n_pix > 100
+
+
 def test_config5_full_parity_at_bench_size(hip_lib):
-    """configs[4] exactly as bench.py runs it (-w 11 --forest random:500:20 --bins 8000): 23 x 23
-    windows, 529 features, 500 random trees of depth <= 20, all 1.42 M candidates."""
+    """The second stress leg of configs[4] (-w 11 --forest random:500:20 --bins 8000): 500 UNTRAINED
+    random trees of depth <= 20 (rounds 1-3's stand-in; 70 % of the candidates score), all 1.42 M
+    candidates."""
     import bench
     fo = bench.load_forest("random:500:20", 11, 529)
     n_cand, n_pix = _full_parity(11, 8000, 200, 200, fo, min_cands=1_400_000)

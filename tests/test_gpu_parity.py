@@ -247,9 +247,9 @@ def test_forest_wide_format(hip_lib, F, with_miss, opts):
     """More than 255 features (w = 11: 529): the rank kernel on 64-candidate tiles with the wide
     node word (10-bit feature, 11-bit pair index), two tiles per workgroup trip (forest_q2_kernel:
     the second one waits in registers; the groups staged by the waves without a tree when there are
-    enough of them -- forest_slots 3 / 5 / 9 -- else by every thread) or one -- forests without
-    missing_go_to_left nodes;
-    one with such nodes does not fit the word and takes the float kernels.  Rows with exact 0 / 1,
+    enough of them -- forest_slots 3 / 5 / 9 -- else by every thread) or one -- with and without
+    missing_go_to_left nodes (the wide word keeps that flag as the parity of the pair index).
+    Rows with exact 0 / 1,
     values on thresholds, NaN cells and all-NaN rows; bit-exact against the oracle."""
     from test_forest_qimage import _random_forest
     fo = _random_forest(F, 40, 1500, 16, seed=F + (7 if with_miss else 0))
@@ -277,8 +277,9 @@ def test_forest_wide_format(hip_lib, F, with_miss, opts):
     finally:
         L.pk_prof_enable(0)
     assert np.array_equal(gio.bits(p), gio.bits(ref))
-    # the rank path (its quantizer) ran exactly when the forest fits the wide word
-    assert (quant_launches > 0) == (not with_miss and opts.get("forest_q", 1) != 0)
+    # the rank path (its quantizer) ran whenever it was allowed to: missing_go_to_left nodes fit the
+    # wide word since round 4 (the flag is the parity of the node's pair index)
+    assert (quant_launches > 0) == (opts.get("forest_q", 1) != 0)
 
 
 def _g3_matrix(z):
