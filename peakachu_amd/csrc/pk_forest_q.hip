@@ -263,6 +263,34 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
         v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index<CH == 1>(w[c]) + 1) << 3));
 }
 
+// One chain per lane (the 64-candidate shape), no priorities: sixteen levels straight, then blocks
+// of four (a walk that has reached its leaf stays there, so up to three surplus levels change
+// nothing) -- every loop test is an instruction in a stream whose length bounds the walk
+// (forest_qr_kernel's finding, round 4).  `split`: see q_level (the wide word's NaN rule).
+template <bool WITH_NAN>
+__device__ __forceinline__ double q_walk_one(unsigned root, int depth, unsigned tbase, unsigned lk0, unsigned split)
+{
+    unsigned w[1] = {root};
+#define Q1_FOUR()                                                  \
+    do {                                                           \
+        q_level<1, 0, 32768, WITH_NAN, false>(w, tbase, lk0, split); \
+        q_level<1, 0, 32768, WITH_NAN, false>(w, tbase, lk0, split); \
+        q_level<1, 0, 32768, WITH_NAN, false>(w, tbase, lk0, split); \
+        q_level<1, 0, 32768, WITH_NAN, false>(w, tbase, lk0, split); \
+    } while (0)
+    int n4 = (depth + 3) >> 2;
+    if (__builtin_expect(n4 >= 4, 1)) {
+        Q1_FOUR();
+        Q1_FOUR();
+        Q1_FOUR();
+        Q1_FOUR();
+        n4 -= 4;
+    }
+    for (; n4 > 0; n4--) Q1_FOUR();
+#undef Q1_FOUR
+    return *LDS_AT(const lds_f64, tbase + ((q_pair_index<true>(w[0]) + 1) << 3));
+}
+
 #define Q_PF16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 #define Q_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u};
 // (register q is only moved when the piece reaches it: a wave-uniform test).  The piece
@@ -1158,11 +1186,15 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         __syncthreads();  // tile A and the first group are in LDS
         double acc = 0.0;
         int cur = 0;  // (uniform) the tile that sits in LDS: 0 = A, 1 = B
+#ifdef PK_QR_STAMPS
 #define Q2_STAMP(k_)                                                                    \
     do {                                                                                \
         if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && g < 32)             \
             stamps[((tid >> 6) * 32 + g) * 8 + (k_)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define Q2_STAMP(k_) do {} while (0)   // (every test of a debug flag is an instruction in the wave's stream)
+#endif
         for (int g = 0; g < n_grp; g++) {
             const int gt = g_cur.y;
             Q2_STAMP(0);
@@ -1189,12 +1221,11 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
             for (int half = 0; half < 2; half++) {
                 // walk the tile in LDS; thread tid owns candidate (tile `cur`, lane tid & 63)
                 if (slot < gt) {  // (lanes without a live candidate walk along: their values are not stored)
-                    double v[1];
                     // (tt.y: levels to walk | the tree's split << 16)
-                    if (cur ? nan_b : nan_a)
-                        q_walk<1, 0, 32768, true, false, -1>((unsigned)tt.z, tt.y & 0xFFFF, tbase, lk0, (unsigned)tt.y >> 16, v);
-                    else q_walk<1, 0, 32768, false, false, -1>((unsigned)tt.z, tt.y & 0xFFFF, tbase, lk0, 0u, v);
-                    if (cur ? act_b : act_a) *LDS_AT(lds_f64, val_off + (slot * 64 + lane) * 8) = v[0];
+                    const double v0 = __builtin_expect(cur ? nan_b : nan_a, 0)
+                                          ? q_walk_one<true>((unsigned)tt.z, tt.y & 0xFFFF, tbase, lk0, (unsigned)tt.y >> 16)
+                                          : q_walk_one<false>((unsigned)tt.z, tt.y & 0xFFFF, tbase, lk0, 0u);
+                    if (cur ? act_b : act_a) *LDS_AT(lds_f64, val_off + (slot * 64 + lane) * 8) = v0;
                 }
                 Q2_STAMP(half ? 5 : 1);
                 __syncthreads();  // every walk of this tile is done, every value parked

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """GPU-box helper: A/B of library builds (tools/ab/*.so, tools/build_variant.sh) on ONE box through
-the library's own HIP-event timers, config 2 (PK_W=6: the w = 6 map).  The workload is built once
+the library's own HIP-event timers, config 2 (PK_W=6: the w = 6 map; PK_W=11 PK_FOREST=<file or
+random:500:20>: configs[4]; PK_BINS / PK_BAND: another map).  The workload is built once
 and handed to one child process per build and repetition (PEAKACHU_HIP_LIB selects the build);
 every child also prints the number of scored pixels and a checksum of all probabilities, so a
 variant that changes a result shows.
@@ -16,7 +17,8 @@ def child(path, steps, opts):
     from peakachu_amd.forest import FlatForest
     d = np.load(path)
     w = int(d["w"])
-    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w%d_t100.npz" % w))
+    import bench
+    fo = bench.load_forest(os.environ.get("PK_FOREST") or None, w, (2 * w + 1) ** 2)   # (default: forest_w<w>_t100)
     L = _lib.require_device()
     for kv in filter(None, opts.split(",")):
         k, v = kv.split("=")
@@ -50,8 +52,8 @@ if __name__ == "__main__":
         a = a[2:]
     import bench
     w = int(os.environ.get("PK_W", "5"))
-    band = 200 if w == 5 else 300
-    Mf, e, x, y, upper = bench.build_workload(0, 30000, band, w, 6, band)
+    band = int(os.environ.get("PK_BAND", 300 if w == 6 else 200))
+    Mf, e, x, y, upper = bench.build_workload(0, int(os.environ.get("PK_BINS", 8000 if w == 11 else 30000)), band, w, 6, band)
     path = os.path.join(tempfile.gettempdir(), "pk_abk_w%d.npz" % w)
     np.savez(path, indptr=Mf.indptr, indices=Mf.indices, data=Mf.data, n=Mf.shape[0], e=e, x=x, y=y, upper=upper, w=w)
     for rep in range(reps):
