@@ -179,15 +179,28 @@ class CoolFile:
             M = Us.T.tocsr() + U
             row = np.repeat(np.arange(n, dtype=np.int32), np.diff(M.indptr))
             out = (row, M.indices, M.data, M.indptr)
+        # Is the result canonical (rows in order, columns strictly ascending inside a row)?  It is for
+        # every conforming file (pixels sorted by bin1, bin2, no duplicates); a file that is not gets no
+        # row pointer attached, and utils.tocsr then sorts and sums like the reference's conversion.
+        if not self._is_canonical(out[0], out[1]):
+            out = (out[0], out[1], out[2], None)
         # the matrices handed out share these arrays (a chromosome's two fetches, balanced and raw,
         # would otherwise copy 4 x 56 MB for 25 000 bins): nobody may write into them
         for a in out:
-            a.flags.writeable = False
+            if a is not None:
+                a.flags.writeable = False
         with self._pixel_lock:
             self.pixel_reads += 1
             self._pixel_cache[chrom] = out
             self._evict()
         return out
+
+    @staticmethod
+    def _is_canonical(row, col):
+        """Rows in order, columns strictly ascending inside a row (no duplicates)."""
+        if col.size < 2:
+            return True
+        return bool(np.all(row[1:] >= row[:-1])) and bool(np.all((col[1:] > col[:-1]) | (row[1:] != row[:-1])))
 
     @staticmethod
     def _mirror_by_scatter(i, j, v, n):
@@ -259,7 +272,9 @@ def sparse_coo(data, row, col, n, indptr=None):
     reference's next step, peakachu/utils.py:10-15 -- has nothing to count or sort."""
     M = sparse.coo_matrix((data, (row, col)), shape=(n, n))
     if indptr is not None:
-        M._pk_csr_parts = (indptr, M.col, M.data)  # (the matrix's own arrays: tocsr checks identity)
+        # (the matrix's own arrays and shape: utils.tocsr checks their identity before it trusts the
+        # row pointer; CoolFile._mirrored has checked that the entries are in canonical order)
+        M._pk_csr_parts = (indptr, M.col, M.data, M.row, M.shape)
     return M
 
 

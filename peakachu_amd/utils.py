@@ -13,11 +13,17 @@ from scipy import sparse, stats
 
 def tocsr(X):
     """peakachu/utils.py:10-15.  A matrix from this package's own `.cool` reader arrives in
-    canonical order with its row pointer attached (cool.sparse_coo): the CSR is then assembled
-    from the parts, as long as nobody has touched the COO arrays since."""
+    canonical order with its row pointer attached (cool.sparse_coo, which has CHECKED that order):
+    the CSR is then assembled from the parts -- as long as the COO is still the object the reader
+    made (same row / col / data arrays, same shape).  The CSR's `indices` ARE the reader's cached,
+    read-only column array (a chromosome's balanced and raw matrices share it): an in-place
+    structural change of the result raises "read-only" instead of reaching the other matrix; the
+    scoring path never makes one (the reference's CSR is a private copy)."""
     parts = getattr(X, "_pk_csr_parts", None)
-    if parts is not None and parts[1] is X.col and parts[2] is X.data:
-        indptr, col, data = parts
+    if (parts is not None and len(parts) == 5 and parts[1] is X.col and parts[2] is X.data
+            and parts[3] is X.row and tuple(parts[4]) == tuple(X.shape)
+            and parts[0].size == X.shape[0] + 1 and int(parts[0][-1]) == X.col.size):
+        indptr, col, data = parts[:3]
         out = sparse.csr_matrix((data.astype(float, copy=False), col, indptr), shape=X.shape)
         out.has_sorted_indices = True
         out.has_canonical_format = True

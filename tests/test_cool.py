@@ -167,6 +167,33 @@ def test_mirror_by_scatter_equals_the_transposed_sum():
     assert np.array_equal(indptr, np.searchsorted(R[o], np.arange(n + 1)))
 
 
+def test_row_pointer_is_only_trusted_for_canonical_untouched_matrices():
+    """utils.tocsr assembles the CSR from the reader's row pointer only while the COO is the object
+    the reader made and its entries are in canonical order; anything else takes the reference's
+    conversion (peakachu/utils.py:10-15), which sorts and sums duplicates."""
+    from peakachu_amd import utils
+    assert cool.CoolFile._is_canonical(np.array([0, 0, 1, 2, 2]), np.array([1, 4, 0, 2, 3]))
+    assert not cool.CoolFile._is_canonical(np.array([0, 0, 1]), np.array([4, 1, 0]))      # columns out of order
+    assert not cool.CoolFile._is_canonical(np.array([0, 0, 1]), np.array([2, 2, 0]))      # a duplicate
+    assert not cool.CoolFile._is_canonical(np.array([1, 0, 2]), np.array([0, 1, 2]))      # rows out of order
+    row = np.array([0, 0, 1, 2], np.int32); col = np.array([0, 2, 1, 2], np.int32)
+    data = np.array([1.0, 2.0, 3.0, 4.0]); indptr = np.array([0, 2, 3, 4], np.int32)
+    X = cool.sparse_coo(data, row, col, 3, indptr)
+    A = utils.tocsr(X)
+    assert A.indices is X.col or np.shares_memory(A.indices, X.col)       # the fast path
+    want = sparse.csr_matrix((data, (row, col)), shape=(3, 3)).toarray()
+    assert np.array_equal(A.toarray(), want)
+    # the same object with its row array replaced (or another shape): the parts no longer describe it
+    Y = cool.sparse_coo(data, row, col, 3, indptr)
+    Y.row = np.array([2, 0, 1, 0], np.int32)
+    B = utils.tocsr(Y)
+    assert not np.shares_memory(B.indices, Y.col)
+    assert np.array_equal(B.toarray(), sparse.csr_matrix((data, (Y.row, col)), shape=(3, 3)).toarray())
+    Z = cool.sparse_coo(data, row, col, 3, indptr)
+    Z._shape = (4, 4)
+    assert utils.tocsr(Z).shape == (4, 4) and not np.shares_memory(utils.tocsr(Z).indices, Z.col)
+
+
 def test_chromosomes_read_on_two_threads_and_shared_arrays():
     """score_genome reads the next two chromosomes on background threads (positional reads, a
     locked pixel cache): what they deliver equals what one thread reads one after the other.
