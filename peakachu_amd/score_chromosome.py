@@ -17,8 +17,8 @@ def main(args):
     correct = False if args.clr_weight_name.lower() == 'raw' else args.clr_weight_name
     width = int((np.sqrt(model.feature_importances_.size) - 1) / 2)
     Lib = io.open_map(args.path)
-    ccname = args.chrom
-    cikada = 'chr' + ccname.lstrip('chr')  # always "chr"-prefixed (score_chromosome.py:37)
-    X = build_chromosome(Lib, ccname, cikada, model, correct, args, width, getattr(args, "device", 0))
+    key = args.chrom
+    label = 'chr' + key.lstrip('chr')  # the output label is always "chr"-prefixed (score_chromosome.py:37)
+    X = build_chromosome(Lib, key, label, model, correct, args, width, getattr(args, "device", 0))
     result, R = X.score(thre=args.minimum_prob)
     X.writeBed(args.output, result, R)
