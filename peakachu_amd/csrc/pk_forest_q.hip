@@ -680,18 +680,24 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
                  "v"(voff), "s"(ptr)                                                        \
                  : "scc")
 // issue slot S = row S of the group (rows >= NR do not exist)
+#ifdef PK_QR_VOFFS
+// (variant: the row's offset added to the lane offset in a VALU instruction instead of two scalar ones)
+#define QR_LD_ROW(R, k) asm volatile("global_load_dwordx4 " R ", %0, %1" ::"v"(voff + (k) * 16384u), "s"(gb))
+#else
+#define QR_LD_ROW(R, k) QR_LD_U(R, gb + (k) * 16384)
+#endif
 template <int S, int NR>
 __device__ __forceinline__ void qr_issue_slot(const char *gb, unsigned voff)
 {
     if constexpr (S < NR) {
-        if constexpr (S == 0) QR_LD_U("v[96:99]", gb);
-        if constexpr (S == 1) QR_LD_U("v[100:103]", gb + 16384);
-        if constexpr (S == 2) QR_LD_U("v[104:107]", gb + 2 * 16384);
-        if constexpr (S == 3) QR_LD_U("v[108:111]", gb + 3 * 16384);
-        if constexpr (S == 4) QR_LD_U("v[112:115]", gb + 4 * 16384);
-        if constexpr (S == 5) QR_LD_U("v[116:119]", gb + 5 * 16384);
-        if constexpr (S == 6) QR_LD_U("v[120:123]", gb + 6 * 16384);
-        if constexpr (S == 7) QR_LD_U("v[124:127]", gb + 7 * 16384);
+        if constexpr (S == 0) QR_LD_ROW("v[96:99]", 0);
+        if constexpr (S == 1) QR_LD_ROW("v[100:103]", 1);
+        if constexpr (S == 2) QR_LD_ROW("v[104:107]", 2);
+        if constexpr (S == 3) QR_LD_ROW("v[108:111]", 3);
+        if constexpr (S == 4) QR_LD_ROW("v[112:115]", 4);
+        if constexpr (S == 5) QR_LD_ROW("v[116:119]", 5);
+        if constexpr (S == 6) QR_LD_ROW("v[120:123]", 6);
+        if constexpr (S == 7) QR_LD_ROW("v[124:127]", 7);
     }
 }
 template <int LO, int HI, int NR>
@@ -720,14 +726,14 @@ __device__ __forceinline__ void qr_issue_tile(unsigned tmask, const char *tb0, c
     X(0, "v[72:75]") X(1, "v[76:79]") X(2, "v[80:83]") X(3, "v[84:87]") X(4, "v[88:91]") X(5, "v[92:95]")
 #define QR_ST_GROUP(q, R)                                                                   \
     if ((q) < NR && (q) * 1024 < st_nu) {                                                   \
-        if (tid + (q) * 1024 < st_nu)                                                       \
+        if (utid + (q) * 1024 < st_nu)                                                      \
             asm volatile("ds_write_b128 %0, " R " offset:%1" ::"v"((q) < 4 ? st_a0 : st_a1), \
                          "n"(((q) & 3) * 16384)                                             \
                          : "memory");                                                       \
     }
 #define QR_ST_TILE(q, R)                                                                    \
     if (((q) % 3) * 1024 < upt && ((q) < 3 || two)) {                                       \
-        if (tid + ((q) % 3) * 1024 < upt)                                                   \
+        if (utid + ((q) % 3) * 1024 < upt)                                                  \
             asm volatile("ds_write_b128 %0, " R " offset:%1" ::"v"((q) < 3 ? tl_a0 : tl_a1), \
                          "n"(((q) % 3) * 16384)                                             \
                          : "memory");                                                       \
@@ -749,6 +755,11 @@ __device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase
     constexpr int PP = POS & 3;
     constexpr int AT = PK_QR_AT(PP);
     constexpr int SP = PK_QR_SPREAD;
+#ifdef PK_QR_NOPRIO
+#define QR_SETPRIO(p_) do {} while (0)
+#else
+#define QR_SETPRIO(p_) __builtin_amdgcn_s_setprio(p_)
+#endif
     // slots [lo, hi) in front of pair k
 #define QR_SLOTS_AT(k_)                                                                          \
     do {                                                                                         \
@@ -765,16 +776,16 @@ __device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase
         q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);    \
     } while (0)
     if (__builtin_expect(depth >= 16, 1)) {
-        __builtin_amdgcn_s_setprio(PT[PP][0]);
+        QR_SETPRIO(PT[PP][0]);
         QR_TWO(0);
         QR_TWO(1);
-        __builtin_amdgcn_s_setprio(PT[PP][1]);
+        QR_SETPRIO(PT[PP][1]);
         QR_TWO(2);
         QR_TWO(3);
-        __builtin_amdgcn_s_setprio(PT[PP][2]);
+        QR_SETPRIO(PT[PP][2]);
         QR_TWO(4);
         QR_TWO(5);
-        __builtin_amdgcn_s_setprio(PT[PP][3]);
+        QR_SETPRIO(PT[PP][3]);
         QR_TWO(6);
         QR_TWO(7);
         // what the sixteen levels did not reach
@@ -783,19 +794,19 @@ __device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase
 #undef QR_SLOTS_AT
 #define QR_SLOTS_AT(k_) do {} while (0)
         for (int n4 = (depth - 16 + 3) >> 2; n4 > 0; n4--) {
-            __builtin_amdgcn_s_setprio(PT[PP][4]);
+            QR_SETPRIO(PT[PP][4]);
             QR_TWO(-1);
-            __builtin_amdgcn_s_setprio(PT[PP][5]);
+            QR_SETPRIO(PT[PP][5]);
             QR_TWO(-1);
         }
     } else {
         qr_issue<0, 8, NR>(gb, voff);  // (short trees)
-        __builtin_amdgcn_s_setprio(PT[PP][0]);
+        QR_SETPRIO(PT[PP][0]);
         for (int n2 = (depth + 1) >> 1; n2 > 0; n2--) QR_TWO(-1);
     }
 #undef QR_TWO
 #undef QR_SLOTS_AT
-    __builtin_amdgcn_s_setprio(0);
+    QR_SETPRIO(0);
 #pragma unroll
     for (int c = 0; c < 2; c++) v[c] = *LDS_AT(const lds_f64, tbase + ((q_pair_index<false>(w[c]) + 1) << 3));
 }
@@ -843,7 +854,14 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int slot = wave >> 1;  // tree slot
         const unsigned lk0 = (unsigned)lane << 2, lk1 = lk0 + 2u;
-        const unsigned voff = (unsigned)tid << 4;    // this thread's 16 bytes of a 16-KiB row
+        // this thread's 16 bytes of a 16-KiB row.  (PK_QR_REV: unit 1023 - tid, so that the partial last row
+        // of a group is stored by the LAST waves, not by the four owner waves that also add the values)
+#ifndef PK_QR_NO_REV
+        const int utid = (THREADS - 1) - tid;
+#else
+        const int utid = tid;
+#endif
+        const unsigned voff = (unsigned)utid << 4;
         if (wg != (int64_t)blockIdx.x && !tile_ready) __syncthreads();  // nobody reads the previous trip's tile any more
         if (PRUNE)
             for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
@@ -948,10 +966,12 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
             QR_STAMP(2);
             // everything this wave asked for has had the whole walk to arrive
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PK_QR_SUM_LAST
             if (g + 1 < n_grp && !(dbg & 4)) {  // (dbg 4: timing ablation, wrong results)
                 st_nu = g_nxt.w;
                 QR_GREGS(QR_ST_GROUP)
             }
+#endif
             const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
             if (owner && active && undecided) {
                 for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
@@ -967,6 +987,14 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
                     }
                 }
             }
+#ifndef PK_QR_SUM_LAST
+            // (the owners add the parked values first, then everybody stores: 1.5 % over the other order,
+            // with the partial last row stored by the last waves -- profiles/r04_ab_commit_order.log)
+            if (g + 1 < n_grp && !(dbg & 4)) {
+                st_nu = g_nxt.w;
+                QR_GREGS(QR_ST_GROUP)
+            }
+#endif
             QR_STAMP(3);
             if (g + 1 < n_grp || !fetched) __syncthreads();  // next group staged; values consumed; votes cast
             bool all_done = false;
