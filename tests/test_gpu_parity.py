@@ -857,6 +857,32 @@ def test_score_genome_distributed_branch_single_rank(hip_lib, tmp_path):
     assert out.read_text() == str(z["genome_weight"])
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_score_genome_fans_out_from_one_command(hip_lib, tmp_path, ranks):
+    """The product's own launcher on the GPU (round 4): the score_genome command line, run through
+    peakachu_amd.launch.spawn, becomes `ranks` child processes that find each other over the
+    standard-library rendezvous, score the chromosomes dealt to them ON THE DEVICE and merge on
+    rank 0; the bedpe must equal the reference's.  One GPU here, so all ranks share device 0
+    (LOCAL_RANK forced to 0) and the records travel over the rendezvous (PK_TRANSPORT=tcp: RCCL
+    refuses two ranks on one GPU); with one GPU per rank the same command uses RCCL."""
+    import os, subprocess, sys
+    z = gio.load("g6_driver.npz")
+    model = tmp_path / "forest.npz"
+    flat(gio.forest(str(z["forest"]))).save(str(model))
+    out = tmp_path / "fan.bedpe"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    argv = [os.path.join(root, "scripts", "peakachu-amd"), "score_genome", "-p",
+            os.path.join(gio.GOLD, str(z["container"])), "-m", str(model), "-O", str(out),
+            "--clr-weight-name", "weight", "-u", str(int(z["upper"]))]
+    code = ("import sys; sys.path.insert(0, %r); from peakachu_amd import launch; "
+            "sys.exit(launch.spawn(%d, argv=%r, env_extra={'LOCAL_RANK': '0', 'PK_TRANSPORT': 'tcp'}))"
+            % (root, ranks, argv))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PK_RDZV_FILE")}
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert out.read_text() == str(z["genome_weight"])
+
+
 @pytest.mark.parametrize("name", ["g3_score_raw.npz", "g3_score_weights.npz",
                                   "g3_score_hicstyle.npz", "g5_buildmatrix.npz"])
 def test_expected_on_device_golden(hip_lib, name):
