@@ -22,6 +22,8 @@
 // (pair address), v_cmp_le_u32_sdwa (code against the word's upper half),
 // v_cndmask_b32; ds_read_u16 + ds_read_b64.  Leaf values are added in tree order
 // in float64, the sequential sum sklearn computes.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "pk_common.h"
@@ -94,7 +96,10 @@ __global__ void q_cells_kernel(const float *__restrict__ qthr, const int32_t *__
         cells[i] = pk_q_cell(qthr[i], qpar[2 * f], qpar[2 * f + 1]);
 }
 
-__global__ __launch_bounds__(256) void quantize_tiles_kernel(
+// TP = tiles a wave converts per trip (2 * TP loads in flight per lane); the block has blockDim.x
+// threads (the tables of one feature: 24 KB of LDS per block)
+template <int TP>
+__global__ __launch_bounds__(1024) void quantize_tiles_kernel(
     const float *__restrict__ tiles, int64_t n_tiles, int Fs, int F, const int32_t *__restrict__ qsrc,
     const float *__restrict__ qthr, const int32_t *__restrict__ qoff, const unsigned *__restrict__ qlut,
     const float *__restrict__ qpar, unsigned short *__restrict__ qtiles, int tile64)
@@ -105,8 +110,8 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     __shared__ unsigned lut[PK_Q_CELLS];
     const int f = blockIdx.x, fs = qsrc[f];
     const int o = qoff[f], n = qoff[f + 1] - o;
-    for (int i = threadIdx.x; i < 2048; i += 256) thr[i] = i < n ? qthr[o + i] : __builtin_inff();
-    for (int i = threadIdx.x; i < PK_Q_CELLS; i += 256) lut[i] = qlut[(size_t)f * PK_Q_CELLS + i];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) thr[i] = i < n ? qthr[o + i] : __builtin_inff();
+    for (int i = threadIdx.x; i < PK_Q_CELLS; i += blockDim.x) lut[i] = qlut[(size_t)f * PK_Q_CELLS + i];
     const float lo = qpar[2 * f], inv = qpar[2 * f + 1];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -117,28 +122,30 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
     // rows are 512 B apart -- immediate offsets of one address; the float buffer is whole
     // groups, so a tile past n_tiles is readable and merely not converted)
     const size_t out_stride = (size_t)F * 64;  // dwords between the rows of consecutive tiles
-    for (int64_t t = ((int64_t)blockIdx.y * 4 + wave) * 4; t < n_tiles; t += (int64_t)gridDim.y * 16) {
+    static_assert(TP == 4 || TP == 8, "a wave's tiles of a trip lie in one group of eight");
+    const int WPB = blockDim.x >> 6;  // waves per block
+    for (int64_t t = ((int64_t)blockIdx.y * WPB + wave) * TP; t < n_tiles; t += (int64_t)gridDim.y * WPB * TP) {
         // float tiles: groups of 8 (1024 candidates per feature row) or, tile64 (wide forests,
         // whose one-window-per-wave extractor stores a feature at a time), single 128-tiles
         const float *src = tile64 ? tiles + ((size_t)t * Fs + fs) * 128 + lane
                                   : tiles + ((size_t)(t >> 3) * Fs + fs) * (128 * PK_Q_FTILE) + (size_t)(t & 7) * 128 + lane;
         const int kstride = tile64 ? Fs * 128 : 128;  // floats between consecutive tiles of this feature
-        float x[8];
-        unsigned code[8];
+        float x[2 * TP];
+        unsigned code[2 * TP];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < TP; k++) {
             const int kk = (tile64 && t + k >= n_tiles) ? 0 : k;  // (single tiles: nothing behind the last one)
             x[2 * k] = src[(size_t)kk * kstride];
             x[2 * k + 1] = src[(size_t)kk * kstride + 64];
         }
-        q_codes<8>(x, code, thr, lut, lo, inv);
+        q_codes<2 * TP>(x, code, thr, lut, lo, inv);
         // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
         // half): the two walks of a lane read the same LDS bank, different lanes different banks
         if (tile64) {
             // 64-candidate tiles [tile][F][64] u16 (wide forests): candidates lane and lane + 64
             // of a 128-tile go to two consecutive 64-tiles
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < TP; k++) {
                 if (t + k >= n_tiles) break;
                 unsigned short *d16 = qtiles + ((size_t)(t + k) * 2 * F + f) * 64 + lane;
                 d16[0] = (unsigned short)code[2 * k];
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void quantize_tiles_kernel(
         }
         unsigned *dst = reinterpret_cast<unsigned *>(qtiles) + ((size_t)t * F + f) * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < TP; k++) {
             if (t + k >= n_tiles) break;
             dst[k * out_stride] = code[2 * k] | (code[2 * k + 1] << 16);
         }
@@ -1543,7 +1550,12 @@ int pk_launch_quant_q(pk_device_ctx *ctx, hipStream_t st, pk_forest *f, const fl
     int64_t split = (n_tiles + 255) / 256;
     if (split > 64) split = 64;
     if (split < 1) split = 1;
-    hipLaunchKernelGGL(quantize_tiles_kernel, dim3((unsigned)F, (unsigned)split), dim3(256), 0, st, tiles,
+    // four tiles per wave and trip, 1024-thread blocks for the 128-candidate tiles (64 tiles = 32 KB of
+    // one feature's floats per block and trip), 512 for the wide forests' single tiles -- round 4's
+    // sweep (profiles/r04_ab_quant_shape.log): w = 5 0.96 -> 0.80 ms per step, w = 6 1.74 -> 1.52,
+    // w = 11 0.90 -> 0.82; eight tiles per trip and 256 / 384 / 768 threads measured beside them
+    const unsigned bt = L.ch == 1 ? 512u : 1024u;
+    hipLaunchKernelGGL(quantize_tiles_kernel<4>, dim3((unsigned)F, (unsigned)split), dim3(bt), 0, st, tiles,
                        n_tiles, f->F, F, f->q_src, f->q_thr, f->q_off, f->q_lut, f->q_par,
                        ctx->q_tiles + (size_t)t0 * F * 128, L.ch == 1 ? 1 : 0);
     PK_HIP(hipGetLastError());
