@@ -13,9 +13,13 @@
  *  - functions returning a handle: NULL = error, message in pk_last_error().
  *  - host pointers are BORROWED for the duration of the call; outputs are
  *    caller-allocated; device memory lives in the opaque handles.
- *  - one HIP stream pair per device; every entry point takes one process-wide
- *    lock, so calls are serialised (across devices too: the intended
- *    deployment is one process per GPU, see peakachu_amd/dist.py).
+ *  - threading: one HIP stream pair and one lock PER DEVICE.  Every entry
+ *    point takes the lock of the device its handle lives on, so calls on one
+ *    device are serialised by the library and calls on different devices run
+ *    side by side (one thread per device in one process works; the
+ *    deployment peakachu_amd/dist.py sets up is still one process per GPU).
+ *    Process-wide state -- the option DEFAULTS, the Gaussian taps, the
+ *    kernel timers -- has its own small locks; errors are thread-local.
  *  - there is no CPU fallback: without a gfx950 device every compute call
  *    fails with PK_E_NODEVICE.
  */
@@ -210,6 +214,10 @@ int pk_prof_reset(void);
 /* accumulated device time (ms) and launch count of kernel class `name`
  * ("extract", "forest", "compact", "band") since the last reset */
 int pk_prof_get(const char *name, double *ms_total, int64_t *launches);
+/* diagnostic, needs no device: 1 if a thread can take the lock of device_b while the caller holds
+ * the lock of device_a (different devices do not wait for each other), 0 if it cannot (same device:
+ * calls are serialised), PK_E_INVALID for indices outside 0..63 */
+int pk_debug_lock_probe(int device_a, int device_b);
 /* diagnostic builds only (option "forest_dbg" bit 4): in-kernel cycle stamps of
  * one workgroup, written to a buffer no kernel reads; n <= 65536 entries */
 int pk_debug_read(int device, int64_t *out, int64_t n);

@@ -77,6 +77,7 @@ SIGNATURES = {
     "pk_prof_reset": (C.c_int, []),
     "pk_prof_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pk_debug_read": (C.c_int, [C.c_int, _i64p, C.c_int64]),
+    "pk_debug_lock_probe": (C.c_int, [C.c_int, C.c_int]),
     "pk_debug_forest_image": (C.c_int, [C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p, _u8p,
                                         _f64p, C.c_int, _i32p, C.c_int64, _u64p,
                                         C.POINTER(C.c_int64), C.c_int64, _i32p,

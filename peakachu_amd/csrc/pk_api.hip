@@ -9,6 +9,7 @@
 
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "pk_common.h"
 
@@ -23,14 +24,26 @@ void pk_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
-pk_options g_opt;
-int64_t g_stat_extract_clean = 0, g_stat_extract_general = 0;
-static std::mutex g_mu;
-// One coarse lock for every entry point that touches a device: the library keeps
-// per-device scratch, cached launch tables inside handles and profiling lists, so
-// calls are serialised (include/peakachu_hip.h, 'Threading').
-std::recursive_mutex g_api_mu;
-#define PK_API_LOCK std::lock_guard<std::recursive_mutex> api_lock__(g_api_mu)
+static pk_options g_opt;
+std::atomic<int64_t> g_stat_extract_clean{0}, g_stat_extract_general{0};
+// Locks (include/peakachu_hip.h, 'Threading'): one recursive lock PER DEVICE, taken by every entry
+// point for the device of its handle -- a device has one stream pair, one tile scratch and handles
+// with cached launch tables, so calls on one device are serialised; calls on different devices run
+// side by side (round 4; rounds 1-3 had one process-wide lock).  What is shared by all devices is
+// small and has its own plain mutexes: g_mu (the context map, the option defaults, the taps) and
+// g_prof_mu (the kernel-timer lists).  Order: device lock first, then g_mu / g_prof_mu, never the
+// other way round.
+static std::mutex g_mu, g_prof_mu;
+static std::recursive_mutex g_dev_mu[PK_MAX_DEVICES];
+std::recursive_mutex &pk_device_mutex(int device)
+{
+    return g_dev_mu[device >= 0 && device < PK_MAX_DEVICES ? device : 0];
+}
+pk_options pk_default_options()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_opt;
+}
 static std::map<int, pk_device_ctx *> g_ctx;
 // Gaussian taps of the window blur (see pk_set_gauss_taps); defaults = numpy 2.2 / scipy 1.15
 static double g_taps[5] = {0x1.9884a307594fbp-2, 0x1.ef8eb9ad499bap-3, 0x1.ba4b99d1799abp-5,
@@ -42,7 +55,7 @@ struct prof_rec {
     pk_kclass k;
     int device;
 };
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 static std::vector<prof_rec> g_prof_pending;
 static double g_prof_ms[PK_K_NCLASS] = {0, 0, 0, 0, 0};
 static int64_t g_prof_n[PK_K_NCLASS] = {0, 0, 0, 0, 0};
@@ -61,10 +74,11 @@ pk_prof_scope::~pk_prof_scope()
 {
     if (!e0) return;
     hipEventRecord(e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_pending.push_back({e0, e1, k, ctx->device});
 }
 
-static void prof_drain()
+static void prof_drain()  // (under g_prof_mu)
 {
     for (auto &r : g_prof_pending) {
         float ms = 0.f;
@@ -185,7 +199,7 @@ extern "C" int pk_device_name(int device, char *buf, int buflen)
 
 extern "C" int pk_device_synchronize(int device)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(device);
     pk_device_ctx *c = pk_ctx(device);
     if (!c) return PK_E_NODEVICE;
     PK_HIP(hipStreamSynchronize(c->stream2));
@@ -196,7 +210,6 @@ extern "C" int pk_device_synchronize(int device)
 
 extern "C" int pk_set_gauss_taps(const double *taps5)
 {
-    PK_API_LOCK;
     if (!taps5) {
         pk_set_error("pk_set_gauss_taps: null pointer");
         return PK_E_INVALID;
@@ -206,16 +219,24 @@ extern "C" int pk_set_gauss_taps(const double *taps5)
             pk_set_error("pk_set_gauss_taps: taps must be finite, in (0, 1) and decreasing from the centre");
             return PK_E_INVALID;
         }
+    std::vector<std::pair<int, pk_device_ctx *>> in_use;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        memcpy(g_taps, taps5, sizeof(g_taps));
-        for (auto &kv : g_ctx) {  // devices that are already in use
-            PK_HIP(hipSetDevice(kv.first));
-            PK_HIP(hipStreamSynchronize(kv.second->stream));
-            PK_HIP(hipStreamSynchronize(kv.second->stream2));
-            const int rc = pk_extract_upload_taps(g_taps);
-            if (rc) return rc;
+        memcpy(g_taps, taps5, sizeof(g_taps));  // a device that comes up from here on starts with these
+        for (auto &kv : g_ctx) in_use.push_back(kv);
+    }
+    for (auto &kv : in_use) {  // devices that are already in use: one after the other, under their own lock
+        PK_DEV_LOCK(kv.first);
+        double t[5];
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            memcpy(t, g_taps, sizeof(t));
         }
+        PK_HIP(hipSetDevice(kv.first));
+        PK_HIP(hipStreamSynchronize(kv.second->stream));
+        PK_HIP(hipStreamSynchronize(kv.second->stream2));
+        const int rc = pk_extract_upload_taps(t);
+        if (rc) return rc;
     }
     return PK_OK;
 }
@@ -335,7 +356,7 @@ static int64_t opt_read(const pk_options &o, const char *name)
 
 extern "C" int pk_set_option(const char *name, int64_t value)
 {
-    PK_API_LOCK;
+    std::lock_guard<std::mutex> lk(g_mu);
     return opt_assign(g_opt, name, value);
 }
 
@@ -344,33 +365,34 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!name) return -1;
     if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
     if (!strcmp(name, "stat_extract_general")) return g_stat_extract_general;
+    std::lock_guard<std::mutex> lk(g_mu);
     return opt_read(g_opt, name);
 }
 
 extern "C" int pk_forest_set_option(pk_forest *f, const char *name, int64_t value)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(f ? f->device : 0);
     return f ? opt_assign(f->opt, name, value) : PK_E_INVALID;
 }
 extern "C" int64_t pk_forest_get_option(pk_forest *f, const char *name) { return f ? opt_read(f->opt, name) : -1; }
 
 extern "C" int pk_matrix_set_option(pk_matrix *m, const char *name, int64_t value)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(m ? m->device : 0);
     return m ? opt_assign(m->opt, name, value) : PK_E_INVALID;
 }
 extern "C" int64_t pk_matrix_get_option(pk_matrix *m, const char *name) { return m ? opt_read(m->opt, name) : -1; }
 
 extern "C" int pk_cands_set_option(pk_cands *c, const char *name, int64_t value)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     return c ? opt_assign(c->opt, name, value) : PK_E_INVALID;
 }
 extern "C" int64_t pk_cands_get_option(pk_cands *c, const char *name) { return c ? opt_read(c->opt, name) : -1; }
 
 extern "C" int pk_debug_read(int device, int64_t *out, int64_t n)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(device);
     pk_device_ctx *c = pk_ctx(device);
     if (!c) return PK_E_NODEVICE;
     if (!out || n < 0 || n > 65536) return PK_E_INVALID;
@@ -379,15 +401,29 @@ extern "C" int pk_debug_read(int device, int64_t *out, int64_t n)
     return PK_OK;
 }
 
+extern "C" int pk_debug_lock_probe(int device_a, int device_b)
+{
+    if (device_a < 0 || device_a >= PK_MAX_DEVICES || device_b < 0 || device_b >= PK_MAX_DEVICES) return PK_E_INVALID;
+    PK_DEV_LOCK(device_a);
+    int got = 0;
+    std::thread t([&]() {  // (a recursive lock: the probe has to come from another thread)
+        if (pk_device_mutex(device_b).try_lock()) {
+            got = 1;
+            pk_device_mutex(device_b).unlock();
+        }
+    });
+    t.join();
+    return got;
+}
+
 extern "C" int pk_prof_enable(int on)
 {
-    PK_API_LOCK;
     g_prof_on = on != 0;
     return PK_OK;
 }
 extern "C" int pk_prof_reset(void)
 {
-    PK_API_LOCK;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     prof_drain();
     for (int i = 0; i < PK_K_NCLASS; i++) {
         g_prof_ms[i] = 0;
@@ -397,7 +433,7 @@ extern "C" int pk_prof_reset(void)
 }
 extern "C" int pk_prof_get(const char *name, double *ms_total, int64_t *launches)
 {
-    PK_API_LOCK;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     static const char *names[PK_K_NCLASS] = {"extract", "forest", "compact", "band", "quant"};
     prof_drain();
     for (int i = 0; i < PK_K_NCLASS; i++)
@@ -424,7 +460,7 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
                                        const int32_t *feat, const double *thr,
                                        const uint8_t *miss_left, const double *p1)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(device);
     if (T <= 0 || F <= 0 || !tree_off || !left || !right || !feat || !thr || !p1) {
         pk_set_error("pk_forest_create: bad arguments");
         return nullptr;
@@ -658,7 +694,7 @@ int pk_forest_stage_flags(pk_forest *f, int region_words)
 
 extern "C" void pk_forest_destroy(pk_forest *f)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(f ? f->device : 0);
     if (!f) return;
     hipSetDevice(f->device);
     if (f->nodes) hipFree(f->nodes);
@@ -687,7 +723,7 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
                                        const double *exp_arr, int32_t exp_len, int32_t dlo,
                                        int32_t dhi)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(device);
     if (n <= 0 || !indptr || !exp_arr || exp_len <= 0 || dhi < dlo) {
         pk_set_error("pk_matrix_create: bad arguments");
         return nullptr;
@@ -750,7 +786,7 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
 extern "C" pk_csr *pk_csr_upload(int device, int32_t n, const int32_t *indptr, const int32_t *indices,
                                  const double *data)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(device);
     if (n <= 0 || !indptr || indptr[0] != 0 || indptr[n] < 0 || (indptr[n] > 0 && (!indices || !data))) {
         pk_set_error("pk_csr_upload: bad arguments / malformed CSR");
         return nullptr;
@@ -798,7 +834,7 @@ extern "C" pk_csr *pk_csr_upload(int device, int32_t n, const int32_t *indptr, c
 
 extern "C" void pk_csr_destroy(pk_csr *c)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->indptr, c->indices, c->data, c->valid_raw, c->valid_bal};
@@ -821,7 +857,7 @@ extern "C" int pk_csr_info(const pk_csr *c, int64_t info[4], double *vmax)
 
 extern "C" pk_matrix *pk_matrix_from_csr(pk_csr *c, int32_t dlo, int32_t dhi, int keep_nan)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     if (!c || dhi < dlo) {
         pk_set_error("pk_matrix_from_csr: bad arguments");
         return nullptr;
@@ -855,7 +891,7 @@ extern "C" pk_matrix *pk_matrix_from_csr(pk_csr *c, int32_t dlo, int32_t dhi, in
 
 extern "C" int pk_matrix_set_expected(pk_matrix *m, const double *exp_arr, int32_t exp_len)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(m ? m->device : 0);
     if (!m || !exp_arr || exp_len <= 0) {
         pk_set_error("pk_matrix_set_expected: bad arguments");
         return PK_E_INVALID;
@@ -875,7 +911,7 @@ extern "C" int pk_matrix_set_expected(pk_matrix *m, const double *exp_arr, int32
 extern "C" int pk_csr_expected_means(pk_csr *c, pk_matrix *band, int first, int top, int mode,
                                      double *means)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     if (!c || !band || !means || first < 0 || top < first || band->device != c->device ||
         band->n != c->n || first < band->dlo || top > band->dhi || top >= band->n) {
         pk_set_error("pk_csr_expected_means: bad arguments (diagonals %d..%d must lie in the band)", first, top);
@@ -913,7 +949,7 @@ extern "C" int pk_csr_expected_means(pk_csr *c, pk_matrix *band, int first, int 
 
 extern "C" void pk_matrix_destroy(pk_matrix *m)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(m ? m->device : 0);
     if (!m) return;
     hipSetDevice(m->device);
     if (m->band) hipFree(m->band);  // the quotient band lives in the same allocation
@@ -924,7 +960,7 @@ extern "C" void pk_matrix_destroy(pk_matrix *m)
 // --------------------------------------------------------------- candidates
 extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(device);
     if (N < 0 || (N > 0 && (!x || !y))) {
         pk_set_error("pk_cands_create: bad arguments");
         return nullptr;
@@ -933,7 +969,7 @@ extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, co
     if (!ctx) return nullptr;
     pk_cands *c = new pk_cands();
     memset(c, 0, sizeof(*c));
-    c->opt = g_opt;  // (the memset took the defaults with it)
+    c->opt = pk_default_options();  // (the memset took the defaults with it)
     c->device = device;
     c->N = N;
     const size_t n1 = (size_t)(N > 0 ? N : 1);
@@ -960,7 +996,7 @@ extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, co
 
 extern "C" int pk_cands_set_prune(pk_cands *c, int on)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     if (!c) return PK_E_INVALID;
     c->prune = on != 0;
     return PK_OK;
@@ -968,7 +1004,7 @@ extern "C" int pk_cands_set_prune(pk_cands *c, int on)
 
 extern "C" void pk_cands_destroy(pk_cands *c)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     if (!c) return;
     hipSetDevice(c->device);
     void *ptrs[] = {c->x, c->y, c->prob, c->status, c->ox, c->oy, c->op, c->osig, c->n_out_dev,
@@ -980,7 +1016,7 @@ extern "C" void pk_cands_destroy(pk_cands *c)
 
 extern "C" int pk_expected_means(pk_matrix *m, int top, const uint8_t *valid, double *means)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(m ? m->device : 0);
     if (!m || !valid || !means || top < 0 || m->dlo != 0 || top > m->dhi || top >= m->n) {
         pk_set_error("pk_expected_means: bad arguments (needs a band with dlo = 0, dhi >= top)");
         return PK_E_INVALID;
@@ -1017,7 +1053,7 @@ static pk_cands *cands_alloc(int device, int64_t N)
 {
     pk_cands *c = new pk_cands();
     memset(c, 0, sizeof(*c));
-    c->opt = g_opt;  // (the memset took the defaults with it)
+    c->opt = pk_default_options();  // (the memset took the defaults with it)
     c->device = device;
     c->N = N;
     const size_t n1 = (size_t)(N > 0 ? N : 1);
@@ -1043,7 +1079,7 @@ extern "C" pk_cands *pk_candidates_create(pk_matrix *raw, int lower, int upper,
                                           const double *weights, const double *mustar,
                                           int64_t n_mustar, int64_t *n_cand, int64_t *n_ambiguous)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(raw ? raw->device : 0);
     if (!raw || !bg || !n_cand || !n_ambiguous || lower < 0 || upper < lower ||
         (!weights && !kstar) || (weights && (!mustar || n_mustar <= 0))) {
         pk_set_error("pk_candidates_create: bad arguments");
@@ -1102,7 +1138,7 @@ extern "C" pk_cands *pk_candidates_create(pk_matrix *raw, int lower, int upper,
 
 extern "C" int pk_cands_fetch(pk_cands *cd, int32_t *x, int32_t *y)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(cd ? cd->device : 0);
     if (!cd) return PK_E_INVALID;
     pk_device_ctx *ctx = pk_ctx(cd->device);
     if (!ctx) return PK_E_NODEVICE;
@@ -1305,7 +1341,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
 extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, double thre,
                             int64_t batch, int64_t *n_out)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(m ? m->device : 0);
     if (!m || !f || !cd || w < 1) {
         pk_set_error("pk_score_run: bad arguments");
         return PK_E_INVALID;
@@ -1366,7 +1402,7 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
 
 extern "C" int pk_score_fetch(pk_cands *cd, int32_t *ox, int32_t *oy, double *op, double *osignal)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(cd ? cd->device : 0);
     if (!cd) return PK_E_INVALID;
     pk_device_ctx *ctx = pk_ctx(cd->device);
     if (!ctx) return PK_E_NODEVICE;
@@ -1382,7 +1418,7 @@ extern "C" int pk_score_fetch(pk_cands *cd, int32_t *ox, int32_t *oy, double *op
 
 extern "C" int pk_score_fetch_all(pk_cands *cd, uint8_t *status, double *prob)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(cd ? cd->device : 0);
     if (!cd) return PK_E_INVALID;
     pk_device_ctx *ctx = pk_ctx(cd->device);
     if (!ctx) return PK_E_NODEVICE;
@@ -1399,7 +1435,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
                         const int32_t *x, const int32_t *y, int32_t *ox, int32_t *oy, double *op,
                         double *osignal, int64_t *n_out)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(m ? m->device : 0);
     if (!m || !f || !n_out) {
         pk_set_error("pk_score: bad arguments");
         return PK_E_INVALID;
@@ -1445,7 +1481,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
 extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, const int32_t *y,
                           double *fea64, float *fea32, int64_t *keep, int64_t *n_keep)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(m ? m->device : 0);
     if (!m || !keep || !n_keep || N < 0 || w < 1 || w > 15) {
         pk_set_error("pk_extract: bad arguments");
         return PK_E_INVALID;
@@ -1520,7 +1556,7 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
 // --------------------------------------------------------- predict_proba API
 extern "C" int pk_predict(pk_forest *f, int64_t N, const float *fea32, double *p1)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(f ? f->device : 0);
     if (!f || N < 0 || (N > 0 && (!fea32 || !p1))) {
         pk_set_error("pk_predict: bad arguments");
         return PK_E_INVALID;

@@ -16,8 +16,6 @@
 #include "pk_common.h"
 #include "pk_comm_protocol.h"
 
-extern std::recursive_mutex g_api_mu;
-#define PK_API_LOCK std::lock_guard<std::recursive_mutex> api_lock__(g_api_mu)
 
 struct pk_comm {
     int device, nranks, rank;
@@ -104,7 +102,7 @@ extern "C" int pk_comm_unique_id(uint8_t id[128])
 
 extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8_t id[128])
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(device);
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) {
         pk_set_error("pk_comm_create: bad arguments");
         return nullptr;
@@ -140,7 +138,7 @@ extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8
 
 extern "C" void pk_comm_destroy(pk_comm *c)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     if (!c) return;
     hipSetDevice(c->device);
     if (c->d_counts) hipFree(c->d_counts);
@@ -154,7 +152,7 @@ extern "C" void pk_comm_destroy(pk_comm *c)
 extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, int64_t cap,
                                      int32_t *ox, int32_t *oy, double *op, double *osignal)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     if (!c || !cd || cd->device != c->device) {
         pk_set_error("pk_comm_gather_scored: bad arguments");
         return PK_E_INVALID;
@@ -170,7 +168,7 @@ extern "C" int pk_comm_gather_scored(pk_comm *c, pk_cands *cd, int64_t *counts, 
 extern "C" int pk_comm_gatherv_bytes(pk_comm *c, const void *send, int64_t nbytes, int64_t *counts,
                                      void *recv, int64_t cap)
 {
-    PK_API_LOCK;
+    PK_DEV_LOCK(c ? c->device : 0);
     if (!c || nbytes < 0 || (nbytes > 0 && !send)) {
         pk_set_error("pk_comm_gatherv_bytes: bad arguments");
         return PK_E_INVALID;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -109,10 +111,14 @@ struct pk_options {
     int64_t forest_img = 1;     // LDS-image forest kernel (fixed-depth walks, absolute LDS addresses)
                                 // when every tree fits; 0 = the grouped preorder kernel
 };
-extern pk_options g_opt;  // the DEFAULTS of new handles (pk_set_option); no launch path reads it directly
+// one recursive lock per device (pk_api.hip, "Locks"); every entry point takes the lock of its handle's device
+#define PK_MAX_DEVICES 64
+std::recursive_mutex &pk_device_mutex(int device);
+#define PK_DEV_LOCK(dev) std::lock_guard<std::recursive_mutex> api_lock__(pk_device_mutex(dev))
+pk_options pk_default_options();  // the DEFAULTS of new handles (pk_set_option), copied under their lock; no launch path reads them
 // launches of the two-lane extractor since load, by kernel (read-only options
 // "stat_extract_clean" / "stat_extract_general": lets tests see which one ran)
-extern int64_t g_stat_extract_clean, g_stat_extract_general;
+extern std::atomic<int64_t> g_stat_extract_clean, g_stat_extract_general;
 
 // ---------------------------------------------------------------- profiling
 // Brackets a kernel launch with HIP events on the library's stream when
@@ -159,7 +165,7 @@ struct pk_prof_scope {
 #define PK_KIND_ONE 3u
 
 struct pk_forest {
-    pk_options opt = g_opt;  // this handle's options: the process defaults (pk_set_option) at its creation,
+    pk_options opt = pk_default_options();  // this handle's options: the process defaults (pk_set_option) at its creation,
                              // then whatever pk_forest_set_option changed -- another handle never sees it
     int device;
     int T, F;
@@ -316,7 +322,7 @@ int pk_forest_stage_flags(pk_forest *f, int region_words);
 // Diagonal-major dense band: cell (r, r+k), dlo <= k <= dhi, lives at
 // band[(k - dlo) * ld + r]; everything else reads 0.
 struct pk_matrix {
-    pk_options opt = g_opt;  // (see pk_forest::opt) extractor options; pipeline options of the calls that
+    pk_options opt = pk_default_options();  // (see pk_forest::opt) extractor options; pipeline options of the calls that
                              // have no candidate handle (pk_score, pk_extract)
     int device;
     int32_t n, dlo, dhi;
@@ -344,7 +350,7 @@ struct pk_csr {
 };
 
 struct pk_cands {
-    pk_options opt = g_opt;  // (see pk_forest::opt) pipeline options of pk_score_run: chunk, overlap, sub_chunk,
+    pk_options opt = pk_default_options();  // (see pk_forest::opt) pipeline options of pk_score_run: chunk, overlap, sub_chunk,
                              // early_exit
     int device;
     int64_t N;

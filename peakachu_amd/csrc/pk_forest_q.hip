@@ -843,7 +843,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
     constexpr int sub = X0 != 0;
     const int n_grp = A.n_grp, T = A.T, F = A.F, dec_off = A.dec_off, val_off = A.val_off, img_off = A.img_off;
     const int dbg = A.dbg;
-    long long *const stamps = A.stamps;
+    [[maybe_unused]] long long *const stamps = A.stamps;  // (used by builds with -DPK_QR_STAMPS)
     const int64_t c0 = A.c0, cn = A.cn;
     const uint8_t *const status = A.status;
     const int HB = F * 256;  // bytes of a rank tile [F][64][2] u16

@@ -26,6 +26,36 @@ def test_library_exports_every_declared_symbol():
     assert L.pk_abi_version() == 1
 
 
+def test_locks_are_per_device():
+    """include/peakachu_hip.h 'threading': calls on one device are serialised, calls on different
+    devices do not wait for each other (the probe takes the locks themselves; no device needed)."""
+    from peakachu_amd import _lib
+    L = _lib.load()
+    assert L.pk_debug_lock_probe(0, 0) == 0
+    assert L.pk_debug_lock_probe(3, 3) == 0
+    assert L.pk_debug_lock_probe(0, 1) == 1
+    assert L.pk_debug_lock_probe(7, 0) == 1
+    assert L.pk_debug_lock_probe(0, 64) == _lib.PK_E_INVALID
+    assert L.pk_debug_lock_probe(-1, 0) == _lib.PK_E_INVALID
+    # the process-wide pieces have their own locks: defaults can be set and read from threads
+    import threading
+    errs = []
+
+    def flip(k):
+        try:
+            for i in range(200):
+                L.pk_set_option(b"chunk", 1 << (16 + (i + k) % 4))
+                assert L.pk_get_option(b"chunk") in (1 << 16, 1 << 17, 1 << 18, 1 << 19)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    old = L.pk_get_option(b"chunk")
+    ts = [threading.Thread(target=flip, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    L.pk_set_option(b"chunk", old)
+    assert not errs and L.pk_get_option(b"chunk") == old
+
+
 def test_no_device_fails_loudly():
     from peakachu_amd import _lib
     L = _lib.load()

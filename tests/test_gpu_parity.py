@@ -494,6 +494,49 @@ def test_options_belong_to_their_handle(hip_lib):
     assert L.pk_cands_set_option(None, b"chunk", 4096) == _lib.PK_E_INVALID
 
 
+def test_threads_on_one_device_are_serialised(hip_lib):
+    """include/peakachu_hip.h 'threading': the lock is per device -- four threads that extract, predict
+    and score on the SAME device at once (own handles, and one shared forest) are serialised by the
+    library and all get the bits a single thread gets; the kernel timers keep counting under it."""
+    import threading
+    L = hip_lib
+    z = gio.load("g3_score_raw.npz")
+    w, upper = int(z["w"]), int(z["upper"])
+    Mf = utils.band_filter(gio.sym_matrix(z, "R"), w, upper)
+    x, y = z["ridx"].astype(np.int32), z["cidx"].astype(np.int32)
+    fo = flat(gio.forest(str(z["forest"])))
+    shared = _lib.HipForest(fo)
+    m0 = hip_matrix(Mf, z["exp_arr"], w, upper)
+    fea0 = m0.extract(w, x, y)[0]
+    p0 = shared.predict(fea0.astype(np.float32))
+    s0 = m0.score(shared, w, 0.5, x, y)
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            m = hip_matrix(Mf, z["exp_arr"], w, upper, options={"extract_clean": k & 1})
+            f = shared if k & 2 else _lib.HipForest(fo, options={"forest_q": (k >> 1) & 1 ^ 1})
+            for _ in range(3):
+                fea = m.extract(w, x, y)[0]
+                out[k] = (fea, f.predict(fea.astype(np.float32)), m.score(f, w, 0.5, x, y))
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    L.pk_prof_enable(1)
+    L.pk_prof_reset()
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    launches = _lib.prof_get("forest")[1]
+    L.pk_prof_enable(0)
+    assert not errs, errs
+    assert launches >= 4 * 3 * 2
+    for k in range(4):
+        fea, p, sc = out[k]
+        assert np.array_equal(gio.bits(fea), gio.bits(fea0))
+        assert np.array_equal(gio.bits(p), gio.bits(p0))
+        assert all(np.array_equal(gio.bits(np.asarray(a, np.float64)), gio.bits(np.asarray(b, np.float64))) for a, b in zip(sc, s0))
+
+
 def test_chromosome_drop_in(hip_lib, tmp_path):
     """The mirror class reproduces the reference's bedpe text byte for byte."""
     from peakachu_amd import scoreUtils
