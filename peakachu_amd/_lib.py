@@ -7,6 +7,7 @@ call raises.
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -337,16 +338,21 @@ class HipMatrix(_Options):
         x = np.ascontiguousarray(x, np.int32)
         y = np.ascontiguousarray(y, np.int32)
         N = x.size
-        ox = np.empty(max(N, 1), np.int32)
-        oy = np.empty(max(N, 1), np.int32)
-        op = np.empty(max(N, 1), np.float64)
-        osig = np.empty(max(N, 1), np.float64)
-        nout = C.c_int64(0)
-        if N:
-            check(self._L.pk_score(self.h, forest.h, int(w), float(thre), int(batch), N, x, y,
-                                   ox, oy, op, osig, C.byref(nout)), "pk_score")
-        k = nout.value
-        return ox[:k], oy[:k], op[:k], osig[:k]
+        # the C call wants room for N pixels; the buffers are kept with the matrix (grow-only) and
+        # the scored pixels handed out as copies -- four fresh N-sized arrays per call cost more
+        # than copying the few thousand pixels that pass
+        with self.__dict__.setdefault("_score_lock", threading.Lock()):  # (the buffers are this object's)
+            out = getattr(self, "_score_out", None)
+            if out is None or out[0].size < max(N, 1):
+                out = self._score_out = (np.empty(max(N, 1), np.int32), np.empty(max(N, 1), np.int32),
+                                         np.empty(max(N, 1), np.float64), np.empty(max(N, 1), np.float64))
+            ox, oy, op, osig = out
+            nout = C.c_int64(0)
+            if N:
+                check(self._L.pk_score(self.h, forest.h, int(w), float(thre), int(batch), N, x, y,
+                                       ox, oy, op, osig, C.byref(nout)), "pk_score")
+            k = nout.value
+            return ox[:k].copy(), oy[:k].copy(), op[:k].copy(), osig[:k].copy()
 
     def close(self):
         if getattr(self, "h", None):

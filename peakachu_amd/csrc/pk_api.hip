@@ -139,6 +139,8 @@ pk_device_ctx *pk_ctx(int device)
     }
     PK_HIP_NULL(hipMalloc((void **)&c->dbg_buf, 65536 * sizeof(long long)));
     PK_HIP_NULL(hipMemset(c->dbg_buf, 0, 65536 * sizeof(long long)));
+    PK_HIP_NULL(hipMalloc((void **)&c->d_ret, PK_RET_BYTES));
+    PK_HIP_NULL(hipHostMalloc((void **)&c->h_ret, PK_RET_BYTES, hipHostMallocDefault));
     if (pk_extract_upload_taps(g_taps) != PK_OK) return nullptr;
     g_ctx[device] = c;
     return c;
@@ -1217,8 +1219,19 @@ __global__ void coords_sanitize_kernel(int32_t *__restrict__ x, int32_t *__restr
     }
 }
 
+#ifdef PK_SCORE_TRACE
+#include <chrono>
+static double tr_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static double tr_t0 = 0;
+#define TR(tag) fprintf(stderr, "TR %-14s %9.1f\n", tag, tr_now() - tr_t0)
+#else
+#define TR(tag)
+#endif
 #ifndef PK_FIRST_UPLOAD
-#define PK_FIRST_UPLOAD 262144  // candidates of pk_score's first upload chunk (the only exposed one); doubling after
+#define PK_FIRST_UPLOAD 262144  // candidates of pk_score's first upload chunk (the only exposed one)
+#endif
+#ifndef PK_UPLOAD_GROWTH
+#define PK_UPLOAD_GROWTH 5
 #endif
 static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands *cd, int w,
                         double prune_sum)
@@ -1262,29 +1275,55 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         PK_HIP(hipEventRecord(ctx->ev_for[0], ctx->stream));
         PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[0], 0));
     }
-    // pk_score hands host coordinates over: the upload of chunk k + 1 (second stream; the host
-    // blocks in the copy while the device scores chunk k) overlaps the kernels of chunk k.  The
-    // chunks then GROW -- 256 Ki candidates first, doubling up to `chunk` -- so that only a
-    // small first upload is exposed and every later one (0.4 ns per candidate over PCIe) fits
-    // behind the scoring of its predecessor (1.1 ns per candidate).
+    // pk_score hands host coordinates over: the upload of chunk k + 1 (second stream) overlaps the
+    // kernels of chunk k.
     const bool stream_coords = cd->h_x != nullptr && !overlap && cd->N > 0;
+    // Chunk sizes of a streamed call: the first one small (its upload is the exposed one), the second
+    // PK_UPLOAD_GROWTH times as large -- an upload moves a candidate in 0.18 ns (8 bytes at ~45 GB/s,
+    // measured through the pageable staging path), the kernels score one in 0.9-1.1 ns, so a chunk
+    // five times its predecessor still arrives in time -- and the rest in equal launches of at most
+    // `chunk` candidates (round 3-4 doubled from 256 Ki: five launches where four do, 80 us of small-
+    // launch inefficiency per call of the bench workload; profiles/r04_pcie_timeline.log).
+    std::vector<int64_t> sizes;
+    if (stream_coords) {
+        auto up = [&](int64_t v) { return (v + blk - 1) / blk * blk; };
+        int64_t left = cd->N;
+        for (int64_t want : {(int64_t)PK_FIRST_UPLOAD, (int64_t)PK_FIRST_UPLOAD * PK_UPLOAD_GROWTH}) {
+            if (left <= 0) break;
+            int64_t sz = up(want) < chunk ? up(want) : chunk;
+            if (left - sz < sz / 2 && up(left) <= chunk) sz = up(left);  // no crumb behind it
+            sizes.push_back(sz);
+            left -= sz;
+        }
+        if (left > 0) {
+            const int64_t n = (left + chunk - 1) / chunk;
+            const int64_t each = up((left + n - 1) / n);
+            for (int64_t i = 0; i < n; i++) sizes.push_back(each < chunk ? each : chunk);
+        }
+    }
     auto span = [&](int64_t k_) -> int64_t {  // candidates of chunk k_
-        if (!stream_coords) return chunk;
-        int64_t sz = (int64_t)PK_FIRST_UPLOAD << (k_ < 8 ? k_ : 8);
-        sz = (sz + blk - 1) / blk * blk;
-        return sz < chunk ? sz : chunk;
+        return (stream_coords && k_ < (int64_t)sizes.size()) ? sizes[(size_t)k_] : chunk;
     };
     auto upload = [&](int64_t c0, int64_t k_) -> int {
         const int64_t cn = cd->N - c0 < span(k_) ? cd->N - c0 : span(k_);
-        PK_HIP(hipMemcpyAsync(cd->x + c0, cd->h_x + c0, (size_t)cn * 4, hipMemcpyHostToDevice, ctx->stream2));
-        PK_HIP(hipMemcpyAsync(cd->y + c0, cd->h_y + c0, (size_t)cn * 4, hipMemcpyHostToDevice, ctx->stream2));
-        PK_HIP(hipEventRecord(ctx->ev_ext[k_ & 1], ctx->stream2));
+        // chunk 0 is the exposed one: on the kernels' own stream (no event hop in front of the first
+        // extractor); the others on the second stream, beside the kernels of their predecessor
+        hipStream_t su = k_ == 0 ? ctx->stream : ctx->stream2;
+        PK_HIP(hipMemcpyAsync(cd->x + c0, cd->h_x + c0, (size_t)cn * 4, hipMemcpyHostToDevice, su));
+        PK_HIP(hipMemcpyAsync(cd->y + c0, cd->h_y + c0, (size_t)cn * 4, hipMemcpyHostToDevice, su));
+        // the range check rides right behind the copy
+        hipLaunchKernelGGL(coords_sanitize_kernel, dim3((unsigned)((cn + 2047) / 2048 < 1024 ? (cn + 2047) / 2048 : 1024)),
+                           dim3(256), 0, su, cd->x + c0, cd->y + c0, cn, m->n, c0,
+                           reinterpret_cast<unsigned long long *>(ctx->dbg_buf + 65533));
+        if (k_ != 0) PK_HIP(hipEventRecord(ctx->ev_ext[k_ & 1], ctx->stream2));
         return PK_OK;
     };
+    TR("pipe:pre");
     if (stream_coords) {
         rc = upload(0, 0);
         if (rc) return rc;
     }
+    TR("pipe:up0");
     int64_t k = 0;
     for (int64_t c0 = 0; c0 < cd->N; c0 += span(k), k++) {
         const int64_t cn = cd->N - c0 < span(k) ? cd->N - c0 : span(k);
@@ -1292,12 +1331,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
         float *tiles = ctx->fea_tiles + (size_t)buf * tile_floats;
         if (overlap && k >= 2)  // forest(k-2) must be done with this buffer
             PK_HIP(hipStreamWaitEvent(st_ext, ctx->ev_for[buf], 0));
-        if (stream_coords) {
-            PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[k & 1], 0));
-            hipLaunchKernelGGL(coords_sanitize_kernel, dim3((unsigned)((cn + 2047) / 2048 < 1024 ? (cn + 2047) / 2048 : 1024)),
-                               dim3(256), 0, ctx->stream, cd->x + c0, cd->y + c0, cn, m->n, c0,
-                               reinterpret_cast<unsigned long long *>(ctx->dbg_buf + 65533));
-        }
+        if (stream_coords && k != 0) PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[k & 1], 0));
         // rank kernels: the float tiles are an intermediate of this chunk only (extractor ->
         // quantizer); made and consumed piece by piece through the start of the buffer they
         // never have to leave the Infinity Cache
@@ -1338,8 +1372,35 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     return PK_OK;
 }
 
+// {n_out, status words} and -- with_records, when they fit -- the scored pixels into one buffer
+__global__ void __launch_bounds__(256) ret_pack_kernel(const int64_t *__restrict__ n_out, const long long *__restrict__ dbg3,
+                                                       const int32_t *__restrict__ ox, const int32_t *__restrict__ oy,
+                                                       const double *__restrict__ op, const double *__restrict__ os,
+                                                       char *__restrict__ ret, int with_records)
+{
+    const int64_t n = *n_out;
+    if (blockIdx.x == 0 && threadIdx.x < 4)
+        reinterpret_cast<long long *>(ret)[threadIdx.x] = threadIdx.x == 0 ? (long long)n : dbg3[threadIdx.x - 1];
+    if (!with_records || n > PK_RET_INLINE) return;
+    int32_t *rx = reinterpret_cast<int32_t *>(ret + 32), *ry = rx + PK_RET_INLINE;
+    double *rp = reinterpret_cast<double *>(ry + PK_RET_INLINE), *rs = rp + PK_RET_INLINE;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        rx[i] = ox[i];
+        ry[i] = oy[i];
+        rp[i] = op[i];
+        rs[i] = os[i];
+    }
+}
+
+static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, double thre, int64_t batch, int64_t *n_out,
+                          bool with_records);
 extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, double thre,
                             int64_t batch, int64_t *n_out)
+{
+    return score_run_impl(m, f, cd, w, thre, batch, n_out, false);
+}
+static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, double thre, int64_t batch, int64_t *n_out,
+                          bool with_records)
 {
     PK_DEV_LOCK(m ? m->device : 0);
     if (!m || !f || !cd || w < 1) {
@@ -1368,18 +1429,29 @@ extern "C" int pk_score_run(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, dou
     // optional exact early termination (option early_exit): only meaningful for thre >= 0
     const double prune_sum =
         ((cd->opt.early_exit || cd->prune) && thre >= 0.0) ? thre * (double)f->T : -INFINITY;
+    TR("run:enter");
     int rc = run_pipeline(ctx, m, f, cd, w, prune_sum);
     if (rc) return rc;
+    TR("run:launched");
     rc = pk_launch_compact(ctx, m, cd, thre, batch);
     if (rc) return rc;
-    PK_HIP(hipMemcpyAsync(&cd->n_out, cd->n_out_dev, sizeof(int64_t), hipMemcpyDeviceToHost,
-                          ctx->stream));
-    // words 65533 (first coordinate outside pk_score's contract, see coords_sanitize_kernel), 65534
-    // (a sink that keeps the kernels' warm-up loads alive) and 65535 (the forest kernels' error word)
-    // of the diagnostic buffer
-    long long dbg3[3] = {0, 0, 0};
-    PK_HIP(hipMemcpyAsync(dbg3, ctx->dbg_buf + 65533, sizeof(dbg3), hipMemcpyDeviceToHost, ctx->stream));
+    // One copy into pinned memory brings back the count, words 65533 (first coordinate outside
+    // pk_score's contract, see coords_sanitize_kernel), 65534 (a sink that keeps the kernels' warm-up
+    // loads alive) and 65535 (the forest kernels' error word) of the diagnostic buffer and -- for
+    // pk_score -- the scored pixels themselves when there are at most PK_RET_INLINE of them (rounds
+    // 1-4: two pageable copies here and four more in pk_score_fetch, 25 us each).
+    cd->ret_inline = false;
+    hipLaunchKernelGGL(ret_pack_kernel, dim3(with_records ? 32 : 1), dim3(256), 0, ctx->stream, cd->n_out_dev,
+                       ctx->dbg_buf + 65533, cd->ox, cd->oy, cd->op, cd->osig, ctx->d_ret, with_records ? 1 : 0);
+    PK_HIP(hipGetLastError());
+    PK_HIP(hipMemcpyAsync(ctx->h_ret, ctx->d_ret, with_records ? PK_RET_BYTES : 32, hipMemcpyDeviceToHost, ctx->stream));
+    TR("run:enq");
     PK_HIP(hipStreamSynchronize(ctx->stream));
+    TR("run:synced");
+    long long dbg3[3];
+    memcpy(&cd->n_out, ctx->h_ret, 8);
+    memcpy(dbg3, ctx->h_ret + 8, 24);
+    cd->ret_inline = with_records && cd->n_out <= PK_RET_INLINE;
     const long long err = dbg3[2];
     if (dbg3[0]) {
         PK_HIP(hipMemset(ctx->dbg_buf + 65533, 0, sizeof(long long)));
@@ -1440,6 +1512,9 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         pk_set_error("pk_score: bad arguments");
         return PK_E_INVALID;
     }
+#ifdef PK_SCORE_TRACE
+    { const double n_ = tr_now(); fprintf(stderr, "TR between-calls %9.1f\n", n_ - tr_t0); tr_t0 = n_; }
+#endif
     int rc = PK_OK;
     // the device-side candidate list of the host-buffer convenience call is kept per device
     // and reused while it is large enough: nine allocations per call cost more than the
@@ -1468,12 +1543,24 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         ctx->score_cands_cap = N;
     }
     cd->opt = m->opt;  // (a call without a candidate handle: the matrix handle's pipeline options)
-    rc = pk_score_run(m, f, cd, w, thre, batch, n_out);
+    rc = score_run_impl(m, f, cd, w, thre, batch, n_out, true);
     if (deferred) {
         cd->h_x = cd->h_y = nullptr;  // borrowed for this call only
-        if (rc) hipStreamSynchronize(ctx->stream2);  // no copy may still read the caller's buffers
+        if (rc) {  // no copy may still read the caller's buffers
+            hipStreamSynchronize(ctx->stream2);
+            hipStreamSynchronize(ctx->stream);
+        }
     }
-    if (!rc) rc = pk_score_fetch(cd, ox, oy, op, osignal);
+    if (!rc && cd->ret_inline) {  // the pixels came back with the count
+        const size_t k = (size_t)cd->n_out;
+        const char *r = ctx->h_ret + 32;
+        if (ox) memcpy(ox, r, k * 4);
+        if (oy) memcpy(oy, r + (size_t)PK_RET_INLINE * 4, k * 4);
+        if (op) memcpy(op, r + (size_t)PK_RET_INLINE * 8, k * 8);
+        if (osignal) memcpy(osignal, r + (size_t)PK_RET_INLINE * 16, k * 8);
+    } else if (!rc)
+        rc = pk_score_fetch(cd, ox, oy, op, osignal);
+    TR("score:fetched");
     return rc;
 }
 

@@ -55,7 +55,12 @@ struct pk_device_ctx {
     size_t scan_scratch_bytes = 0;
     int cu_count = 0;
     long long *dbg_buf = nullptr;  // diagnostic cycle stamps (pk_debug_read), 64 Ki entries
+    // what a scoring call brings back in ONE copy into pinned memory: {n_out, three status words of
+    // dbg_buf} and, for pk_score, the first PK_RET_INLINE scored pixels [x | y | p | signal]
+    char *d_ret = nullptr, *h_ret = nullptr;
 };
+#define PK_RET_INLINE 8192
+#define PK_RET_BYTES (32 + (size_t)PK_RET_INLINE * 24)
 pk_device_ctx *pk_ctx(int device);  // lazily created; nullptr + error on failure
 int pk_ctx_reserve_tiles(pk_device_ctx *, size_t bytes);
 int pk_ctx_reserve_scan(pk_device_ctx *, size_t bytes);
@@ -362,6 +367,7 @@ struct pk_cands {
     int32_t *ox, *oy;
     double *op, *osig;
     int64_t *n_out_dev;    // device scalar
+    bool ret_inline;       // the scored pixels of the last run lie in the context's h_ret (pk_score)
     int64_t n_out;         // host copy after the run
     int32_t *batch_cnt;    // device [n_batches] survivors per reference batch
     int64_t n_batches_cap;

@@ -450,6 +450,39 @@ def test_score_checks_streamed_coordinates_on_the_device(hip_lib):
                                   gio.bits(b) if b.dtype == np.float64 else b) for a, b in zip(first, ok))
 
 
+def test_score_returns_pixels_with_the_count_or_by_fetch(hip_lib):
+    """pk_score brings the scored pixels back in the same pinned copy as their count while there are
+    at most 8 192 of them (PK_RET_INLINE) and by pk_score_fetch's four copies beyond: both routes
+    against pk_score_run + pk_score_fetch on a device-resident list, on either side of the limit and
+    for an empty result."""
+    z = gio.load("g3_score_raw.npz")
+    w, upper = int(z["w"]), int(z["upper"])
+    Mf = utils.band_filter(gio.sym_matrix(z, "R"), w, upper)
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper)
+    hf = _lib.HipForest(flat(gio.forest(str(z["forest"]))))
+    reps = 300000 // z["ridx"].size + 1
+    x = np.tile(z["ridx"].astype(np.int32), reps)
+    y = np.tile(z["cidx"].astype(np.int32), reps)
+    cd = _lib.HipCands(x, y)
+    cd.run(hm, hf, w, -1.0)            # every window that passes the filters is "scored"
+    passing = np.cumsum(cd.fetch_all()[0] != 0)
+    assert passing[-1] > 20000
+    sizes = []
+    for n_cand, thre in ((int(np.searchsorted(passing, 8192)) + 1, -1.0), (int(np.searchsorted(passing, 8193)) + 1, -1.0),
+                         (x.size, -1.0), (x.size, 0.5), (x.size, 2.0)):
+        xs, ys = x[:n_cand].copy(), y[:n_cand].copy()
+        for _ in range(2):             # first call: whole upload; second: streamed
+            got = hm.score(hf, w, thre, xs, ys)
+        ref_cd = _lib.HipCands(xs, ys)
+        ref_cd.run(hm, hf, w, thre)
+        want = ref_cd.fetch()
+        sizes.append(got[0].size)
+        assert got[0].size == want[0].size
+        for a, b in zip(got, want):
+            assert np.array_equal(gio.bits(a) if a.dtype == np.float64 else a, gio.bits(b) if b.dtype == np.float64 else b)
+    assert sizes[0] == 8192 and sizes[1] == 8193 and sizes[2] > 20000 and sizes[4] == 0, sizes
+
+
 def test_options_belong_to_their_handle(hip_lib):
     """Round 4: every handle carries its own options (rounds 1-3 had one process-wide set, and a
     knob left set by one caller changed every other caller).  Two matrices and two forests with
