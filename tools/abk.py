@@ -33,10 +33,17 @@ def child(path, steps, opts):
         cd.run(hm, hf, w, 0.5)
     r = {k: _lib.prof_get(k)[0] / steps for k in ("extract", "quant", "forest", "compact")}
     L.pk_prof_enable(0)
+    import time
+    L.pk_device_synchronize(0)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cd.run(hm, hf, w, 0.5)
+    L.pk_device_synchronize(0)
+    wall = (time.perf_counter() - t0) / steps * 1e3
     st, pr = cd.fetch_all()
     crc = zlib.crc32(pr.tobytes()) ^ zlib.crc32(st.tobytes())
-    print(" ".join("%s %.3f" % kv for kv in r.items()), " total %.3f ms -> %.0f M/s  pixels %d crc %08x"
-          % (sum(r.values()), d["x"].size / sum(r.values()) / 1e3, out, crc), flush=True)
+    print(" ".join("%s %.3f" % kv for kv in r.items()), " total %.3f ms -> %.0f M/s  wall %.3f ms  pixels %d crc %08x"
+          % (sum(r.values()), d["x"].size / sum(r.values()) / 1e3, wall, out, crc), flush=True)
 
 
 if __name__ == "__main__":
