@@ -95,13 +95,13 @@ __global__ void csr_info_kernel(const int32_t *__restrict__ indptr, const int32_
 // workgroup straddles at most two batches when batch >= 4096; smaller
 // batches fall back to per-candidate atomics).
 constexpr int BC_ITEMS = 16;
-__global__ void batch_count_kernel(const uint8_t *__restrict__ status, int64_t N, int64_t batch,
-                                   int32_t *__restrict__ batch_cnt)
+__global__ void __launch_bounds__(256) batch_count_kernel(const uint8_t *__restrict__ status, int64_t N, int64_t batch,
+                                                          int32_t *__restrict__ batch_cnt)
 {
     __shared__ int cnt[2];
     const int64_t base = (int64_t)blockIdx.x * (256 * BC_ITEMS);
     const int64_t b0 = base / batch;
-    if (batch < 256 * BC_ITEMS) {
+    if (batch < 256 * BC_ITEMS) {  // (a block may span more than two batches)
         for (int i = 0; i < BC_ITEMS; i++) {
             const int64_t c = base + (int64_t)i * 256 + threadIdx.x;
             if (c < N && status[c]) atomicAdd(&batch_cnt[c / batch], 1);
@@ -110,12 +110,35 @@ __global__ void batch_count_kernel(const uint8_t *__restrict__ status, int64_t N
     }
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     __syncthreads();
+    // thread t takes the BC_ITEMS = 16 consecutive flags base + 16 t ..: one 16-byte load (the list is
+    // allocated by hipMalloc and `base` is a multiple of 4 096), flags are 0, 1 or 2
+    static_assert(BC_ITEMS == 16, "one uint4 of flags per thread");
     int mine0 = 0, mine1 = 0;
-    for (int i = 0; i < BC_ITEMS; i++) {
-        const int64_t c = base + (int64_t)i * 256 + threadIdx.x;
-        if (c < N && status[c]) {
-            if (c / batch == b0) mine0++;
-            else mine1++;
+    const int64_t c0 = base + (int64_t)threadIdx.x * BC_ITEMS;
+    if (c0 + BC_ITEMS <= N) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(status + c0);
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+        if (c0 / batch == (c0 + BC_ITEMS - 1) / batch) {
+            int k = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) k += __popc((w4[j] | (w4[j] >> 1)) & 0x01010101u);
+            if (c0 / batch == b0) mine0 = k;
+            else mine1 = k;
+        } else {
+#pragma unroll
+            for (int j = 0; j < BC_ITEMS; j++)
+                if ((w4[j >> 2] >> ((j & 3) * 8)) & 0xFFu) {
+                    if ((c0 + j) / batch == b0) mine0++;
+                    else mine1++;
+                }
+        }
+    } else {
+        for (int j = 0; j < BC_ITEMS; j++) {
+            const int64_t c = c0 + j;
+            if (c < N && status[c]) {
+                if (c / batch == b0) mine0++;
+                else mine1++;
+            }
         }
     }
 #pragma unroll
@@ -168,29 +191,35 @@ __global__ void compact_count_kernel(const uint8_t *__restrict__ status,
 }
 
 // exclusive scan of block_cnt in place by one workgroup; total -> *n_out
-__global__ void compact_scan_kernel(int64_t *__restrict__ block_cnt, int64_t nblocks,
-                                    int64_t *__restrict__ n_out)
+// (thread t owns a contiguous run of blocks; the 1024 partial sums are scanned by wave shuffles --
+// a serial pass of one thread over them was half of this kernel's 19 us)
+__global__ void __launch_bounds__(1024) compact_scan_kernel(int64_t *__restrict__ block_cnt, int64_t nblocks,
+                                                            int64_t *__restrict__ n_out)
 {
-    __shared__ int64_t part[1024];
-    const int tid = threadIdx.x;
-    const int64_t per = (nblocks + blockDim.x - 1) / blockDim.x;
+    __shared__ int64_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t per = (nblocks + 1023) / 1024;
     const int64_t b0 = (int64_t)tid * per;
     const int64_t b1 = b0 + per < nblocks ? b0 + per : nblocks;
     int64_t s = 0;
     for (int64_t b = b0; b < b1; b++) s += block_cnt[b];
-    part[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int64_t run = 0;
-        for (int i = 0; i < (int)blockDim.x; i++) {
-            const int64_t v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        *n_out = run;
+    int64_t incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
     }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    int64_t run = part[tid];
+    int64_t woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int64_t v = wsum[i];
+        if (i < wave) woff += v;
+        total += v;
+    }
+    if (tid == 0) *n_out = total;
+    int64_t run = woff + incl - s;
     for (int64_t b = b0; b < b1; b++) {
         const int64_t v = block_cnt[b];
         block_cnt[b] = run;
