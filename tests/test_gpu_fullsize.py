@@ -360,3 +360,38 @@ def test_clean_extractor_bitwise_equals_general_on_balanced_values(hip_lib, conf
         assert (L.pk_get_option(b"stat_extract_clean") > before) == (clean == 1)
     assert got[0] == got[1]
     assert sum(p[1] for p in got[1]) > 300_000
+
+
+@pytest.mark.skipif(os.environ.get("PK_TEST_HUGE") != "1",
+                    reason="opt-in (PK_TEST_HUGE=1): 2.15e9 candidates, ~90 GB of HBM and ~20 GB of host memory")
+def test_more_candidates_than_int32_holds(config2):
+    """Maximum sizes: a candidate list of more than 2^31 entries (the configs[1] list 387 times over:
+    2 150 856 603 candidates, 88 GB of device arrays) through pk_score_run.  The list is periodic, so
+    is the result: every period scores the same 7 115 pixels with the same bits (no batch of 100 000
+    has fewer than two survivors here, so the batch rule never bites), in candidate order; the
+    per-candidate status / probability of the LAST period equal the first period's.  Run by hand
+    (profiles/r04_huge_list.log); indices, block counts and offsets beyond int32 are what it checks."""
+    c = config2
+    w, x, y = c["w"], c["x"], c["y"]
+    reps = (1 << 31) // x.size + 1
+    N = reps * x.size
+    assert N > (1 << 31)
+    one = _lib.HipCands(x, y)
+    n1 = one.run(c["hm"], c["hf"], w, 0.5)
+    ox1, oy1, op1, os1 = one.fetch()
+    st1, pr1 = one.fetch_all()
+    del one
+    X, Y = np.tile(x, reps), np.tile(y, reps)
+    cd = _lib.HipCands(X, Y)
+    del X, Y
+    n = cd.run(c["hm"], c["hf"], w, 0.5)
+    assert n == reps * n1
+    ox, oy, op, osig = cd.fetch()
+    for got, want in ((ox, ox1), (oy, oy1), (op, op1), (osig, os1)):
+        got = got.reshape(reps, n1)
+        assert np.array_equal(gio.bits(got[0]) if got.dtype == np.float64 else got[0],
+                              gio.bits(want) if want.dtype == np.float64 else want)
+        assert (got == got[0]).all()
+    st, pr = cd.fetch_all()
+    assert np.array_equal(st[-x.size:], st1) and np.array_equal(gio.bits(pr[-x.size:]), gio.bits(pr1))
+    assert np.array_equal(st[:x.size], st1) and np.array_equal(gio.bits(pr[:x.size]), gio.bits(pr1))
