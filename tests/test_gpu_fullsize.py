@@ -395,3 +395,79 @@ def test_more_candidates_than_int32_holds(config2):
     st, pr = cd.fetch_all()
     assert np.array_equal(st[-x.size:], st1) and np.array_equal(gio.bits(pr[-x.size:]), gio.bits(pr1))
     assert np.array_equal(st[:x.size], st1) and np.array_equal(gio.bits(pr[:x.size]), gio.bits(pr1))
+
+
+def _wide_band_csr(n, B, seed):
+    """Symmetric band matrix with every cell |col - row| <= B stored (small integer counts, a third
+    of them explicit zeros), built row block by row block: 536 M stored cells at n = 120 000, B = 2 226."""
+    from scipy import sparse
+    rng = np.random.default_rng(seed)
+    V = rng.integers(0, 6, size=(B + 1, n), dtype=np.uint8)   # V[d, k] = M[k, k + d]
+    V[V == 5] = 0
+    V[V == 4] = 0
+    rows = np.arange(n, dtype=np.int64)
+    lo, hi = np.maximum(rows - B, 0), np.minimum(rows + B, n - 1)
+    indptr = np.concatenate([[0], np.cumsum(hi - lo + 1)])
+    assert indptr[-1] < 2 ** 31
+    indices = np.empty(indptr[-1], np.int32)
+    data = np.empty(indptr[-1], np.float64)
+    off = np.arange(-B, B + 1, dtype=np.int64)
+    for r0 in range(0, n, 512):
+        r = rows[r0:r0 + 512]
+        cols = r[:, None] + off[None, :]
+        ok = (cols >= 0) & (cols < n)
+        d = np.abs(off)[None, :].repeat(r.size, 0)[ok]
+        cc = cols[ok]
+        rr = np.broadcast_to(r[:, None], cols.shape)[ok]
+        sl = slice(indptr[r0], indptr[min(r0 + 512, n)])
+        indices[sl] = cc
+        data[sl] = V[d, np.minimum(rr, cc)]
+    return sparse.csr_matrix((data, indices, indptr.astype(np.int32)), shape=(n, n))
+
+
+@pytest.mark.skipif(os.environ.get("PK_TEST_HUGE") != "1",
+                    reason="opt-in (PK_TEST_HUGE=1): a 4.3 GB band, ~12 GB of host memory, ~2 minutes")
+def test_bands_on_either_side_of_the_32_bit_offsets(hip_lib):
+    """Maximum sizes: the clean extractor addresses the raw band and the quotient band behind it with
+    32-bit byte offsets (csrc/pk_api.hip: both must end below 4 GiB - 4 KiB).  One matrix, two bands:
+    2 236 diagonals x 120 000 columns x 8 B x 2 = 4 293 120 000 B (the clean kernel, offsets up to the
+    limit) and 2 237 diagonals (over: the general kernel with 64-bit addresses) -- 1.5 M candidates
+    spread over all diagonals incl. the last one and the last rows, against the oracle."""
+    # (B = the first band's last diagonal: the matrix holds nothing beyond what Chromosome's band filter,
+    # scoreUtils.py:30-33, would keep, so the oracle and the device read the same cells)
+    n, B, w = 120_000, 2_217 + 2 * 5 - 1, 5
+    M = _wide_band_csr(n, B, 11)
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w5_t100.npz"))
+    hf = _lib.HipForest(fo)
+    rng = np.random.default_rng(5)
+    L = hip_lib
+    for upper, want_clean in ((2_217, True), (2_218, False)):
+        assert ((upper + 4 * w - 1) * n * 16 < (1 << 32) - 4096) == want_clean
+        e = 3.0 / np.sqrt(1.0 + np.arange(upper + 2 * w + 1))
+        k = 1_500_000
+        d = rng.integers(6, upper + 1, k)
+        d[:2000] = upper                      # the last diagonal of the band
+        x = rng.integers(0, n, k)
+        x[2000:4000] = n - 1 - w - d[2000:4000]   # windows that end in the last rows / columns
+        x = np.minimum(x, n - 1 - d)
+        y = x + d
+        x, y = x.astype(np.int32), y.astype(np.int32)
+        hm = _lib.HipMatrix(M.indptr, M.indices, M.data, n, e, -2 * w + 1, upper + 2 * w - 1)
+        before = L.pk_get_option(b"stat_extract_clean"), L.pk_get_option(b"stat_extract_general")
+        cd = _lib.HipCands(x, y)
+        cd.run(hm, hf, w, 0.5)
+        after = L.pk_get_option(b"stat_extract_clean"), L.pk_get_option(b"stat_extract_general")
+        assert (after[0] > before[0], after[1] > before[1]) == (want_clean, not want_clean)
+        got, (st, pr) = cd.fetch(), cd.fetch_all()
+        want, st_ref, pr_ref = onp.score_all(M, e, w, {f: getattr(fo, f) for f in FlatForest.FIELDS}, 0.5, x, y)
+        # every candidate's status and probability (most windows of this noise pass the filters and
+        # score low), and the few scored pixels
+        assert np.array_equal(st != 0, st_ref != 0) and (st != 0).mean() > 0.3
+        assert np.array_equal(gio.bits(pr), gio.bits(pr_ref))
+        assert got[0].size == want[0].size
+        for a, b in zip(got, want):
+            a, b = np.asarray(a), np.asarray(b)
+            assert np.array_equal(gio.bits(a.astype(np.float64)) if a.dtype.kind == "f" else a.astype(np.int64),
+                                  gio.bits(b.astype(np.float64)) if b.dtype.kind == "f" else b.astype(np.int64))
+        del cd
+        del hm
