@@ -471,3 +471,43 @@ def test_bands_on_either_side_of_the_32_bit_offsets(hip_lib):
                                   gio.bits(b.astype(np.float64)) if b.dtype.kind == "f" else b.astype(np.int64))
         del cd
         del hm
+
+
+@pytest.mark.skipif(os.environ.get("PK_TEST_HUGE") != "1",
+                    reason="opt-in (PK_TEST_HUGE=1): matrices of more than a million bins")
+def test_more_bins_than_the_clean_extractors_24_bit_products_hold(hip_lib):
+    """Maximum sizes: the clean extractor multiplies (column offset) x (8 x leading dimension) with
+    v_mad_i32_i24 and is only used for ld < 2^20 (csrc/pk_extract.hip: `m->ld < (1 << 20)`).  A thin
+    band over 1 048 000 bins (ld = 1 048 000: the clean kernel, products up to 2^23 - 4 608) and over
+    1 100 000 bins (the general kernel), 2 M candidates each incl. the last rows, against the oracle."""
+    w, upper = 5, 20
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w5_t100.npz"))
+    hf = _lib.HipForest(fo)
+    rng = np.random.default_rng(9)
+    L = hip_lib
+    e = 3.0 / np.sqrt(1.0 + np.arange(upper + 2 * w + 1))
+    for n, want_clean in ((1_048_000, True), (1_100_000, False)):
+        assert (((n + 63) // 64 * 64) < (1 << 20)) == want_clean
+        M = _wide_band_csr(n, upper + 2 * w - 1, 3)
+        k = 2_000_000
+        d = rng.integers(6, upper + 1, k)
+        x = rng.integers(0, n, k)
+        x[:5000] = n - 1 - w - d[:5000] - rng.integers(0, 3, 5000)   # windows in the last rows / columns
+        x = np.clip(x, 0, n - 1 - d)
+        x, y = x.astype(np.int32), (x + d).astype(np.int32)
+        hm = _lib.HipMatrix(M.indptr, M.indices, M.data, n, e, -2 * w + 1, upper + 2 * w - 1)
+        before = L.pk_get_option(b"stat_extract_clean"), L.pk_get_option(b"stat_extract_general")
+        cd = _lib.HipCands(x, y)
+        cd.run(hm, hf, w, 0.5)
+        after = L.pk_get_option(b"stat_extract_clean"), L.pk_get_option(b"stat_extract_general")
+        assert (after[0] > before[0], after[1] > before[1]) == (want_clean, not want_clean)
+        got, (st, pr) = cd.fetch(), cd.fetch_all()
+        want, st_ref, pr_ref = onp.score_all(M, e, w, {f: getattr(fo, f) for f in FlatForest.FIELDS}, 0.5, x, y)
+        assert np.array_equal(st != 0, st_ref != 0) and (st != 0).mean() > 0.3
+        assert np.array_equal(gio.bits(pr), gio.bits(pr_ref))
+        assert got[0].size == want[0].size
+        for a, b in zip(got, want):
+            a, b = np.asarray(a), np.asarray(b)
+            assert np.array_equal(gio.bits(a.astype(np.float64)) if a.dtype.kind == "f" else a.astype(np.int64),
+                                  gio.bits(b.astype(np.float64)) if b.dtype.kind == "f" else b.astype(np.int64))
+        del cd, hm, M
