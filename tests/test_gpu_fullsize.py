@@ -425,8 +425,8 @@ def _wide_band_csr(n, B, seed):
     return sparse.csr_matrix((data, indices, indptr.astype(np.int32)), shape=(n, n))
 
 
-@pytest.mark.skipif(os.environ.get("PK_TEST_HUGE") != "1",
-                    reason="opt-in (PK_TEST_HUGE=1): a 4.3 GB band, ~12 GB of host memory, ~2 minutes")
+@pytest.mark.skipif(os.environ.get("PK_TEST_NO_BIG") == "1",
+                    reason="PK_TEST_NO_BIG=1: skips the 4.3 GB band (~12 GB of host memory, ~10 s)")
 def test_bands_on_either_side_of_the_32_bit_offsets(hip_lib):
     """Maximum sizes: the clean extractor addresses the raw band and the quotient band behind it with
     32-bit byte offsets (csrc/pk_api.hip: both must end below 4 GiB - 4 KiB).  One matrix, two bands:
@@ -473,8 +473,8 @@ def test_bands_on_either_side_of_the_32_bit_offsets(hip_lib):
         del hm
 
 
-@pytest.mark.skipif(os.environ.get("PK_TEST_HUGE") != "1",
-                    reason="opt-in (PK_TEST_HUGE=1): matrices of more than a million bins")
+@pytest.mark.skipif(os.environ.get("PK_TEST_NO_BIG") == "1",
+                    reason="PK_TEST_NO_BIG=1: skips the matrices of more than a million bins (~5 s)")
 def test_more_bins_than_the_clean_extractors_24_bit_products_hold(hip_lib):
     """Maximum sizes: the clean extractor multiplies (column offset) x (8 x leading dimension) with
     v_mad_i32_i24 and is only used for ld < 2^20 (csrc/pk_extract.hip: `m->ld < (1 << 20)`).  A thin
