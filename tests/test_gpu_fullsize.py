@@ -382,6 +382,15 @@ def test_more_candidates_than_int32_holds(config2):
     st1, pr1 = one.fetch_all()
     del one
     X, Y = np.tile(x, reps), np.tile(y, reps)
+    # pk_score with host buffers: the first call uploads the list whole, the second streams it chunk by
+    # chunk (1 027 launches) -- offsets beyond int32 in the upload schedule as well
+    for _ in range(2):
+        sx, sy, sp, ss = c["hm"].score(c["hf"], w, 0.5, X, Y)
+        assert sx.size == reps * n1
+        assert (sx.reshape(reps, n1) == ox1).all() and (sy.reshape(reps, n1) == oy1).all()
+        assert (gio.bits(sp).reshape(reps, n1) == gio.bits(op1)).all() and (gio.bits(ss).reshape(reps, n1) == gio.bits(os1)).all()
+    del sx, sy, sp, ss
+    c["hm"].__dict__.pop("_score_out", None)   # (the wrapper's N-sized result buffers)
     cd = _lib.HipCands(X, Y)
     del X, Y
     n = cd.run(c["hm"], c["hf"], w, 0.5)
