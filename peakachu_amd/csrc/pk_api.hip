@@ -271,6 +271,9 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
     } else if (!strcmp(name, "sub_chunk")) {
         if (value < 0) return PK_E_INVALID;
         o.sub_chunk = value;
+    } else if (!strcmp(name, "forest_q_rank12")) {
+        if (value < 0 || value > 2) return PK_E_INVALID;
+        o.forest_q_rank12 = value;
     } else if (!strcmp(name, "forest_warm")) {
         if (value < 0) return PK_E_INVALID;
         o.forest_warm = value;
@@ -338,6 +341,7 @@ static int64_t opt_read(const pk_options &o, const char *name)
     if (!strcmp(name, "forest_warm")) return o.forest_warm;
     if (!strcmp(name, "overlap")) return o.overlap;
     if (!strcmp(name, "sub_chunk")) return o.sub_chunk;
+    if (!strcmp(name, "forest_q_rank12")) return o.forest_q_rank12;
     if (!strcmp(name, "forest_pipe")) return o.forest_pipe;
     if (!strcmp(name, "forest_l2_tile")) return o.forest_l2_tile;
     if (!strcmp(name, "early_exit")) return o.early_exit;
@@ -376,7 +380,15 @@ extern "C" int pk_forest_set_option(pk_forest *f, const char *name, int64_t valu
     PK_DEV_LOCK(f ? f->device : 0);
     return f ? opt_assign(f->opt, name, value) : PK_E_INVALID;
 }
-extern "C" int64_t pk_forest_get_option(pk_forest *f, const char *name) { return f ? opt_read(f->opt, name) : -1; }
+extern "C" int64_t pk_forest_get_option(pk_forest *f, const char *name)
+{
+    if (!f || !name) return -1;
+    // read-only: what the rank plan of this forest came to (0 before the first scoring call plans it)
+    if (!strcmp(name, "stat_q_mode")) return f->q_state == 1 ? f->q_mode : -1;   // PK_Q_NARROW / _WIDE / _NARROW12
+    if (!strcmp(name, "stat_q_rows")) return f->q_state == 1 ? f->q_F : -1;
+    if (!strcmp(name, "stat_q_shape")) return f->q_state == 1 ? f->q_ch : -1;
+    return opt_read(f->opt, name);
+}
 
 extern "C" int pk_matrix_set_option(pk_matrix *m, const char *name, int64_t value)
 {

@@ -101,6 +101,8 @@ struct pk_options {
     int64_t forest_q = 1;       // rank-quantised tiles + 4-byte nodes (forest_q_kernel) when the forest fits
     int64_t forest_q_two = 1;   // 64-candidate shape: two rank tiles per workgroup trip (forest_q2_kernel)
     int64_t forest_q_help = 1;  // forest_q2_kernel: the waves that walk load their share of a group behind the first walk
+    int64_t forest_q_rank12 = 1; // rank image: the 12-bit rank word (4 095 thresholds per rank-tile row) when it keeps a
+                                 // forest in a larger workgroup shape than 11-bit ranks; 0 never, 2 whenever it saves rows
     int64_t forest_q_ch = 0;    // walks per lane of forest_q_kernel: 0 = auto (4 when F <= 128), 2, 4
     int64_t forest_q_wpt = 0;   // waves per tree with 4 walks per lane: 0 = auto (2), 1, 2
     int64_t forest_q_persist = 1; // rank kernel: persistent launch, this many workgroups per CU, each looping over
@@ -206,10 +208,12 @@ struct pk_forest {
     // rank image (forest_q_kernel): 0 = not tried, 1 = built, -1 = does not apply
     int q_state = 0;
     int q_slots = 0, q_ch = 0, q_n_grp = 0;
+    int q_mode = 0;        // node word format of the rank image (PK_Q_NARROW / _WIDE / _NARROW12): codes are r << 5,
+                           // r << 5, r << 4
     int q_F = 0;           // rows of a rank tile: F + the virtual features (pk_q_tables)
     int32_t *q_src = nullptr;  // device [q_F]: the float feature a row is quantized from
     int q_slot_bytes = 0;  // > 0: fixed tree slots, early staging
-    int64_t q_opt_slots = -1, q_opt_ch = -1, q_opt_wpt = -1, q_opt_early = -1;
+    int64_t q_opt_slots = -1, q_opt_ch = -1, q_opt_wpt = -1, q_opt_early = -1, q_opt_rank12 = -1;
     int q_max_group_bytes = 0;     // the largest tree group of the rank image
     struct pk_q_layout *q_layout = nullptr;
     uint4 *q_img = nullptr;        // device: tree images
@@ -254,6 +258,8 @@ int pk_launch_forest_img(pk_device_ctx *, pk_forest *f, const float *tiles, cons
 // ---- rank image (pk_qimage.hip builds it, pk_forest_q.hip quantizes tiles and walks it) ----
 #define PK_Q_CELLS 4096
 #define PK_Q_MAX_RANK 2047  // thresholds per rank-tile row (11-bit rank field); a feature with more is split
+#define PK_Q_MAX_RANK12 4095  // ... of the 12-bit rank field (PK_Q_NARROW12)
+enum { PK_Q_NARROW = 0, PK_Q_WIDE = 1, PK_Q_NARROW12 = 2 };  // node word formats (pk_qimage.hip)
 #define PK_Q_FTILE 8   // 128-candidate tiles per float32 tile handed to the quantizer
 struct pk_q_layout {
     int F, slots, ch;   // ch = 64-candidate blocks per workgroup: 2 (128 candidates), 4 (256), or 1 (64
@@ -268,6 +274,8 @@ struct pk_q_layout {
 };
 struct pk_q_out {
     int Fq = 0;                   // rows of the rank tile: the features + the virtual ones (pk_q_tables)
+    int max_rank = PK_Q_MAX_RANK; // thresholds per row the tables were made for
+    int mode = PK_Q_NARROW;       // node word format of `pairs` (pk_q_trees)
     std::vector<int32_t> qsrc;    // [Fq] the float feature a row is quantized from
     std::vector<int32_t> qfirst;  // [F] first virtual row of a feature with more than PK_Q_MAX_RANK thresholds, or -1
     std::vector<float> qthr;      // per row: sorted distinct float32 thresholds, laid end to end
@@ -296,9 +304,9 @@ void pk_q_fill_lut(pk_q_out *out, int F, const std::vector<int32_t> &qcell);
 inline int pk_q_stage_regs() { return 8; }  // uint4 staging registers per thread (1024) of forest_q_kernel
 bool pk_q_make_layout(int F, int slots, int ch, pk_q_layout *L);
 int pk_q_tables(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *feat,
-                const double *thr, pk_q_out *out);
+                const double *thr, int max_rank, pk_q_out *out);
 int pk_q_trees(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
-               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1, bool wide,
+               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1, int mode,
                pk_q_out *out);
 int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
                const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,

@@ -56,7 +56,7 @@ typedef __attribute__((address_space(3))) u64 lds_u64;
 // at the end; the rare lanes whose cell holds more than one threshold finish in a loop).
 template <int N>
 __device__ __forceinline__ void q_codes(const float (&x)[N], unsigned (&code)[N], const float *thr,
-                                        const unsigned *lut, float lo, float inv)
+                                        const unsigned *lut, float lo, float inv, int shift)
 {
     unsigned e[N], r[N];
     float th[N];
@@ -84,7 +84,7 @@ __device__ __forceinline__ void q_codes(const float (&x)[N], unsigned (&code)[N]
         }
     }
 #pragma unroll
-    for (int i = 0; i < N; i++) code[i] = x[i] != x[i] ? 0xFFFFu : r[i] << 5;
+    for (int i = 0; i < N; i++) code[i] = x[i] != x[i] ? 0xFFFFu : r[i] << shift;  // (5; 4 for the 12-bit rank field)
 }
 
 // the cell of every threshold, computed where the quantizer computes the cells of the features
@@ -102,15 +102,17 @@ template <int TP>
 __global__ __launch_bounds__(1024) void quantize_tiles_kernel(
     const float *__restrict__ tiles, int64_t n_tiles, int Fs, int F, const int32_t *__restrict__ qsrc,
     const float *__restrict__ qthr, const int32_t *__restrict__ qoff, const unsigned *__restrict__ qlut,
-    const float *__restrict__ qpar, unsigned short *__restrict__ qtiles, int tile64)
+    const float *__restrict__ qpar, unsigned short *__restrict__ qtiles, int tile64, int shift)
 {
     // Fs rows in a float tile, F >= Fs rows in a rank tile: row f is made from float feature qsrc[f]
     // (a feature with more than 2 047 thresholds has virtual features behind the real ones)
-    __shared__ float thr[2048];  // n <= 2047 entries + padding
+    // shift = 5: 11-bit ranks, n <= 2047 thresholds per row; 4: the 12-bit rank field, n <= 4095
+    __shared__ float thr[4096];  // n entries + padding (filled as far as the rank field counts)
     __shared__ unsigned lut[PK_Q_CELLS];
     const int f = blockIdx.x, fs = qsrc[f];
     const int o = qoff[f], n = qoff[f + 1] - o;
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) thr[i] = i < n ? qthr[o + i] : __builtin_inff();
+    const int thr_fill = shift == 4 ? 4096 : 2048;
+    for (int i = threadIdx.x; i < thr_fill; i += blockDim.x) thr[i] = i < n ? qthr[o + i] : __builtin_inff();
     for (int i = threadIdx.x; i < PK_Q_CELLS; i += blockDim.x) lut[i] = qlut[(size_t)f * PK_Q_CELLS + i];
     const float lo = qpar[2 * f], inv = qpar[2 * f + 1];
     __syncthreads();
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(1024) void quantize_tiles_kernel(
             x[2 * k] = src[(size_t)kk * kstride];
             x[2 * k + 1] = src[(size_t)kk * kstride + 64];
         }
-        q_codes<2 * TP>(x, code, thr, lut, lo, inv);
+        q_codes<2 * TP>(x, code, thr, lut, lo, inv, shift);
         // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
         // half): the two walks of a lane read the same LDS bank, different lanes different banks
         if (tile64) {
@@ -178,8 +180,10 @@ __device__ __forceinline__ unsigned q_pair_index(unsigned w)
 // workgroup: code address = (c >> 1) * 32 KiB + feature * 256 + lane * 4 + (c & 1) * 2
 // X0: LDS offset of the rank tile walks 0 and 1 read; walks 2 and 3 read the one HALF1
 // bytes further (both are immediate offsets of the ds_read)
+// nsplit (narrow word, WITH_NAN only): 0 = "NaN goes left" is bit 20 of the word; otherwise the 12-bit rank
+// form, whose bit 20 belongs to the rank: the node's pair lies at or beyond the tree's split (pk_qimage.hip)
 template <int CH, int X0, int HALF1, bool WITH_NAN, bool ALL_LEFT>
-__device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsigned lk0, unsigned lk1)
+__device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsigned lk0, unsigned lk1, unsigned nsplit = 0u)
 {
     unsigned xv[CH];
     u64 pr[CH];
@@ -201,7 +205,9 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
         // spare: its nodes that send NaN left have their child pairs at or beyond the tree's `split`
         // (pk_qimage.hip), handed in through lk1 (a one-walk lane has no second code offset)
         if (WITH_NAN)
-            gl = gl | ((xv[c] == 0xFFFFu) & (WIDE ? ((w[c] >> 10) & 0x7FFu) >= lk1 : (w[c] & (1u << 20)) != 0));
+            gl = gl | ((xv[c] == 0xFFFFu) & (WIDE     ? ((w[c] >> 10) & 0x7FFu) >= lk1
+                                             : nsplit ? ((w[c] >> 8) & 0xFFFu) >= nsplit
+                                                      : (w[c] & (1u << 20)) != 0));
         if (ALL_LEFT) gl = gl | (xv[c] < 0x10000u);  // timing ablation: every lane takes the same path
         w[c] = gl ? (unsigned)pr[c] : (unsigned)(pr[c] >> 32);
     }
@@ -213,7 +219,7 @@ __device__ __forceinline__ void q_level(unsigned (&w)[CH], unsigned tbase, unsig
 // the first, and everybody waits for them at the barrier.
 template <int CH, int X0, int HALF1, bool WITH_NAN, bool ALL_LEFT = false, int POS = -1>
 __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase, unsigned lk0,
-                                       unsigned lk1, double (&v)[CH])
+                                       unsigned lk1, double (&v)[CH], unsigned nsplit = 0u)
 {
     unsigned w[CH];
 #pragma unroll
@@ -221,8 +227,8 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
     int d = depth;
 #define Q_TWO_LEVELS()                                                  \
     do {                                                                \
-        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1); \
-        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1); \
+        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1, nsplit); \
+        q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1, nsplit); \
     } while (0)
     if (POS >= 0) {
         // (round 2: four levels per priority measured best: 3.85 ms; two 3.91, one 3.93, none 4.01)
@@ -263,7 +269,7 @@ __device__ __forceinline__ void q_walk(unsigned root, int depth, unsigned tbase,
         for (; d >= 2; d -= 2) Q_TWO_LEVELS();  // two levels per trip: a taken branch costs an instruction refetch
     }
 #undef Q_TWO_LEVELS
-    if (d) q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1);
+    if (d) q_level<CH, X0, HALF1, WITH_NAN, ALL_LEFT>(w, tbase, lk0, lk1, nsplit);
     if (POS >= 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int c = 0; c < CH; c++)  // the leaf's float64 value follows its pair
@@ -520,7 +526,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
                 const unsigned root = (unsigned)tt.z;
                 // lanes without a live candidate walk along (their values are not stored)
 #define Q_WALK_POS(X0_, NAN_, POS_) \
-    q_walk<NCH, X0_, HALF1, NAN_, false, POS_>(root, tt.y & 0xFFFF, tbase, lk0, CH == 1 ? (unsigned)tt.y >> 16 : lk1, v)
+    q_walk<NCH, X0_, HALF1, NAN_, false, POS_>(root, tt.y & 0xFFFF, tbase, lk0, CH == 1 ? (unsigned)tt.y >> 16 : lk1, v, \
+                                               CH == 1 ? 0u : (unsigned)tt.y >> 16)
 #define Q_WALK(X0_, NAN_)                              \
     do {                                               \
         if (dbg & 32) Q_WALK_POS(X0_, NAN_, -1);       \
@@ -755,7 +762,7 @@ __device__ __forceinline__ void qr_issue_tile(unsigned tmask, const char *tb0, c
 // the up to three surplus levels change nothing.
 template <int X0, int HALF1, bool WITH_NAN, int POS, int NR>
 __device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase, unsigned lk0, unsigned lk1,
-                                        double (&v)[2], const char *gb, unsigned voff)
+                                        double (&v)[2], const char *gb, unsigned voff, unsigned nsplit = 0u)
 {
     unsigned w[2] = {root, root};
     constexpr int PT[4][6] = {PK_Q_PRIO_TAB};
@@ -779,8 +786,8 @@ __device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase
 #define QR_TWO(k_)                                                     \
     do {                                                               \
         QR_SLOTS_AT(k_);                                               \
-        q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);    \
-        q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1);    \
+        q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1, nsplit);    \
+        q_level<2, X0, HALF1, WITH_NAN, false>(w, tbase, lk0, lk1, nsplit);    \
     } while (0)
     if (__builtin_expect(depth >= 16, 1)) {
         QR_SETPRIO(PT[PP][0]);
@@ -959,8 +966,10 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
                 double v[NCH];
                 const unsigned tbase = (unsigned)(img_off + tt.x);
                 const unsigned root = (unsigned)tt.z;
-                if (__builtin_expect(wave_nan, 0)) qr_walk<X0, HALF1, true, POS, NR>(root, tt.y, tbase, lk0, lk1, v, gb, voff);
-                else qr_walk<X0, HALF1, false, POS, NR>(root, tt.y, tbase, lk0, lk1, v, gb, voff);
+                // (tt.y: levels to walk | the tree's split << 16, non-zero for the 12-bit rank word only)
+                if (__builtin_expect(wave_nan, 0))
+                    qr_walk<X0, HALF1, true, POS, NR>(root, tt.y & 0xFFFF, tbase, lk0, lk1, v, gb, voff, (unsigned)tt.y >> 16);
+                else qr_walk<X0, HALF1, false, POS, NR>(root, tt.y & 0xFFFF, tbase, lk0, lk1, v, gb, voff);
 #pragma unroll
                 for (int c = 0; c < NCH; c++)
                     if (walk[c])
@@ -1365,18 +1374,43 @@ static int q_plan_build(pk_forest *f)
     // the rank tables first: they say how many ROWS the rank tile has (Fq = the features + the virtual
     // features of those with more than 2 047 thresholds, pk_qimage.hip), and the shape follows from that
     pk_q_out best;
-    int rc = pk_q_tables(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_feat.data(), f->h_thr.data(), &best);
+    int rc = pk_q_tables(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_feat.data(), f->h_thr.data(), PK_Q_MAX_RANK, &best);
     if (rc) return rc;
-    const int Fq = best.Fq;
-    int ch = (int)f->opt.forest_q_ch;
+    int Fq = best.Fq;
+    int mode = PK_Q_NARROW;
     // 256 candidates per workgroup while two rank tiles of 256 B per row fit 64 KiB of
     // offsets, 128 up to 255 rows (the narrow word's feature byte), 64 candidates and the
     // wide word beyond (w = 11: 529 features)
-    if (ch == 0) ch = Fq <= 192 ? 4 : Fq <= 255 ? 2 : 1;
+    auto shape_of = [](int rows) { return rows <= 192 ? 4 : rows <= 255 ? 2 : 1; };
+    int ch = (int)f->opt.forest_q_ch;
+    if (ch == 0) ch = shape_of(Fq);
+    // Features with more than 2 047 thresholds cost rows (one per further 2 047).  When the rows push the
+    // forest out of a shape that 12-bit ranks (4 095 per row) would keep -- a 100-tree forest fitted on
+    // 90 000 windows: 2 154 thresholds per feature, 220 rows against 121 -- the 12-bit narrow word is used
+    // (option forest_q_rank12: 0 never, 1 when it keeps a larger shape (default), 2 whenever rows are saved).
+    if (f->opt.forest_q_rank12 != 0 && F <= 255 && Fq > F) {
+        pk_q_out alt;
+        if (pk_q_tables(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_feat.data(), f->h_thr.data(), PK_Q_MAX_RANK12, &alt) == PK_OK &&
+            alt.Fq < Fq && alt.Fq <= 255) {
+            const int ch12 = f->opt.forest_q_ch ? (int)f->opt.forest_q_ch : shape_of(alt.Fq);
+            const bool fits12 = !((ch12 == 4 && alt.Fq > 192) || (ch12 == 2 && alt.Fq > 255)) && ch12 != 1;
+            if (fits12 && (f->opt.forest_q_rank12 == 2 || ch12 > shape_of(Fq) || Fq > 255) &&
+                pk_q_trees(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(), f->h_feat.data(), f->h_thr.data(),
+                           f->h_miss.empty() ? nullptr : f->h_miss.data(), f->h_p1.data(), PK_Q_NARROW12, &alt) == PK_OK) {
+                best = alt;
+                Fq = best.Fq;
+                ch = ch12;
+                mode = PK_Q_NARROW12;
+            }
+        }
+    }
     if ((ch == 4 && Fq > 192) || (ch == 2 && Fq > 255)) return PK_E_UNSUPPORTED;
-    rc = pk_q_trees(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(), f->h_feat.data(),
-                    f->h_thr.data(), f->h_miss.empty() ? nullptr : f->h_miss.data(), f->h_p1.data(), ch == 1, &best);
-    if (rc) return rc;  // the forest does not fit the format at all, or is malformed
+    if (mode != PK_Q_NARROW12) {
+        mode = ch == 1 ? PK_Q_WIDE : PK_Q_NARROW;
+        rc = pk_q_trees(T, F, f->h_tree_off.data(), f->h_left.data(), f->h_right.data(), f->h_feat.data(),
+                        f->h_thr.data(), f->h_miss.empty() ? nullptr : f->h_miss.data(), f->h_p1.data(), mode, &best);
+        if (rc) return rc;  // the forest does not fit the format at all, or is malformed
+    }
     // tables and trees exist once (they do not depend on the layout); only the grouping is tried
     // for every slot count
     pk_q_layout bestL;
@@ -1437,6 +1471,7 @@ static int q_plan_build(pk_forest *f)
     f->q_slots = best_slots;
     f->q_slot_bytes = slot_bytes;
     f->q_ch = ch;
+    f->q_mode = mode;
     f->q_F = Fq;
     f->q_n_grp = best.n_grp;
     f->q_max_group_bytes = 0;
@@ -1474,7 +1509,8 @@ static int q_plan_build(pk_forest *f)
 int pk_forest_q_plan(pk_forest *f)
 {
     if (f->q_state != 0 && (f->q_opt_slots != f->opt.forest_slots || f->q_opt_ch != f->opt.forest_q_ch ||
-                            f->q_opt_wpt != f->opt.forest_q_wpt || f->q_opt_early != f->opt.forest_q_early)) {
+                            f->q_opt_wpt != f->opt.forest_q_wpt || f->q_opt_early != f->opt.forest_q_early ||
+                            f->q_opt_rank12 != f->opt.forest_q_rank12)) {
         q_free(f);
         f->q_state = 0;
     }
@@ -1483,6 +1519,7 @@ int pk_forest_q_plan(pk_forest *f)
         f->q_opt_ch = f->opt.forest_q_ch;
         f->q_opt_wpt = f->opt.forest_q_wpt;
         f->q_opt_early = f->opt.forest_q_early;
+        f->q_opt_rank12 = f->opt.forest_q_rank12;
         const int rc = q_plan_build(f);
         f->q_state = rc == PK_OK ? 1 : -1;
         if (rc != PK_OK) q_free(f);
@@ -1557,7 +1594,7 @@ int pk_launch_quant_q(pk_device_ctx *ctx, hipStream_t st, pk_forest *f, const fl
     const unsigned bt = L.ch == 1 ? 512u : 1024u;
     hipLaunchKernelGGL(quantize_tiles_kernel<4>, dim3((unsigned)F, (unsigned)split), dim3(bt), 0, st, tiles,
                        n_tiles, f->F, F, f->q_src, f->q_thr, f->q_off, f->q_lut, f->q_par,
-                       ctx->q_tiles + (size_t)t0 * F * 128, L.ch == 1 ? 1 : 0);
+                       ctx->q_tiles + (size_t)t0 * F * 128, L.ch == 1 ? 1 : 0, f->q_mode == PK_Q_NARROW12 ? 4 : 5);
     PK_HIP(hipGetLastError());
     return PK_OK;
 }

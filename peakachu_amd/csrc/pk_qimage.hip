@@ -22,6 +22,10 @@
 //   child pair: the left child's word, then the right child's word.
 //   A feature code is r(x) << 5 (NaN: 0xFFFF), so `code <= (word >> 16)` is
 //   `r(x) <= k` whatever bits 20..16 hold.
+//   (round 4, more than 2 047 thresholds on features of a <= 255-row forest: the RANK-12 narrow word
+//   [31:20] rank k (12 bits) | [19:8] pair | [7:0] feature with codes r(x) << 4 and the wide word's NaN
+//   rule -- a forest fitted on 90 000 windows has 2 154 thresholds per feature: 121 rows instead of
+//   220, so it keeps the 256-candidate kernel)
 // Leaf word: rank field 0x7FF (every code compares <=: a leaf always goes left),
 //   bit 20 set (NaN goes left too), pair = the leaf's own block [leaf word][0][float64
 //   value]: a walk that has reached a leaf stays on it however many more levels it is
@@ -80,11 +84,17 @@ struct q_tree {
 //          holding NaN codes makes (round 4; rounds 2-3 sent such forests to the float kernels: 44 ms
 //          instead of 11 for the fitted 500-tree forest of configs[4]).  The four pairs of two pure
 //          leaves exist on either side of the split.  *split_out receives it (0 for the narrow word).
+// mode: PK_Q_NARROW (11-bit rank, NaN flag in bit 20), PK_Q_WIDE, PK_Q_NARROW12 (12-bit rank at [31:20], pair
+// and feature where the narrow word has them, NaN by the pair's side of `split` like the wide word)
 int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> *out, uint32_t *root,
-                int *depth, std::string *err, bool wide, int *split_out = nullptr)
+                int *depth, std::string *err, int mode, int *split_out = nullptr)
 {
+    const bool wide = mode == PK_Q_WIDE;
+    const bool two_sided = mode != PK_Q_NARROW;   // "NaN goes left" = the pair lies at or beyond `split`
     const int pair_shift = wide ? 10 : 8;
     const int max_pairs = wide ? 2048 : 4096;
+    const int rank_shift = mode == PK_Q_NARROW12 ? 20 : 21;
+    const uint32_t rank_leaf = mode == PK_Q_NARROW12 ? (0xFFFu << 20) : (0x7FFu << 21);
     const int const_pairs = Q_CONST_PAIRS;
     const int nn = t.nn;
     std::vector<int> order, dep((size_t)nn, 0), stack;
@@ -125,14 +135,14 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
     std::vector<int> by_level(order);
     std::stable_sort(by_level.begin(), by_level.end(),
                      [&](int a, int b) { return dep[(size_t)a] < dep[(size_t)b]; });
-    for (int side = 0; side < (wide ? 2 : 1); side++) {
+    for (int side = 0; side < (two_sided ? 2 : 1); side++) {
         if (side == 1) {
             split = next;   // the second set of pure/pure pairs opens the "NaN goes left" side
             next += 4;
         }
         for (int n : by_level) {
-            const int want = (wide && t.miss && t.miss[n]) ? 1 : 0;
-            if (wide && want != side) continue;
+            const int want = (two_sided && t.miss && t.miss[n]) ? 1 : 0;
+            if (two_sided && want != side) continue;
             const bool pl = t.kind(t.left[n]) >= 2, pr = t.kind(t.right[n]) >= 2;
             if (pl && pr) {
                 const int vl = t.kind(t.left[n]) - 2, vr = t.kind(t.right[n]) - 2;
@@ -166,7 +176,7 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
     if (next & 1) next++;  // whole 16-byte units
     if (next > max_pairs) return -2;
     auto leaf_word = [&](int block) {
-        return (wide ? (0x7FFu << 21) : Q_LEAF) | ((uint32_t)block << pair_shift);
+        return (two_sided ? rank_leaf : Q_LEAF) | ((uint32_t)block << pair_shift);
     };
     auto word_of = [&](int v) -> uint32_t {
         if (t.left[v] == -1) return leaf_word(lblock[(size_t)v]);
@@ -179,8 +189,8 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
             f = part;
         const float *b = tab.qthr.data() + tab.qoff[(size_t)f], *e = tab.qthr.data() + tab.qoff[(size_t)f + 1];
         const int k = (int)(std::lower_bound(b, e, t32) - b);  // t32 is in the table by construction
-        uint32_t w = ((uint32_t)k << 21) | ((uint32_t)pairi[(size_t)v] << pair_shift) | (uint32_t)f;
-        if (!wide && t.miss && t.miss[v]) w |= 1u << 20;
+        uint32_t w = ((uint32_t)k << rank_shift) | ((uint32_t)pairi[(size_t)v] << pair_shift) | (uint32_t)f;
+        if (!two_sided && t.miss && t.miss[v]) w |= 1u << 20;
         return w;
     };
     *root = word_of(0);
@@ -192,7 +202,7 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
         uint64_t b;
         memcpy(&b, &v, 8);
         // (wide word: a leaf's block index carries no flag, so both ways lead back to the leaf)
-        P[p] = make_uint2(leaf_word(p), wide ? leaf_word(p) : 0);
+        P[p] = make_uint2(leaf_word(p), two_sided ? leaf_word(p) : 0);
         P[p + 1] = make_uint2((uint32_t)(b & 0xffffffffu), (uint32_t)(b >> 32));
     };
     put_block(0, 0.0);
@@ -202,12 +212,12 @@ int q_emit_tree(const q_tree &t, int F, const pk_q_out &tab, std::vector<uint2> 
                                  make_uint2(leaf_word(0), leaf_word(0)), make_uint2(leaf_word(2), leaf_word(2))};
         for (int c = 0; c < 4; c++) {
             P[4 + c] = combos[c];
-            if (wide) P[split + c] = combos[c];
+            if (two_sided) P[split + c] = combos[c];
         }
     }
     for (auto &bk : blocks) put_block(bk.first, bk.second);
     for (int n : order)
-        if (pairi[(size_t)n] >= const_pairs && !(wide && pairi[(size_t)n] >= split && pairi[(size_t)n] < split + 4))
+        if (pairi[(size_t)n] >= const_pairs && !(two_sided && pairi[(size_t)n] >= split && pairi[(size_t)n] < split + 4))
             P[pairi[(size_t)n]] = make_uint2(word_of(t.left[n]), word_of(t.right[n]));
     return next;
 }
@@ -305,9 +315,10 @@ void pk_q_fill_lut(pk_q_out *out, int F, const std::vector<int32_t> &qcell)
 // exact, because the code of part c is clamp(r(x) - 2047 c, 0, 2047) by construction.  (Round 4;
 // rounds 2-3 sent such forests to the float kernels.)
 int pk_q_tables(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *feat,
-                const double *thr, pk_q_out *out)
+                const double *thr, int max_rank, pk_q_out *out)
 {
     *out = pk_q_out();
+    out->max_rank = max_rank;
     if (T <= 0 || F < 1 || F > 1023) return PK_E_UNSUPPORTED;
     std::vector<std::vector<float>> per((size_t)F);
     for (int t = 0; t < T; t++)
@@ -329,14 +340,14 @@ int pk_q_tables(int T, int F, const int32_t *tree_off, const int32_t *left, cons
         std::sort(p.begin(), p.end());
         p.erase(std::unique(p.begin(), p.end()), p.end());  // -0.0 == 0.0: one entry
         out->qsrc[(size_t)f] = f;
-        rows[(size_t)f].assign(p.begin(), p.begin() + (ptrdiff_t)std::min<size_t>(p.size(), PK_Q_MAX_RANK));
+        rows[(size_t)f].assign(p.begin(), p.begin() + (ptrdiff_t)std::min<size_t>(p.size(), (size_t)max_rank));
     }
     for (int f = 0; f < F; f++) {
         const auto &p = per[(size_t)f];
-        for (size_t o = PK_Q_MAX_RANK; o < p.size(); o += PK_Q_MAX_RANK) {
+        for (size_t o = (size_t)max_rank; o < p.size(); o += (size_t)max_rank) {
             if (out->qfirst[(size_t)f] < 0) out->qfirst[(size_t)f] = (int32_t)rows.size();
             out->qsrc.push_back(f);
-            rows.emplace_back(p.begin() + (ptrdiff_t)o, p.begin() + (ptrdiff_t)std::min(p.size(), o + PK_Q_MAX_RANK));
+            rows.emplace_back(p.begin() + (ptrdiff_t)o, p.begin() + (ptrdiff_t)std::min(p.size(), o + (size_t)max_rank));
         }
     }
     const int Fq = (int)rows.size();
@@ -374,10 +385,12 @@ int pk_q_tables(int T, int F, const int32_t *tree_off, const int32_t *left, cons
 // The tree images (they depend on the word format, not on the layout): `wide` = the 10-bit feature
 // field of the 64-candidate shape.  PK_E_UNSUPPORTED when a tree does not fit the pair field.
 int pk_q_trees(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
-               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1, bool wide,
+               const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1, int mode,
                pk_q_out *out)
 {
-    if (out->Fq > (wide ? 1023 : 255)) return PK_E_UNSUPPORTED;
+    if (out->Fq > (mode == PK_Q_WIDE ? 1023 : 255)) return PK_E_UNSUPPORTED;
+    if ((mode == PK_Q_NARROW12) != (out->max_rank == PK_Q_MAX_RANK12)) return PK_E_INVALID;  // (tables of the other width)
+    out->mode = mode;
     out->pairs.clear();
     // tree images
     out->troot.assign((size_t)T, 0);
@@ -394,7 +407,7 @@ int pk_q_trees(int T, int F, const int32_t *tree_off, const int32_t *left, const
         }
         std::string err;
         const int np = q_emit_tree(tv, F, *out, &out->pairs, &out->troot[(size_t)t],
-                                   &out->tdepth[(size_t)t], &err, wide, &tsplit[(size_t)t]);
+                                   &out->tdepth[(size_t)t], &err, mode, &tsplit[(size_t)t]);
         if (np == -1) {
             pk_set_error("forest rank image: tree %d: %s", t, err.c_str());
             return PK_E_INVALID;
@@ -418,10 +431,10 @@ int pk_q_build(int T, int F, const int32_t *tree_off, const int32_t *left, const
                const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1,
                const pk_q_layout &L, pk_q_out *out)
 {
-    int rc = pk_q_tables(T, F, tree_off, left, feat, thr, out);
+    int rc = pk_q_tables(T, F, tree_off, left, feat, thr, PK_Q_MAX_RANK, out);
     if (rc) return rc;
     if (L.F != out->Fq) return PK_E_UNSUPPORTED;  // (the layout was made for another row count)
-    rc = pk_q_trees(T, F, tree_off, left, right, feat, thr, miss, p1, L.ch == 1, out);
+    rc = pk_q_trees(T, F, tree_off, left, right, feat, thr, miss, p1, L.ch == 1 ? PK_Q_WIDE : PK_Q_NARROW, out);
     if (rc) return rc;
     return pk_q_group(out, L);
 }
@@ -487,10 +500,15 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
         return PK_E_INVALID;
     }
     const bool fixed_slots = (ch & 0x100) != 0;
+    const bool rank12 = (ch & 0x200) != 0;  // the 12-bit rank field (PK_Q_NARROW12; ch = 2 or 4 only)
     ch &= 0xFF;
+    if (rank12 && ch == 1) {
+        pk_set_error("pk_debug_forest_qimage: the wide word has no 12-bit rank form");
+        return PK_E_INVALID;
+    }
     pk_q_layout L;
     pk_q_out out;
-    int rc = pk_q_tables(T, F, tree_off, left, feat, thr, &out);
+    int rc = pk_q_tables(T, F, tree_off, left, feat, thr, rank12 ? PK_Q_MAX_RANK12 : PK_Q_MAX_RANK, &out);
     if (rc == PK_OK && (out.Fq > cap_rows || !qsrc)) {
         pk_set_error("pk_debug_forest_qimage: %d rank-tile rows, room for %d", out.Fq, (int)cap_rows);
         return PK_E_NOMEM;
@@ -500,7 +518,9 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
                      slots, ch);
         return PK_E_UNSUPPORTED;
     }
-    if (rc == PK_OK) rc = pk_q_trees(T, F, tree_off, left, right, feat, thr, miss_left, p1, L.ch == 1, &out);
+    if (rc == PK_OK)
+        rc = pk_q_trees(T, F, tree_off, left, right, feat, thr, miss_left, p1,
+                        L.ch == 1 ? PK_Q_WIDE : rank12 ? PK_Q_NARROW12 : PK_Q_NARROW, &out);
     if (rc == PK_OK) rc = pk_q_group(&out, L);
     if (fixed_slots && (rc == PK_OK || (rc == PK_E_UNSUPPORTED && !out.toff.empty()))) {
         pk_q_fixed_slots(out, slots, &L);
@@ -519,6 +539,7 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
                        L.slot_bytes};
     for (int i = 0; i < 17; i++) lay[9 + i] = L.slot_off[i];
     lay[26] = out.Fq;
+    lay[27] = out.mode;
     memcpy(layout8, lay, sizeof(lay));
     memcpy(qsrc, out.qsrc.data(), out.qsrc.size() * sizeof(int32_t));
     memcpy(qoff, out.qoff.data(), out.qoff.size() * sizeof(int32_t));

@@ -46,7 +46,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
     L = _lib.require_device()
     t0 = time.time()
-    paths = {"rank": 0, "other": 0}
+    paths = {"rank": 0, "other": 0, "rank12": 0}
     for case in range(n_cases):
         F = int(rng.choice([1, 2, 9, 25, 49, 81, 121, 169, 192, 193, 225, 255, 256, 300, 529, 768, 900, 1023, 1024, 1100]))
         T = int(rng.choice([1, 2, 3, 7, 8, 9, 16, 17, 50, 100, 300]))
@@ -59,6 +59,9 @@ def main():
             pool = rng.random(int(rng.choice([1, 3, 50])))
         if rng.random() < 0.07:  # > 2047 thresholds on a feature: the rank format must give way
             F, T, max_nodes, depth = int(rng.choice([1, 2])), 3, 9001, 40
+        elif rng.random() < 0.12:  # 2 048 .. 4 095 thresholds on the features: one row each with 12-bit ranks, two with 11
+            F, T, max_nodes, depth = int(rng.choice([2, 3, 5, 9])), int(rng.choice([4, 8, 16])), 2501, 25
+            miss = float(rng.choice([0.0, 0.3, 0.5]))
         if T * max_nodes > 400000:
             T = max(1, 400000 // max_nodes)
         fo = random_forest(rng, F, T, max_nodes, depth, miss, pool, comb)
@@ -86,11 +89,15 @@ def main():
             opts["forest_slots"] = int(rng.choice([2, 3, 5, 8, 11, 16]))
         if rng.random() < 0.1:
             opts["forest_q"] = 0
+        if rng.random() < 0.5:  # the 12-bit rank word: never / when it keeps a larger shape (default) / whenever it saves rows
+            opts["forest_q_rank12"] = int(rng.choice([0, 2, 2]))
         if F > 255 and rng.random() < 0.4:  # the wide word: one tile or two per trip, walkers loading early or late
             opts[str(rng.choice(["forest_q_two", "forest_q_help"]))] = 0
         L.pk_prof_enable(1); L.pk_prof_reset()
         try:
-            p = _lib.HipForest(ff, options=opts).predict(X)   # (options are this handle's own)
+            hf = _lib.HipForest(ff, options=opts)   # (options are this handle's own)
+            p = hf.predict(X)
+            q_mode = hf.get_option("stat_q_mode")
         except _lib.PeakachuHipError as e:
             L.pk_prof_enable(0)
             if F > 1023 or "unsupported" in str(e).lower() or "does not fit" in str(e).lower():
@@ -101,9 +108,11 @@ def main():
         used_rank = _lib.prof_get("quant")[1] > 0
         L.pk_prof_enable(0)
         paths["rank" if used_rank else "other"] += 1
+        if used_rank and q_mode == 2:
+            paths["rank12"] += 1
         ok = np.array_equal(p.view(np.uint64), ref.view(np.uint64))
         print("case %3d F=%4d T=%3d nodes<=%4d depth=%2d comb=%d miss=%.1f N=%5d %s: %s %s" % (
-            case, F, T, max_nodes, depth, comb, miss, N, opts, "rank" if used_rank else "float", "ok" if ok else "MISMATCH"))
+            case, F, T, max_nodes, depth, comb, miss, N, opts, ("rank12" if q_mode == 2 else "rank") if used_rank else "float", "ok" if ok else "MISMATCH"))
         if not ok:
             bad = np.flatnonzero(p.view(np.uint64) != ref.view(np.uint64))
             print("   first mismatches:", bad[:5], p[bad[:5]], ref[bad[:5]])

@@ -54,7 +54,7 @@ def build_qimage(fo, F, slots, ch):
     if rc != 0:
         return rc, _lib.last_error()
     Fq = int(lay[26])
-    return 0, dict(lay=lay, Fq=Fq, qsrc=qsrc[:Fq], qoff=qoff[:Fq + 1], qthr=qthr,
+    return 0, dict(lay=lay, Fq=Fq, mode=int(lay[27]), qsrc=qsrc[:Fq], qoff=qoff[:Fq + 1], qthr=qthr,
                    qlut=qlut[:Fq * CELLS].reshape(Fq, CELLS), qpar=qpar[:Fq * 2].reshape(Fq, 2),
                    pairs=pairs[:npairs.value], gtab=gtab[:4 * (ng.value + 2)].reshape(-1, 4),
                    n_grp=ng.value, ttab=ttab.reshape(T, 4))
@@ -72,7 +72,8 @@ def quantize(img, X):
         for f in range(F):
             thr = img["qthr"][img["qoff"][f]:img["qoff"][f + 1]]
             n = thr.size
-            assert n <= 2047
+            rank12 = img.get("mode", 0) == 2     # the 12-bit rank word: 4 095 thresholds per row, codes r << 4
+            assert n <= (4095 if rank12 else 2047)
             lo, inv = img["qpar"][f]
             x = X[:, img["qsrc"][f]]
             cf = (x - lo) * inv                              # float32 arithmetic, like pk_q_cell
@@ -92,7 +93,7 @@ def quantize(img, X):
             # the definition: number of distinct thresholds below x
             ok = ~np.isnan(x)
             assert np.array_equal(r[ok], np.searchsorted(thr, x[ok], side="left"))
-            codes[:, f] = np.where(np.isnan(x), 0xFFFF, r << 5)
+            codes[:, f] = np.where(np.isnan(x), 0xFFFF, r << (4 if rank12 else 5))
     return codes, steps
 
 
@@ -104,6 +105,10 @@ def walk_qimage(img, codes, T):
     # goes left" = the node's child pair lies at or beyond the tree's split (the high half of the
     # tree table's depth word); a NaN code 0xFFFF is above every rank: otherwise it goes right
     wide = ch == 1
+    # mode 2 (round 4): the narrow word with a 12-bit rank field [31:20]; pair and feature where the narrow
+    # word has them, NaN by the pair's side of the split like the wide word
+    rank12 = img.get("mode", 0) == 2
+    assert not (wide and rank12) and img.get("mode", 0) == (1 if wide else 2 if rank12 else 0)
     fmask, pshift, pmask = (0x3FF, 10, 0x7FF) if wide else (0xFF, 8, 0xFFF)
     assert HB == (F * 128 if wide else F * 256)
     N = codes.shape[0]
@@ -121,7 +126,7 @@ def walk_qimage(img, codes, T):
         for t in range(t0, t0 + nt):
             toff, depth, root, tu = [int(v) for v in img["ttab"][t]]
             depth, split = depth & 0xFFFF, depth >> 16
-            assert wide or split == 0
+            assert wide or rank12 or split == 0
             assert toff % 16 == 0 and toff < nu * 16 and toff + tu * 16 <= nu * 16
             tbase = img_off + toff
             if slot_bytes:  # the two waves of the slot stage their halves of the tree
@@ -143,7 +148,7 @@ def walk_qimage(img, codes, T):
                 assert (ca + 8 <= (img_off + slot_off[t - t0 + 1] if slot_bytes else img_off + nu * 16)).all()
                 pr = lds[ca // 8]
                 gl = xv <= (w >> 16)
-                nan_left = (((w >> pshift) & pmask) >= split) if wide else ((w >> 20) & 1 != 0)
+                nan_left = (((w >> pshift) & pmask) >= split) if (wide or rank12) else ((w >> 20) & 1 != 0)
                 gl = gl | ((xv == 0xFFFF) & nan_left)
                 w = np.where(gl, pr & np.uint64(0xFFFFFFFF), pr >> np.uint64(32)).astype(np.uint32)
             va = tbase + (((w >> pshift) & pmask).astype(np.int64) + 1) * 8
@@ -360,3 +365,34 @@ def test_wide_word_forests(F, slots):
         p2 = walk_qimage(img2, codes2, 12)
         assert np.array_equal(gio.bits(p2), gio.bits(onp.predict(fo2, X))), pattern
     assert not np.array_equal(gio.bits(p2), gio.bits(p))   # (the flags did change some NaN row's way)
+
+
+@pytest.mark.parametrize("slots,ch", [(4, 4), (8, 4), (3, 2), (16, 2)])
+def test_rank12_word(slots, ch):
+    """Round 4: the 12-bit rank form of the narrow word (ch | 0x200 asks the diagnostic entry for it) --
+    features with 2 048 .. 4 095 thresholds keep ONE row of the rank tile (11-bit ranks: two), NaN goes
+    where missing_go_to_left says (the pair's side of the tree's split), values on / next to thresholds."""
+    F, T = 40, 12
+    rng = np.random.default_rng(3 + slots)
+    fo = _random_forest(F, T, 1601, 30, 17 + slots)
+    inner = np.flatnonzero(fo["left"] != -1)
+    fo["feat"][inner[rng.random(inner.size) < 0.3]] = 7          # one feature with > 2 047 thresholds
+    fo["miss_left"][inner] = rng.random(inner.size) < 0.4
+    n7 = np.unique(fo["thr"][(fo["feat"] == 7) & (fo["left"] != -1)].astype(np.float32)).size
+    assert 2047 < n7 <= 4095
+    rc11, img11 = build_qimage(fo, F, slots, ch)
+    rc12, img12 = build_qimage(fo, F, slots, ch | 0x200)
+    assert rc11 == 0 and rc12 == 0, (img11, img12)
+    assert img11["mode"] == 0 and img12["mode"] == 2
+    assert img11["Fq"] == F + 1 and img12["Fq"] == F and (img12["ttab"][:, 1] >> 16 > 0).all()
+    X = rng.random((700, F)).astype(np.float32)
+    thr7 = fo["thr"][(fo["feat"] == 7) & (fo["left"] != -1)]
+    X[:300, 7] = np.float32(thr7[:300])
+    X[300:400, 7] = np.nextafter(np.float32(thr7[300:400]), np.float32(2))
+    X[400:450, 7] = np.nan
+    X[450:470] = np.nan
+    ref = onp.predict(fo, X)
+    for img in (img11, img12):
+        codes, _ = quantize(img, X)
+        got = walk_qimage(img, codes, T)
+        assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
