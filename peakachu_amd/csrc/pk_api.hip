@@ -387,6 +387,7 @@ extern "C" int64_t pk_forest_get_option(pk_forest *f, const char *name)
     if (!strcmp(name, "stat_q_mode")) return f->q_state == 1 ? f->q_mode : -1;   // PK_Q_NARROW / _WIDE / _NARROW12
     if (!strcmp(name, "stat_q_rows")) return f->q_state == 1 ? f->q_F : -1;
     if (!strcmp(name, "stat_q_shape")) return f->q_state == 1 ? f->q_ch : -1;
+    if (!strcmp(name, "stat_q_trees")) return f->q_state == 1 ? f->q_T : -1;   // trees of the image (pieces count)
     return opt_read(f->opt, name);
 }
 

@@ -208,6 +208,7 @@ struct pk_forest {
     // rank image (forest_q_kernel): 0 = not tried, 1 = built, -1 = does not apply
     int q_state = 0;
     int q_slots = 0, q_ch = 0, q_n_grp = 0;
+    int q_T = 0;           // trees of the rank image: T, or more when trees were cut into pieces (pk_qimage.hip)
     int q_mode = 0;        // node word format of the rank image (PK_Q_NARROW / _WIDE / _NARROW12): codes are r << 5,
                            // r << 5, r << 4
     int q_F = 0;           // rows of a rank tile: F + the virtual features (pk_q_tables)

@@ -350,7 +350,7 @@ struct q_slot_table {
 template <int CH, int WPT, int HALF1, bool PRUNE, bool EARLY>
 __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp,
-    const int4 *__restrict__ ttab, int T, int F, int dec_off, int val_off, int img_off,
+    const int4 *__restrict__ ttab, int T, int t_div, int F, int dec_off, int val_off, int img_off,
     const q_slot_table slots_at,
     const unsigned short *__restrict__ qtiles, const uint8_t *__restrict__ status, int64_t c0,
     int64_t cn, double *__restrict__ prob, double prune_sum, int warm_ahead, int dbg,
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             tt = tt_nxt;
             if (all_done) break;
         }
-        if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
+        if (valid) prob[c0 + local] = active ? acc / (double)t_div : 0.0;  // (t_div: the model's trees; T: the image's pieces)
         if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-ahead loads alive
         tile_ready = fetched;
         if (fetched) {  // every walk of this tile is behind the last barrier: its rank tiles can go
@@ -828,7 +828,7 @@ __device__ __forceinline__ void qr_walk(unsigned root, int depth, unsigned tbase
 struct qr_args {
     const char *img_b;
     const int4 *gtab, *ttab;
-    int n_grp, T, F, dec_off, val_off, img_off;
+    int n_grp, T, t_div, F, dec_off, val_off, img_off;  // T: trees of the image (pieces); t_div: the model's trees
     const unsigned short *qtiles;
     const uint8_t *status;
     int64_t c0, cn;
@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 #define QR_TSTAMP(k_) do {} while (0)
 #endif
         QR_TSTAMP(0);
-        if (valid) A.prob[c0 + local] = active ? acc / (double)T : 0.0;
+        if (valid) A.prob[c0 + local] = active ? acc / (double)A.t_div : 0.0;
         // the next tile and (PREF0) its first group: every walk of this tile is behind barrier 1 of
         // the last group and the sums are done, so its rank tiles and trees can go
         const bool grp0_here = fetched && pref0;
@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 template <int HALF1, bool PRUNE, int NR>
 __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGPRS))) void forest_qr_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
-    int F, int dec_off, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
+    int t_div, int F, int dec_off, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
     const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob, double prune_sum,
     int opt, int dbg, long long *__restrict__ stamps)
 {
@@ -1083,6 +1083,7 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
     A.ttab = ttab;
     A.n_grp = n_grp;
     A.T = T;
+    A.t_div = t_div;
     A.F = F;
     A.dec_off = dec_off;
     A.val_off = val_off;
@@ -1131,7 +1132,7 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
-    int F, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
+    int t_div, int F, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
     const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob,
     long long *__restrict__ stamps, int dbg, int late_below)
 {
@@ -1314,7 +1315,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
             g_cur = g_nxt;
             tt = tt_nxt;
         }
-        if (valid) prob[c0 + cbase + tid] = active ? acc / (double)T : 0.0;
+        if (valid) prob[c0 + cbase + tid] = active ? acc / (double)t_div : 0.0;
     }
     if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-up loads alive
 #undef Q2_STAMP
@@ -1472,6 +1473,7 @@ static int q_plan_build(pk_forest *f)
     f->q_slot_bytes = slot_bytes;
     f->q_ch = ch;
     f->q_mode = mode;
+    f->q_T = (int)best.troot.size();  // (the model's trees, or more: trees cut into pieces)
     f->q_F = Fq;
     f->q_n_grp = best.n_grp;
     f->q_max_group_bytes = 0;
@@ -1535,7 +1537,7 @@ int pk_forest_q_plan(pk_forest *f)
         hipLaunchKernelGGL((forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>), dim3(grid), dim3(Q_THREADS), \
                            163840, ctx->stream, reinterpret_cast<const v4u *>(f->q_img),       \
                            reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp,              \
-                           reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->q_F, L.dec_off,   \
+                           reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.dec_off,   \
                            L.val_off, L.img_off, slots_at, ctx->q_tiles, d_status, c0,         \
                            cn, d_prob,                                                         \
                            prune_sum,                                                          \
@@ -1644,7 +1646,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         if (rc__) return rc__;                                                                             \
         hipLaunchKernelGGL((forest_qr_kernel<HALF1, PRUNE, NR>), dim3(grid), dim3(Q_THREADS), 163840, ctx->stream, \
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab), \
-                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->q_F, L.dec_off,   \
+                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.dec_off,   \
                            L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob, prune_sum,        \
                            (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg, ctx->dbg_buf);          \
     } while (0)
@@ -1685,7 +1687,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         if (f->opt.forest_q_persist != 0 && grid2 > want) grid2 = want;
         hipLaunchKernelGGL(forest_q2_kernel, dim3(grid2), dim3(Q_THREADS), 163840, ctx->stream,
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab),
-                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->T, f->q_F, L.val_off, L.img_off,
+                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.val_off, L.img_off,
                            ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)f->opt.forest_dbg, late_below);
     } else if (L.ch == 1) {
         Q_LAUNCH(1, 1, 32768, false);

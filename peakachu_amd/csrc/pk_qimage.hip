@@ -39,6 +39,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <map>
 
 #include "pk_common.h"
@@ -382,8 +383,117 @@ int pk_q_tables(int T, int F, const int32_t *tree_off, const int32_t *left, cons
     return PK_OK;
 }
 
-// The tree images (they depend on the word format, not on the layout): `wide` = the 10-bit feature
-// field of the 64-candidate shape.  PK_E_UNSUPPORTED when a tree does not fit the pair field.
+// A tree that has more child pairs than the pair field counts is cut in two (round 4): the subtree S
+// nearest to half its size is taken out.  Piece A is the tree with a pure 0.0 leaf in S's place; piece B
+// is the path from the root to S -- the same tests, every way off the path ending in a pure 0.0 leaf --
+// with S at its end.  A candidate reaches S in exactly one of the two and a 0.0 leaf in the other, and
+// x + 0.0 == x exactly: the model's sequential float64 sum is unchanged, only its divisor must stay the
+// model's tree count (the kernels' t_div).  Pieces are cut again while they do not fit.
+struct q_owned_tree {
+    std::vector<int32_t> left, right, feat;
+    std::vector<double> thr, p1;
+    std::vector<uint8_t> miss;
+    q_tree view() const
+    {
+        return q_tree{(int)left.size(), left.data(), right.data(), feat.data(), thr.data(), p1.data(),
+                      miss.empty() ? nullptr : miss.data()};
+    }
+    int add(int l, int r, int f, double t, double v, uint8_t m)
+    {
+        left.push_back(l); right.push_back(r); feat.push_back(f); thr.push_back(t); p1.push_back(v); miss.push_back(m);
+        return (int)left.size() - 1;
+    }
+};
+
+static bool q_cut_tree(const q_tree &t, q_owned_tree *A, q_owned_tree *B)
+{
+    const int nn = t.nn;
+    // interior nodes per subtree and parents (iterative post-order; the tree was validated by q_emit_tree)
+    std::vector<int> parent((size_t)nn, -1), size((size_t)nn, 0), order;
+    order.reserve((size_t)nn);
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        const int v = stack.back();
+        stack.pop_back();
+        order.push_back(v);
+        if (t.left[v] != -1) {
+            parent[(size_t)t.left[v]] = parent[(size_t)t.right[v]] = v;
+            stack.push_back(t.left[v]);
+            stack.push_back(t.right[v]);
+        }
+    }
+    for (size_t i = order.size(); i-- > 0;) {
+        const int v = order[i];
+        if (t.left[v] != -1) size[(size_t)v] = 1 + size[(size_t)t.left[v]] + size[(size_t)t.right[v]];
+    }
+    const int total = size[0];
+    if (total < 4) return false;
+    int s = -1;
+    for (int v : order)
+        if (v != 0 && t.left[v] != -1 && (s < 0 || abs(2 * size[(size_t)v] - total) < abs(2 * size[(size_t)s] - total))) s = v;
+    if (s < 0) return false;
+    auto m_of = [&](int v) { return (uint8_t)(t.miss ? t.miss[v] : 0); };
+    // copies the subtree of `v` (all of it, or with S replaced by a 0.0 leaf) into `dst`; returns its root there
+    auto copy_sub = [&](int v0, bool drop_s, q_owned_tree *dst) {
+        std::vector<std::pair<int, int>> st;  // (source node, index in dst)
+        const int root = dst->add(-1, -1, -2, -2.0, 0.0, 0);
+        st.push_back({v0, root});
+        while (!st.empty()) {
+            const auto [v, d] = st.back();
+            st.pop_back();
+            if (t.left[v] == -1 || (drop_s && v == s)) {
+                dst->p1[(size_t)d] = (drop_s && v == s) ? 0.0 : t.p1[v];
+                continue;
+            }
+            dst->feat[(size_t)d] = t.feat[v];
+            dst->thr[(size_t)d] = t.thr[v];
+            dst->miss[(size_t)d] = m_of(v);
+            const int l = dst->add(-1, -1, -2, -2.0, 0.0, 0), r = dst->add(-1, -1, -2, -2.0, 0.0, 0);
+            dst->left[(size_t)d] = l;
+            dst->right[(size_t)d] = r;
+            st.push_back({t.right[v], r});
+            st.push_back({t.left[v], l});
+        }
+        return root;
+    };
+    *A = q_owned_tree();
+    copy_sub(0, true, A);
+    *B = q_owned_tree();
+    std::vector<int> path;  // root .. parent of s
+    for (int v = parent[(size_t)s]; v >= 0; v = parent[(size_t)v]) path.push_back(v);
+    std::reverse(path.begin(), path.end());
+    int at = B->add(-1, -1, -2, -2.0, 0.0, 0);  // the root of B
+    for (size_t i = 0; i < path.size(); i++) {
+        const int u = path[i], next = i + 1 < path.size() ? path[i + 1] : s;
+        B->feat[(size_t)at] = t.feat[u];
+        B->thr[(size_t)at] = t.thr[u];
+        B->miss[(size_t)at] = m_of(u);
+        const int on = B->add(-1, -1, -2, -2.0, 0.0, 0), off = B->add(-1, -1, -2, -2.0, 0.0, 0);  // off: a pure 0.0 leaf
+        if (t.left[u] == next) {
+            B->left[(size_t)at] = on;
+            B->right[(size_t)at] = off;
+        } else {
+            B->left[(size_t)at] = off;
+            B->right[(size_t)at] = on;
+        }
+        at = on;
+    }
+    {   // S itself, rooted at `at`
+        q_owned_tree S;
+        copy_sub(s, false, &S);
+        const int base = (int)B->left.size();
+        // node 0 of S lands on `at`, the others behind the nodes B has so far (indices shift by base - 1)
+        auto map = [&](int i) { return i < 0 ? i : (i == 0 ? at : base + i - 1); };
+        B->left[(size_t)at] = map(S.left[0]); B->right[(size_t)at] = map(S.right[0]);
+        B->feat[(size_t)at] = S.feat[0]; B->thr[(size_t)at] = S.thr[0]; B->p1[(size_t)at] = S.p1[0]; B->miss[(size_t)at] = S.miss[0];
+        for (size_t i = 1; i < S.left.size(); i++) B->add(map(S.left[i]), map(S.right[i]), S.feat[i], S.thr[i], S.p1[i], S.miss[i]);
+    }
+    return true;
+}
+
+// The tree images (they depend on the word format, not on the layout).  A tree beyond the pair field is
+// cut into pieces (q_cut_tree): the image then holds more trees than the model (out->troot.size()).
+// PK_E_UNSUPPORTED when a piece still does not fit.
 int pk_q_trees(int T, int F, const int32_t *tree_off, const int32_t *left, const int32_t *right,
                const int32_t *feat, const double *thr, const uint8_t *miss, const double *p1, int mode,
                pk_q_out *out)
@@ -392,11 +502,34 @@ int pk_q_trees(int T, int F, const int32_t *tree_off, const int32_t *left, const
     if ((mode == PK_Q_NARROW12) != (out->max_rank == PK_Q_MAX_RANK12)) return PK_E_INVALID;  // (tables of the other width)
     out->mode = mode;
     out->pairs.clear();
-    // tree images
-    out->troot.assign((size_t)T, 0);
-    out->tdepth.assign((size_t)T, 0);
-    std::vector<int32_t> tsplit((size_t)T, 0);    // wide word: first pair of the "NaN goes left" side
-    std::vector<int32_t> toff((size_t)T + 1, 0);  // pairs
+    out->troot.clear();
+    out->tdepth.clear();
+    std::vector<int32_t> toff{0};  // pairs
+    // emits one tree (or its pieces, depth first: A before B keeps them next to each other in the image)
+    int budget = 64 * T + 4096;   // pieces in all (a guard against a pathological forest, not a tuning knob)
+    std::function<int(const q_tree &, int, int)> emit = [&](const q_tree &tv, int t, int level) -> int {
+        std::string err;
+        uint32_t root = 0;
+        int depth = 0, split = 0;
+        const int np = q_emit_tree(tv, F, *out, &out->pairs, &root, &depth, &err, mode, &split);
+        if (np == -1) {
+            pk_set_error("forest rank image: tree %d: %s", t, err.c_str());
+            return PK_E_INVALID;
+        }
+        if (np == -2) {  // more pairs than the field counts: two pieces
+            q_owned_tree A, B;
+            if (level > 12 || --budget < 0 || !q_cut_tree(tv, &A, &B)) return PK_E_UNSUPPORTED;
+            int rc = emit(A.view(), t, level + 1);
+            if (!rc) rc = emit(B.view(), t, level + 1);
+            return rc;
+        }
+        if (np < 0 || depth > 0xFFFF) return PK_E_UNSUPPORTED;
+        toff.push_back(toff.back() + np);
+        out->troot.push_back(root);
+        // (the walk's level count in the low half, the split in the high half of one table word)
+        out->tdepth.push_back(depth | (split << 16));
+        return PK_OK;
+    };
     for (int t = 0; t < T; t++) {
         const int32_t b = tree_off[t];
         const q_tree tv{tree_off[t + 1] - b, left + b, right + b, feat + b, thr + b, p1 + b,
@@ -405,18 +538,8 @@ int pk_q_trees(int T, int F, const int32_t *tree_off, const int32_t *left, const
             pk_set_error("forest rank image: tree %d is empty", t);
             return PK_E_INVALID;
         }
-        std::string err;
-        const int np = q_emit_tree(tv, F, *out, &out->pairs, &out->troot[(size_t)t],
-                                   &out->tdepth[(size_t)t], &err, mode, &tsplit[(size_t)t]);
-        if (np == -1) {
-            pk_set_error("forest rank image: tree %d: %s", t, err.c_str());
-            return PK_E_INVALID;
-        }
-        if (np < 0) return PK_E_UNSUPPORTED;
-        toff[(size_t)t + 1] = toff[(size_t)t] + np;
-        // (the walk's level count in the low half, the split in the high half of one table word)
-        if (out->tdepth[(size_t)t] > 0xFFFF) return PK_E_UNSUPPORTED;
-        out->tdepth[(size_t)t] |= tsplit[(size_t)t] << 16;
+        const int rc = emit(tv, t, 0);
+        if (rc) return rc;
     }
     out->toff = toff;
     out->pairs.push_back(make_uint2(0, 0));  // the clamped staging loads stay inside
@@ -530,8 +653,10 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
         if (rc == PK_E_UNSUPPORTED) pk_set_error("pk_debug_forest_qimage: the forest does not fit the rank format");
         return rc;
     }
+    // (a tree cut into pieces, q_cut_tree: the tree table has more rows than the model has trees; the
+    // caller's tables hold cap_groups - 4 trees)
     if ((int64_t)out.qthr.size() > cap_thr || (int64_t)out.pairs.size() > cap_pairs ||
-        out.n_grp + 2 > cap_groups) {
+        out.n_grp + 2 > cap_groups || (int64_t)out.troot.size() > cap_groups - 4) {
         pk_set_error("pk_debug_forest_qimage: output buffers too small");
         return PK_E_NOMEM;
     }
@@ -540,6 +665,7 @@ extern "C" int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, con
     for (int i = 0; i < 17; i++) lay[9 + i] = L.slot_off[i];
     lay[26] = out.Fq;
     lay[27] = out.mode;
+    lay[28] = (int32_t)out.troot.size();  // trees of the image: the model's, or more (pieces)
     memcpy(layout8, lay, sizeof(lay));
     memcpy(qsrc, out.qsrc.data(), out.qsrc.size() * sizeof(int32_t));
     memcpy(qoff, out.qoff.data(), out.qoff.size() * sizeof(int32_t));

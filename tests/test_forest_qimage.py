@@ -41,23 +41,26 @@ def build_qimage(fo, F, slots, ch):
     cap_pairs = 2 * nn + 64 * T + 64
     pairs = np.zeros(cap_pairs, np.uint64)
     npairs = C.c_int64()
-    gtab = np.zeros(4 * (T + 4), np.int32)
+    Tcap = 4 * T + 64     # trees of the image: the model's, or more (a tree beyond the pair field is cut into pieces)
+    gtab = np.zeros(4 * (Tcap + 4), np.int32)
     ng = C.c_int32()
-    ttab = np.zeros(4 * T, np.int32)
+    ttab = np.zeros(4 * Tcap, np.int32)
     rc = L.pk_debug_forest_qimage(
         T, F, np.ascontiguousarray(fo["tree_off"], np.int32),
         np.ascontiguousarray(fo["left"], np.int32), np.ascontiguousarray(fo["right"], np.int32),
         np.ascontiguousarray(fo["feat"], np.int32), np.ascontiguousarray(fo["thr"], np.float64),
         np.ascontiguousarray(fo["miss_left"], np.uint8), np.ascontiguousarray(fo["p1"], np.float64),
         slots, ch, lay, qoff, qthr.size, qthr, qlut, qpar, cap_pairs, pairs, C.byref(npairs),
-        T + 4, gtab, C.byref(ng), ttab, R, qsrc)
+        Tcap + 4, gtab, C.byref(ng), ttab, R, qsrc)
     if rc != 0:
         return rc, _lib.last_error()
     Fq = int(lay[26])
-    return 0, dict(lay=lay, Fq=Fq, mode=int(lay[27]), qsrc=qsrc[:Fq], qoff=qoff[:Fq + 1], qthr=qthr,
+    Ti = int(lay[28])
+    ttab = ttab[:4 * Ti]
+    return 0, dict(lay=lay, Fq=Fq, mode=int(lay[27]), trees=Ti, qsrc=qsrc[:Fq], qoff=qoff[:Fq + 1], qthr=qthr,
                    qlut=qlut[:Fq * CELLS].reshape(Fq, CELLS), qpar=qpar[:Fq * 2].reshape(Fq, 2),
                    pairs=pairs[:npairs.value], gtab=gtab[:4 * (ng.value + 2)].reshape(-1, 4),
-                   n_grp=ng.value, ttab=ttab.reshape(T, 4))
+                   n_grp=ng.value, ttab=ttab.reshape(Ti, 4))
 
 
 def quantize(img, X):
@@ -396,3 +399,31 @@ def test_rank12_word(slots, ch):
         codes, _ = quantize(img, X)
         got = walk_qimage(img, codes, T)
         assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+
+
+@pytest.mark.parametrize("mode_flag", [0, 0x200])
+def test_trees_beyond_the_pair_field_are_cut(mode_flag):
+    """Round 4: a tree with more child pairs than the 12-bit pair field counts is cut in two -- the tree
+    with a 0.0 leaf where subtree S was, and the path to S with S at its end (every way off the path a
+    0.0 leaf); x + 0.0 == x, so the sequential sum is the model's; the divisor stays the model's tree
+    count.  Rounds 2-4 sent such forests (a model fitted on 139 000 windows: 10 167 nodes in a tree) to
+    the float kernels."""
+    F, T = 30, 5
+    fo = _random_forest(F, T, 11001, 40, 5)            # ~5 500 interior nodes per tree
+    rng = np.random.default_rng(1)
+    inner = np.flatnonzero(fo["left"] != -1)
+    fo["miss_left"][inner] = rng.random(inner.size) < 0.3
+    assert (np.diff(fo["tree_off"]) > 9000).all()
+    rc, img = build_qimage(fo, F, 4, 4 | mode_flag)
+    assert rc == 0, img
+    assert img["trees"] > T and img["ttab"].shape[0] == img["trees"]
+    pairs_per_tree = img["ttab"][:, 3] * 2
+    assert pairs_per_tree.max() <= 4096 and pairs_per_tree.sum() < 2 * 5 * 5600 + 64 * img["trees"]
+    X = rng.random((500, F)).astype(np.float32)
+    X[:40, 3] = np.nan
+    X[40:50] = np.nan
+    thr = fo["thr"][inner]
+    X[50:250, :] = np.float32(thr[rng.integers(0, thr.size, (200, F))])   # many values exactly on thresholds
+    codes, _ = quantize(img, X)
+    got = walk_qimage(img, codes, T)
+    assert np.array_equal(got.view(np.uint64), onp.predict(fo, X).view(np.uint64))

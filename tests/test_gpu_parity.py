@@ -1080,3 +1080,45 @@ def test_clean_extractor_and_its_fallback(hip_lib, w, poison):
     assert np.array_equal(gio.bits(got[0][0]), gio.bits(got[1][0]))   # general == clean path
     if poison in ("none", "exp_tiny"):
         assert not nan_ref.any()
+
+
+def test_large_models_stay_on_the_rank_kernels(hip_lib):
+    """Round 4: (i) features with 2 048 .. 4 095 distinct thresholds keep ONE rank-tile row (the 12-bit rank
+    word), (ii) a tree with more child pairs than the pair field counts is cut into pieces -- both used to
+    send a model to the float kernels.  predict_proba through the C ABI against the oracle, NaN features and
+    missing_go_to_left nodes included; the plan's read-only options tell which route ran."""
+    from test_forest_qimage import _random_forest
+    L = hip_lib
+    rng = np.random.default_rng(11)
+    # (i) 40 features, one of them with ~2 900 thresholds; option 2 = take the 12-bit word whenever it saves rows
+    fo = _random_forest(40, 12, 1601, 30, 21)
+    inner = np.flatnonzero(fo["left"] != -1)
+    fo["feat"][inner[rng.random(inner.size) < 0.3]] = 7
+    fo["miss_left"][inner] = rng.random(inner.size) < 0.4
+    X = rng.random((5000, 40)).astype(np.float32)
+    X[:300, 7] = np.float32(fo["thr"][inner][:300])
+    X[300:330, 7] = np.nan
+    X[330:340] = np.nan
+    ref = onp.predict(fo, X)
+    for rank12, want_mode, want_rows in ((0, 0, 41), (2, 2, 40)):
+        hf = _lib.HipForest(flat(fo), options={"forest_q_rank12": rank12})
+        L.pk_prof_enable(1); L.pk_prof_reset()
+        p = hf.predict(X)
+        assert _lib.prof_get("quant")[1] > 0
+        L.pk_prof_enable(0)
+        assert (hf.get_option("stat_q_mode"), hf.get_option("stat_q_rows")) == (want_mode, want_rows)
+        assert np.array_equal(gio.bits(p), gio.bits(ref))
+    # (ii) five trees of ~5 500 child pairs each (the pair field counts 4 096)
+    fo = _random_forest(30, 5, 11001, 40, 5)
+    inner = np.flatnonzero(fo["left"] != -1)
+    fo["miss_left"][inner] = rng.random(inner.size) < 0.3
+    X = rng.random((3000, 30)).astype(np.float32)
+    X[:40, 3] = np.nan
+    X[50:250, :] = np.float32(fo["thr"][inner][rng.integers(0, inner.size, (200, 30))])
+    hf = _lib.HipForest(flat(fo))
+    L.pk_prof_enable(1); L.pk_prof_reset()
+    p = hf.predict(X)
+    assert _lib.prof_get("quant")[1] > 0                     # the rank kernels ran
+    L.pk_prof_enable(0)
+    assert hf.get_option("stat_q_trees") > 5
+    assert np.array_equal(gio.bits(p), gio.bits(onp.predict(fo, X)))
