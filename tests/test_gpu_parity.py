@@ -1092,6 +1092,7 @@ def test_large_models_stay_on_the_rank_kernels(hip_lib):
     rng = np.random.default_rng(11)
     # (i) 40 features, one of them with ~2 900 thresholds; option 2 = take the 12-bit word whenever it saves rows
     fo = _random_forest(40, 12, 1601, 30, 21)
+    fo["F"] = 40
     inner = np.flatnonzero(fo["left"] != -1)
     fo["feat"][inner[rng.random(inner.size) < 0.3]] = 7
     fo["miss_left"][inner] = rng.random(inner.size) < 0.4
@@ -1110,6 +1111,7 @@ def test_large_models_stay_on_the_rank_kernels(hip_lib):
         assert np.array_equal(gio.bits(p), gio.bits(ref))
     # (ii) five trees of ~5 500 child pairs each (the pair field counts 4 096)
     fo = _random_forest(30, 5, 11001, 40, 5)
+    fo["F"] = 30
     inner = np.flatnonzero(fo["left"] != -1)
     fo["miss_left"][inner] = rng.random(inner.size) < 0.3
     X = rng.random((3000, 30)).astype(np.float32)
