@@ -287,6 +287,81 @@ def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, step
             "whole_path_frac": value * b_alg(F) / 1e9 / HBM_PEAK_GBS}
 
 
+def _timed_runs(L, dev, cd, hm, hf, w, thre, batch, reps):
+    """`reps` warm pk_score_run calls on one resident list: wall microseconds per call
+    (host clock around the loop) and the library's own HIP-event kernel times per call."""
+    from peakachu_amd import _lib
+    cd.run(hm, hf, w, thre, batch)
+    cd.run(hm, hf, w, thre, batch)
+    L.pk_prof_enable(1)
+    L.pk_prof_reset()
+    _lib.check(L.pk_device_synchronize(dev), "sync")
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        n_out = cd.run(hm, hf, w, thre, batch)
+    _lib.check(L.pk_device_synchronize(dev), "sync")
+    el = time.perf_counter() - t0
+    L.pk_prof_enable(0)
+    kern = {k: _lib.prof_get(k)[0] / reps * 1e3 for k in ("extract", "quant", "forest", "compact")}
+    return el / reps * 1e6, kern, int(n_out)
+
+
+def real_regime(L, dev, M, fo, w, lower, upper, thre, batch, x_all, y_all, hm, hf):
+    """The regime the CLI runs in (peakachu/scoreUtils.py:40-68, 95-106): the Poisson-filtered
+    candidate list get_candidate makes -- a few percent of the band's non-zero pixels, scattered
+    along the diagonals -- and short lists, scored by pk_score_run with the early exit
+    Chromosome.score switches on.  Warm microseconds per call, candidates/s and the kernels' own
+    HIP-event times; plus the cold cost of one Chromosome(...) + .score() of this matrix."""
+    import io as _io
+    from peakachu_amd import _lib, scoreUtils
+    out = {"note": "pk_score_run with early exit (what Chromosome.score runs), device-resident lists; "
+                   "us = warm wall time per call"}
+    legs = []
+
+    def leg(name, x, y, reps):
+        cd = _lib.HipCands(x, y, device=dev)
+        try:
+            cd.set_prune(True)
+            us, kern, n_out = _timed_runs(L, dev, cd, hm, hf, w, thre, batch, reps)
+        finally:
+            cd.close()
+        legs.append({"list": name, "candidates": int(x.size), "us_per_call": us,
+                     "value": x.size / (us * 1e-6), "unit": "candidates/s", "scored_pixels": n_out,
+                     "kernel_us_per_call": kern, "whole_path_frac": x.size / (us * 1e-6) * b_alg((2 * w + 1) ** 2)
+                     / 1e9 / HBM_PEAK_GBS})
+
+    # (i) the list Chromosome.get_candidate makes for this matrix (raw mode), cold and warm
+    sink = _io.StringIO()
+    cold = []
+    for rep in range(3):
+        old = sys.stdout
+        sys.stdout = sink
+        try:
+            t0 = time.perf_counter()
+            X = scoreUtils.Chromosome(M, model=fo, raw_M=M, weights=None, lower=lower, upper=upper,
+                                      cname="chr1", res=10000, width=w, device=dev)
+            t1 = time.perf_counter()
+            res, R = X.score(thre=thre)
+            t2 = time.perf_counter()
+        finally:
+            sys.stdout = old
+        cold.append({"construct_ms": (t1 - t0) * 1e3, "score_ms": (t2 - t1) * 1e3,
+                     "candidates": int(X.ridx.size), "scored_pixels": int(res.nnz)})
+        px, py = X.ridx.astype(np.int32), X.cidx.astype(np.int32)
+        del X
+    out["chromosome_cold"] = {"bins": int(M.shape[0]), "passes": cold,
+                              "note": "Chromosome(...) [upload, band, expected curve, Poisson candidates] and "
+                                      ".score() [pk_score_run + fetch + CSR build], three times in one process: "
+                                      "the first carries this process's one-off costs"}
+    leg("get_candidate (Poisson p < 0.01)", px, py, 50)
+    # (ii) strided sub-lists of the all-non-zero-band-pixels list
+    for m in (1000, 10000, 100000, 1000000):
+        s = max(1, x_all.size // m)
+        leg("every %d-th non-zero band pixel" % s, x_all[::s].copy(), y_all[::s].copy(), 200 if m <= 10000 else 50)
+    out["legs"] = legs
+    return out
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher: run the same command under
     torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1) as a child process and

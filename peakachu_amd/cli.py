@@ -77,6 +77,18 @@ def run(argv=None):
         if n > 1:
             raise SystemExit(launch.spawn(n))
     args.func(args)
+    _stage_report()
+
+
+def _stage_report():
+    """PK_STAGE_TIMES=1 PK_STAGE_REPORT=<file>: the wall time per stage of this run, as JSON."""
+    import os
+    from . import stagetime
+    path = os.environ.get("PK_STAGE_REPORT")
+    if stagetime.ENABLED and path:
+        import json
+        with open(path, "w") as fh:
+            json.dump(stagetime.report(), fh)
 
 
 if __name__ == "__main__":

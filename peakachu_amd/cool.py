@@ -31,6 +31,7 @@ import numpy as np
 from scipy import sparse
 
 from . import h5lite
+from .stagetime import stage
 
 
 class _Selector:
@@ -154,8 +155,13 @@ class CoolFile:
         p0, p1 = int(off[0]), int(off[-1])
         # pixels are sorted by (bin1, bin2): bin1 follows from the index, no need to read it
         i = np.repeat(np.arange(n, dtype=np.int32), np.diff(off))
-        j = self._g["pixels/bin2_id"][p0:p1]
-        v = self._g["pixels/count"][p0:p1]
+        with stage("read: HDF5 pixel chunks (bin2_id, count)"):
+            j = self._g["pixels/bin2_id"][p0:p1]
+            v = self._g["pixels/count"][p0:p1]
+        with stage("read: mirror the pixels to the symmetric matrix"):
+            return self._assemble(chrom, n, lo, hi, i, j, v)
+
+    def _assemble(self, chrom, n, lo, hi, i, j, v):
         cis = j < hi  # bin2 >= bin1 >= lo always; drop the trans pixels
         j = (j - lo).astype(np.int32)
         if not cis.all():
@@ -226,6 +232,20 @@ class CoolFile:
         row[pos_u], col[pos_u], val[pos_u] = i, j, v
         return row, col, val, indptr.astype(np.int32)
 
+    def _balanced(self, name, lo, hi, col, data, indptr):
+        w = self._weights(name, lo, hi)
+        if self._divisive(name):
+            # divisive columns: the biases are inverted first and then applied like
+            # multiplicative ones -- (1/b_i) * (1/b_j) * count, which does not round like
+            # count / (b_i * b_j).  UNVERIFIED against cooler itself (see the module text)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                w = 1.0 / w
+        # (w[row] * w[col]) * count: the row factor by repetition (the rows are runs)
+        f = np.repeat(w, np.diff(indptr))
+        f *= np.take(w, col)
+        f *= data
+        return f
+
     # -- the reference's three calls
     def matrix(self, balance=True, sparse=True):
         if not sparse:
@@ -237,18 +257,8 @@ class CoolFile:
             n = hi - lo
             row, col, data, indptr = self._mirrored(chrom, lo, hi)
             if name:
-                w = self._weights(name, lo, hi)
-                if self._divisive(name):
-                    # divisive columns: the biases are inverted first and then applied like
-                    # multiplicative ones -- (1/b_i) * (1/b_j) * count, which does not round like
-                    # count / (b_i * b_j).  UNVERIFIED against cooler itself (see the module text)
-                    with np.errstate(divide="ignore", invalid="ignore"):
-                        w = 1.0 / w
-                # (w[row] * w[col]) * count: the row factor by repetition (the rows are runs)
-                f = np.repeat(w, np.diff(indptr))
-                f *= np.take(w, col)
-                f *= data
-                data = f
+                with stage("read: balance (w[row] * w[col] * count)"):
+                    data = self._balanced(name, lo, hi, col, data, indptr)
             # row, col (and the raw counts) are the cached arrays themselves, read-only
             return sparse_coo(data, row, col, n, indptr)
         return _Selector(fetch)

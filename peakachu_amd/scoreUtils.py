@@ -10,6 +10,7 @@ from scipy import sparse
 
 from . import _lib, utils
 from .forest import as_flat_forest
+from .stagetime import stage
 
 
 # The device copy of a model (pk_forest: packed trees, rank tables, LDS images) is built
@@ -23,7 +24,8 @@ def _device_forest(model, device):
         if m is model and d == device and hf.h:
             _FOREST_CACHE.append(_FOREST_CACHE.pop(i))
             return hf
-    hf = _lib.HipForest(as_flat_forest(model), device=device)
+    with stage("forest: upload + device image (once per model)"):
+        hf = _lib.HipForest(as_flat_forest(model), device=device)
     _FOREST_CACHE.append((model, device, hf))
     while len(_FOREST_CACHE) > 4:
         # only the cache's reference goes: a Chromosome that still holds the evicted forest
@@ -104,7 +106,8 @@ class Chromosome():
         return utils.isotonic_expected(exp_arr)
 
     def _prepare_on_device(self, M, raw_M, weights, upper, width):
-        Mc = utils.canonical_csr(M)
+        with stage("prepare: canonical_csr"):
+            Mc = utils.canonical_csr(M)
         n = Mc.shape[0]
         if Mc.nnz == 0 or n <= 2 * width:
             return False
@@ -112,28 +115,33 @@ class Chromosome():
         dlo, dhi = -2 * width + 1, max(upper + 2 * width - 1, -2 * width + 1)
         csr = rcsr = None
         try:
-            csr = _lib.HipCsr(Mc, device=self.device)
+            with stage("prepare: H2D of the CSR + facts (pk_csr_upload)"):
+                csr = _lib.HipCsr(Mc, device=self.device)
             balanced = weights is not None
             if not balanced and csr.n_negative:
                 return False  # the validity test is a sign of a column sum: host path
-            band = csr.band(dlo, dhi)
-            band.dlo, band.dhi = dlo, dhi
-            self.exp_arr = self._expected_on_device(csr, band, maxdis, balanced)
-            band.set_expected(self.exp_arr)
+            with stage("prepare: band build (pk_matrix_from_csr)"):
+                band = csr.band(dlo, dhi)
+                band.dlo, band.dhi = dlo, dhi
+            with stage("prepare: expected curve (device means + isotonic fit)"):
+                self.exp_arr = self._expected_on_device(csr, band, maxdis, balanced)
+                band.set_expected(self.exp_arr)
             self._hm = band
             if balanced or self._raw_is_M:
                 self.background = self.exp_arr
             if self._raw_is_M:
                 self._raw_facts = dict(integer=csr.n_noninteger == 0, vmax=csr.vmax, nnz=Mc.nnz, band=band)
             else:
-                Rc = utils.canonical_csr(raw_M)
+                with stage("prepare: canonical_csr"):
+                    Rc = utils.canonical_csr(raw_M)
                 if Rc.nnz == 0:
                     if not balanced:
                         self._hm = None
                         return False
                     self._raw_facts = dict(integer=True, vmax=0.0, nnz=0, band=None)
                     return True
-                rcsr = _lib.HipCsr(Rc, device=self.device)
+                with stage("prepare: H2D of the CSR + facts (pk_csr_upload)"):
+                    rcsr = _lib.HipCsr(Rc, device=self.device)
                 if not balanced:
                     # .hic style: M holds normalised values, the background comes from the raw counts
                     if rcsr.n_negative:
@@ -143,8 +151,9 @@ class Chromosome():
                 hi = min(int(upper), self.background.size - 1, n - 1)
                 rband = None
                 if hi >= self.lower:
-                    rband = rcsr.band(self.lower, hi)
-                    rband.dlo, rband.dhi = self.lower, hi
+                    with stage("prepare: band build (pk_matrix_from_csr)"):
+                        rband = rcsr.band(self.lower, hi)
+                        rband.dlo, rband.dhi = self.lower, hi
                 self._raw_facts = dict(integer=rcsr.n_noninteger == 0, vmax=rcsr.vmax, nnz=Rc.nnz,
                                        band=rband, own=True)
             return True
@@ -160,14 +169,17 @@ class Chromosome():
         with scipy); otherwise, or when a pixel falls inside the table's guard
         band, on the host with scipy directly."""
         self._cands = None
-        got = self._candidates_on_device(lower, upper)  # device errors propagate
+        with stage("candidates: Poisson tables (scipy) + device scan"):
+            got = self._candidates_on_device(lower, upper)  # device errors propagate
         if got is None:
-            self.ridx, self.cidx = utils.candidates(self.raw_M, self.background, self.weights,
-                                                    lower, upper)
+            with stage("candidates: host path (scipy per pixel)"):
+                self.ridx, self.cidx = utils.candidates(self.raw_M, self.background, self.weights,
+                                                        lower, upper)
         else:
             self._cands = got
-            x, y = got.coords()
-            self.ridx, self.cidx = x.astype(np.int64), y.astype(np.int64)
+            with stage("candidates: D2H of ridx / cidx"):
+                x, y = got.coords()
+                self.ridx, self.cidx = x.astype(np.int64), y.astype(np.int64)
         self._cands_key = (self.ridx, self.cidx)
 
     def _candidates_on_device(self, lower, upper):
@@ -265,15 +277,19 @@ class Chromosome():
         # option is touched): a candidate stops once its sum can no longer exceed thre*T;
         # the reported pixels are identical (tests/test_gpu_fullsize.py)
         cd.set_prune(True)
-        cd.run(self._matrix(), self._forest(), self.w, thre, batch=100000)
-        ri, ci, prob_pool, signal = cd.fetch()
-        ri = ri.astype(int)
-        ci = ci.astype(int)
-        result = sparse.csr_matrix((prob_pool, (ri, ci)), shape=self._shape)
-        if ri.size > 0:
-            self.M = sparse.csr_matrix((signal, (ri, ci)), shape=self._shape)
-        else:
-            self.M = result
+        hm, hf = self._matrix(), self._forest()
+        with stage("score: pk_score_run (extract, forest, compact)"):
+            cd.run(hm, hf, self.w, thre, batch=100000)
+        with stage("score: D2H of the scored pixels"):
+            ri, ci, prob_pool, signal = cd.fetch()
+        with stage("score: result CSR matrices"):
+            ri = ri.astype(int)
+            ci = ci.astype(int)
+            result = sparse.csr_matrix((prob_pool, (ri, ci)), shape=self._shape)
+            if ri.size > 0:
+                self.M = sparse.csr_matrix((signal, (ri, ci)), shape=self._shape)
+            else:
+                self.M = result
         self._hm = None  # self.M changed, as in the reference
         return result, self.M
 

@@ -12,6 +12,7 @@ import numpy as np
 
 from . import dist, io, scoreUtils, utils
 from .forest import load_model
+from .stagetime import stage
 
 
 def select_chromosomes(chromnames, chroms):
@@ -53,7 +54,8 @@ def prefetched(Lib, keys, correct):
     with ThreadPoolExecutor(max_workers=depth) as pool:
         ahead = deque(pool.submit(fetch_inputs, Lib, k, correct) for k in keys[:depth])
         for i, key in enumerate(keys):
-            cur = ahead.popleft().result()
+            with stage("wait for the reader threads"):
+                cur = ahead.popleft().result()
             if i + depth < len(keys):
                 ahead.append(pool.submit(fetch_inputs, Lib, keys[i + depth], correct))
             yield key, cur
@@ -63,11 +65,13 @@ def build_chromosome(Lib, key, cname, model, correct, args, width, device, input
     """peakachu/score_genome.py:53-67 (the .cool branch)."""
     M, raw_M, weights = inputs if inputs is not None else fetch_inputs(Lib, key, correct)
     if correct:
-        M, raw_M = utils.tocsr(M), utils.tocsr(raw_M)
+        with stage("tocsr"):
+            M, raw_M = utils.tocsr(M), utils.tocsr(raw_M)
         return scoreUtils.Chromosome(M, model=model, raw_M=raw_M, weights=weights, cname=cname,
                                      lower=args.lower, upper=args.upper, res=args.resolution,
                                      width=width, device=device)
-    M = utils.tocsr(M)
+    with stage("tocsr"):
+        M = utils.tocsr(M)
     return scoreUtils.Chromosome(M, model=model, raw_M=M, weights=None, cname=cname,
                                  lower=args.lower, upper=args.upper, res=args.resolution,
                                  width=width, device=device)
@@ -79,10 +83,12 @@ def main(args):
     if rank == 0 and os.path.exists(args.output):
         os.remove(args.output)
 
-    model = load_model(args.model)
+    with stage("load the model"):
+        model = load_model(args.model)
     correct = False if args.clr_weight_name.lower() == 'raw' else args.clr_weight_name
     width = int((np.sqrt(model.feature_importances_.size) - 1) / 2)
-    Lib = io.open_map(args.path)
+    with stage("open the contact map"):
+        Lib = io.open_map(args.path)
     queue = select_chromosomes(Lib.chromnames[:], args.chroms)
 
     # PK_FORCE_DIST=1 sends a single rank down the multi-rank branch (tests)
@@ -91,7 +97,8 @@ def main(args):
             cname = key if key.startswith('chr') else 'chr' + key
             X = build_chromosome(Lib, key, cname, model, correct, args, width, local_rank, inputs)
             result, R = X.score(thre=args.minimum_prob)
-            X.writeBed(args.output, result, R)
+            with stage("writeBed"):
+                X.writeBed(args.output, result, R)
         return
 
     # N ranks: chromosomes are independent units; weigh them by bin count^1
