@@ -91,6 +91,22 @@ void pk_matrix_destroy(pk_matrix *);
  * that are not non-negative integers, [3] finite negative entries; *vmax largest finite value. */
 pk_csr *pk_csr_upload(int device, int32_t n, const int32_t *indptr, const int32_t *indices,
                       const double *data);
+/* The same from a chromosome AS A CONTACT-MAP FILE STORES IT: the upper triangle, pixels sorted
+ * by (bin1, bin2) -- a .cool's pixel table, which the reference has cooler mirror and balance on
+ * the host first (peakachu/score_genome.py:55-57: matrix(balance=name, sparse=True).fetch, then
+ * utils.tocsr, peakachu/utils.py:10-15).  indptr[n+1]: first pixel of each bin1 (relative to the
+ * chromosome's first pixel), cols: bin2 relative to the chromosome's first bin (entries with
+ * cols >= n are pixels of other chromosomes and are ignored), counts: int32, or float64 when
+ * counts_are_f64.  The pk_csr stands for the MIRRORED matrix; with bias != NULL its values are
+ * (bias[row] * bias[col]) * count -- cooler's api.matrix multiplies the two biases first -- NaN
+ * where a bias is NaN.  A table that is not in that order (a column left of the diagonal, columns
+ * not strictly ascending inside a row) is refused with PK_E_INVALID's message. */
+pk_csr *pk_csr_upload_upper(int device, int32_t n, const int32_t *indptr, const int32_t *cols,
+                            const void *counts, int counts_are_f64, const double *bias);
+/* another view of the same stored entries with other biases (NULL: the plain values): nothing is
+ * uploaded again.  score_genome's balanced mode needs two matrices per chromosome, the balanced
+ * one for the windows and the raw one for the Poisson candidates (peakachu/score_genome.py:55-58). */
+pk_csr *pk_csr_view(pk_csr *, const double *bias);
 void pk_csr_destroy(pk_csr *);
 int pk_csr_info(const pk_csr *, int64_t info[4], double *vmax);
 /* band of col-row in [dlo, dhi] holding the finite non-zero entries (keep_nan = 0: the

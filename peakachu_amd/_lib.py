@@ -43,6 +43,8 @@ SIGNATURES = {
                                C.c_int32, C.c_int32]),
     "pk_matrix_destroy": (None, [_vp]),
     "pk_csr_upload": (_vp, [C.c_int, C.c_int32, _i32p, _i32p, _f64p]),
+    "pk_csr_upload_upper": (_vp, [C.c_int, C.c_int32, _i32p, _i32p, _vp, C.c_int, _vp]),
+    "pk_csr_view": (_vp, [_vp, _vp]),
     "pk_csr_destroy": (None, [_vp]),
     "pk_csr_info": (C.c_int, [_vp, _i64p, C.POINTER(C.c_double)]),
     "pk_matrix_from_csr": (_vp, [_vp, C.c_int32, C.c_int32, C.c_int]),
@@ -254,11 +256,46 @@ class HipCsr:
         if not self.h:
             raise PeakachuHipError("pk_csr_upload: " + last_error())
         self.device = device
+        self._facts()
+
+    def _facts(self):
         info = np.zeros(4, np.int64)
         vmax = C.c_double(0.0)
-        check(L.pk_csr_info(self.h, info, C.byref(vmax)), "pk_csr_info")
+        check(self._L.pk_csr_info(self.h, info, C.byref(vmax)), "pk_csr_info")
         self.n_finite, self.n_nonfinite, self.n_noninteger, self.n_negative = [int(v) for v in info]
         self.vmax = float(vmax.value)
+
+    @classmethod
+    def from_upper(cls, n, indptr, cols, counts, bias=None, device=0):
+        """A chromosome's upper triangle as a contact-map file stores it (pk_csr_upload_upper):
+        the handle stands for the mirrored matrix, balanced by `bias` when given."""
+        L = require_device()
+        self = cls.__new__(cls)
+        self._L, self.n, self.device = L, int(n), device
+        indptr = np.ascontiguousarray(indptr, np.int32)
+        nnz = int(indptr[-1])
+        cols = np.ascontiguousarray(cols, np.int32) if nnz else np.zeros(1, np.int32)
+        counts = np.asarray(counts)
+        f64 = counts.dtype != np.int32
+        counts = np.ascontiguousarray(counts, np.float64 if f64 else np.int32) if nnz else np.zeros(1, np.int32)
+        b = None if bias is None else np.ascontiguousarray(bias, np.float64)
+        self.h = L.pk_csr_upload_upper(device, self.n, indptr, cols, counts.ctypes.data, 1 if (f64 and nnz) else 0,
+                                       None if b is None else b.ctypes.data)
+        if not self.h:
+            raise PeakachuHipError("pk_csr_upload_upper: " + last_error())
+        self._facts()
+        return self
+
+    def view(self, bias=None):
+        """The same stored entries with other biases (None: the plain values), nothing uploaded again."""
+        b = None if bias is None else np.ascontiguousarray(bias, np.float64)
+        h = self._L.pk_csr_view(self.h, None if b is None else b.ctypes.data)
+        if not h:
+            raise PeakachuHipError("pk_csr_view: " + last_error())
+        other = type(self).__new__(type(self))
+        other._L, other.n, other.device, other.h = self._L, self.n, self.device, h
+        other._facts()
+        return other
 
     def band(self, dlo, dhi, keep_nan=False):
         h = self._L.pk_matrix_from_csr(self.h, int(dlo), int(dhi), 1 if keep_nan else 0)

@@ -140,97 +140,74 @@ class CoolFile:
             return bool(attr)
         return name in ("KR", "VC", "SQRT_VC")
 
-    def _mirrored(self, chrom, lo, hi):
-        """(row, col, count) of the chromosome's symmetric matrix.  The scoring drivers fetch a
-        chromosome twice in balanced mode (balanced values, then raw counts): the pixels are
-        read and inflated once."""
-        with self._pixel_lock:
-            hit = self._pixel_cache.get(chrom)
-        if hit is not None:
-            return hit
-        n = hi - lo
+    def _read_upper(self, lo, hi):
+        """The chromosome's rows of the pixel table: (indptr [n+1], bin2 relative to the
+        chromosome as int32 -- >= n for the trans pixels that share the rows --, counts)."""
         if self._bin1_offset is None:
             self._bin1_offset = self._g["indexes/bin1_offset"].read().astype(np.int64)
         off = self._bin1_offset[lo:hi + 1]
         p0, p1 = int(off[0]), int(off[-1])
         # pixels are sorted by (bin1, bin2): bin1 follows from the index, no need to read it
-        i = np.repeat(np.arange(n, dtype=np.int32), np.diff(off))
         with stage("read: HDF5 pixel chunks (bin2_id, count)"):
             j = self._g["pixels/bin2_id"][p0:p1]
             v = self._g["pixels/count"][p0:p1]
-        with stage("read: mirror the pixels to the symmetric matrix"):
-            return self._assemble(chrom, n, lo, hi, i, j, v)
+        j = (j - lo).astype(np.int32)   # bin2 >= bin1 >= lo always
+        return (off - p0).astype(np.int32), j, v
 
-    def _assemble(self, chrom, n, lo, hi, i, j, v):
-        cis = j < hi  # bin2 >= bin1 >= lo always; drop the trans pixels
-        j = (j - lo).astype(np.int32)
-        if not cis.all():
-            i, j, v = i[cis], j[cis], v[cis]
-        # The mirrored matrix in CANONICAL order (row-major, columns ascending) without a sort of
-        # the pixel list: upper part U = the file's own order (a canonical CSR as it stands),
-        # lower part = the transpose of U without its diagonal (scipy's csc -> csr, a counting
-        # sort), rows merged by scipy's sorted-row addition.  What utils.tocsr makes of the
-        # result is canonical from the start: canonical_csr has nothing to sum or sort (0.55 s
-        # per 15.7 M-pixel file before).
-        indptr_u = np.zeros(n + 1, np.int64)
-        np.cumsum(np.bincount(i, minlength=n), out=indptr_u[1:])
-        U = sparse.csr_matrix((v, j, indptr_u.astype(np.int32)), shape=(n, n))
-        if v.size and not np.all(v != 0):
-            out = self._mirror_by_scatter(i, j, v, n)  # (sorted-row addition drops explicit zeros)
-        else:
-            off_diag = i != j
-            indptr_s = np.zeros(n + 1, np.int64)
-            np.cumsum(np.bincount(i[off_diag], minlength=n), out=indptr_s[1:])
-            Us = sparse.csr_matrix((v[off_diag], j[off_diag], indptr_s.astype(np.int32)), shape=(n, n))
-            M = Us.T.tocsr() + U
-            row = np.repeat(np.arange(n, dtype=np.int32), np.diff(M.indptr))
-            out = (row, M.indices, M.data, M.indptr)
-        # Is the result canonical (rows in order, columns strictly ascending inside a row)?  It is for
-        # every conforming file (pixels sorted by bin1, bin2, no duplicates); a file that is not gets no
-        # row pointer attached, and utils.tocsr then sorts and sums like the reference's conversion.
-        if not self._is_canonical(out[0], out[1]):
-            out = (out[0], out[1], out[2], None)
-        # the matrices handed out share these arrays (a chromosome's two fetches, balanced and raw,
-        # would otherwise copy 4 x 56 MB for 25 000 bins): nobody may write into them
-        for a in out:
-            if a is not None:
-                a.flags.writeable = False
+    def upper(self, chrom):
+        """The chromosome as the file stores it (utils.UpperPixels): no mirroring, no balancing,
+        nothing cached -- `Chromosome.from_upper` has the device do both from one upload."""
+        from .utils import UpperPixels
+        lo, hi = self.extent(chrom)
+        with self._pixel_lock:
+            self.pixel_reads += 1
+        return UpperPixels(hi - lo, *self._read_upper(lo, hi))
+
+    def bias(self, name, chrom):
+        """(bias, column): the vector cooler multiplies the counts with -- 1 / column for divisive
+        columns -- and the column as `bins().fetch(chrom)[name].values` returns it."""
+        lo, hi = self.extent(chrom)
+        w = self._weights(name, lo, hi)
+        if self._divisive(name):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                return 1.0 / w, w
+        return w, w
+
+    def _mirrored(self, chrom, lo, hi):
+        """(row, col, count) of the chromosome's symmetric matrix.  The scoring drivers fetch a
+        chromosome twice in balanced mode (balanced values, then raw counts): the pixels are
+        read and inflated once."""
+        from . import utils
+        with self._pixel_lock:
+            hit = self._pixel_cache.get(chrom)
+        if hit is not None:
+            return hit
+        n = hi - lo
+        indptr_u, j, v = self._read_upper(lo, hi)
+        with stage("read: mirror the pixels to the symmetric matrix"):
+            i = np.repeat(np.arange(n, dtype=np.int32), np.diff(indptr_u))
+            cis = j < n   # drop the trans pixels
+            if not cis.all():
+                i, j, v = i[cis], j[cis], v[cis]
+            # The mirrored matrix in CANONICAL order without a sort of the pixel list (what
+            # utils.tocsr makes of the result is canonical from the start: canonical_csr has
+            # nothing to sum or sort -- 0.55 s per 15.7 M-pixel file before).
+            out = utils.mirror_upper(i, j, v, n)
+            # Is the result canonical (rows in order, columns strictly ascending inside a row)?  It is for
+            # every conforming file (pixels sorted by bin1, bin2, no duplicates); a file that is not gets no
+            # row pointer attached, and utils.tocsr then sorts and sums like the reference's conversion.
+            if not utils.is_canonical(out[0], out[1]):
+                out = (out[0], out[1], out[2], None)
+            # the matrices handed out share these arrays (a chromosome's two fetches, balanced and raw,
+            # would otherwise copy 4 x 56 MB for 25 000 bins): nobody may write into them
+            for a in out:
+                if a is not None:
+                    a.flags.writeable = False
         with self._pixel_lock:
             self.pixel_reads += 1
             self._pixel_cache[chrom] = out
             self._evict()
         return out
-
-    @staticmethod
-    def _is_canonical(row, col):
-        """Rows in order, columns strictly ascending inside a row (no duplicates)."""
-        if col.size < 2:
-            return True
-        return bool(np.all(row[1:] >= row[:-1])) and bool(np.all((col[1:] > col[:-1]) | (row[1:] != row[:-1])))
-
-    @staticmethod
-    def _mirror_by_scatter(i, j, v, n):
-        """The same canonical (row, col, value, indptr) with numpy alone: row r = its lower entries
-        (the pixels of column r above the diagonal, ordered by their row = a stable sort by
-        column) followed by its upper entries (already in order)."""
-        strict = np.flatnonzero(i != j)
-        lo_order = strict[np.argsort(j[strict], kind="stable")]
-        cnt_u = np.bincount(i, minlength=n)
-        cnt_l = np.bincount(j[strict], minlength=n)
-        indptr = np.zeros(n + 1, np.int64)
-        np.cumsum(cnt_u + cnt_l, out=indptr[1:])
-        start_l = np.cumsum(cnt_l) - cnt_l
-        start_u = np.cumsum(cnt_u) - cnt_u
-        total = int(indptr[-1])
-        row = np.empty(total, np.int32)
-        col = np.empty(total, np.int32)
-        val = np.empty(total, v.dtype)
-        rl = j[lo_order]                       # row of a lower entry = the pixel's column
-        pos_l = indptr[:-1][rl] + (np.arange(rl.size, dtype=np.int64) - start_l[rl])
-        row[pos_l], col[pos_l], val[pos_l] = rl, i[lo_order], v[lo_order]
-        pos_u = indptr[:-1][i] + cnt_l[i] + (np.arange(i.size, dtype=np.int64) - start_u[i])
-        row[pos_u], col[pos_u], val[pos_u] = i, j, v
-        return row, col, val, indptr.astype(np.int32)
 
     def _balanced(self, name, lo, hi, col, data, indptr):
         w = self._weights(name, lo, hi)

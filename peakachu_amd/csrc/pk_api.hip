@@ -798,6 +798,42 @@ extern "C" pk_matrix *pk_matrix_create(int device, int32_t n, const int32_t *ind
 }
 
 // ------------------------------------------- uploaded CSR and what is made from it
+// scan of a pk_csr's entries (with its bias, if any): facts and validity flags
+static bool csr_scan(pk_device_ctx *ctx, pk_csr *c, const char *who)
+{
+    unsigned long long *d_info = nullptr;
+    bool ok = hipMalloc((void **)&c->valid_raw, (size_t)c->n) == hipSuccess &&
+              hipMalloc((void **)&c->valid_bal, (size_t)c->n) == hipSuccess &&
+              hipMalloc((void **)&d_info, 6 * sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) pk_set_error("%s: device allocation failed (%d bins)", who, c->n);
+    if (ok) {
+        ok = pk_launch_csr_info(ctx, c->indptr, c->indices, c->data, c->nnz, c->n, d_info, c->valid_raw, c->valid_bal,
+                                c->bias, c->upper ? 1 : 0) == PK_OK &&
+             hipMemcpyAsync(c->info, d_info, sizeof(c->info), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+             hipStreamSynchronize(ctx->stream) == hipSuccess;
+        if (!ok && !g_err[0]) pk_set_error("%s: upload / scan failed", who);
+    }
+    if (d_info) hipFree(d_info);
+    if (ok && c->upper && c->info[5]) {
+        pk_set_error("%s: %llu pixels are out of order (columns must ascend strictly inside a row and none may lie "
+                     "left of the diagonal); mirror the table on the host instead", who, c->info[5]);
+        ok = false;
+    }
+    return ok;
+}
+
+static bool upload_bias(pk_device_ctx *ctx, pk_csr *c, const double *bias, const char *who)
+{
+    c->bias = nullptr;
+    if (!bias) return true;
+    if (hipMalloc((void **)&c->bias, sizeof(double) * (size_t)c->n) != hipSuccess ||
+        hipMemcpyAsync(c->bias, bias, sizeof(double) * (size_t)c->n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        pk_set_error("%s: upload of the bias vector failed", who);
+        return false;
+    }
+    return true;
+}
+
 extern "C" pk_csr *pk_csr_upload(int device, int32_t n, const int32_t *indptr, const int32_t *indices,
                                  const double *data)
 {
@@ -813,14 +849,14 @@ extern "C" pk_csr *pk_csr_upload(int device, int32_t n, const int32_t *indptr, c
     c->device = device;
     c->n = n;
     c->nnz = indptr[n];
+    c->pix = new pk_pixels();
+    memset(c->pix, 0, sizeof(*c->pix));
+    c->pix->refs = 1;
     const size_t z = (size_t)(c->nnz > 0 ? c->nnz : 1);
-    unsigned long long *d_info = nullptr;
-    bool ok = hipMalloc((void **)&c->indptr, sizeof(int32_t) * (size_t)(n + 1)) == hipSuccess &&
-              hipMalloc((void **)&c->indices, sizeof(int32_t) * z) == hipSuccess &&
-              hipMalloc((void **)&c->data, sizeof(double) * z) == hipSuccess &&
-              hipMalloc((void **)&c->valid_raw, (size_t)n) == hipSuccess &&
-              hipMalloc((void **)&c->valid_bal, (size_t)n) == hipSuccess &&
-              hipMalloc((void **)&d_info, 5 * sizeof(unsigned long long)) == hipSuccess;
+    bool ok = hipMalloc((void **)&c->pix->indptr, sizeof(int32_t) * (size_t)(n + 1)) == hipSuccess &&
+              hipMalloc((void **)&c->pix->indices, sizeof(int32_t) * z) == hipSuccess &&
+              hipMalloc((void **)&c->pix->data, sizeof(double) * z) == hipSuccess;
+    c->indptr = c->pix->indptr, c->indices = c->pix->indices, c->data = c->pix->data;
     if (!ok) pk_set_error("pk_csr_upload: device allocation failed (%lld entries)", (long long)c->nnz);
     if (ok) {
         ok = hipMemcpyAsync(c->indptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
@@ -830,17 +866,88 @@ extern "C" pk_csr *pk_csr_upload(int device, int32_t n, const int32_t *indptr, c
                                 ctx->stream) == hipSuccess &&
                  hipMemcpyAsync(c->data, data, sizeof(double) * z, hipMemcpyHostToDevice, ctx->stream) ==
                      hipSuccess;
-        if (ok)
-            ok = pk_launch_csr_info(ctx, c->indptr, c->indices, c->data, c->nnz, n, d_info, c->valid_raw,
-                                    c->valid_bal) == PK_OK;
-        if (ok)
-            ok = hipMemcpyAsync(c->info, d_info, sizeof(c->info), hipMemcpyDeviceToHost, ctx->stream) ==
-                     hipSuccess &&
-                 hipStreamSynchronize(ctx->stream) == hipSuccess;
-        if (!ok && !g_err[0]) pk_set_error("pk_csr_upload: upload / scan failed");
+        if (!ok) pk_set_error("pk_csr_upload: upload failed");
+        if (ok) ok = csr_scan(ctx, c, "pk_csr_upload");
     }
-    if (d_info) hipFree(d_info);
     if (!ok) {
+        pk_csr_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" pk_csr *pk_csr_upload_upper(int device, int32_t n, const int32_t *indptr, const int32_t *cols,
+                                       const void *counts, int counts_are_f64, const double *bias)
+{
+    PK_DEV_LOCK(device);
+    if (n <= 0 || !indptr || indptr[0] != 0 || indptr[n] < 0 || (indptr[n] > 0 && (!cols || !counts))) {
+        pk_set_error("pk_csr_upload_upper: bad arguments / malformed pixel table");
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(device);
+    if (!ctx) return nullptr;
+    pk_csr *c = new pk_csr();
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    c->n = n;
+    c->nnz = indptr[n];
+    c->upper = true;
+    c->pix = new pk_pixels();
+    memset(c->pix, 0, sizeof(*c->pix));
+    c->pix->refs = 1;
+    const size_t z = (size_t)(c->nnz > 0 ? c->nnz : 1);
+    int32_t *d_cnt = nullptr;
+    bool ok = hipMalloc((void **)&c->pix->indptr, sizeof(int32_t) * (size_t)(n + 1)) == hipSuccess &&
+              hipMalloc((void **)&c->pix->indices, sizeof(int32_t) * z) == hipSuccess &&
+              hipMalloc((void **)&c->pix->data, sizeof(double) * z) == hipSuccess &&
+              (counts_are_f64 || hipMalloc((void **)&d_cnt, sizeof(int32_t) * z) == hipSuccess);
+    c->indptr = c->pix->indptr, c->indices = c->pix->indices, c->data = c->pix->data;
+    if (!ok) pk_set_error("pk_csr_upload_upper: device allocation failed (%lld pixels)", (long long)c->nnz);
+    if (ok) {
+        ok = hipMemcpyAsync(c->indptr, indptr, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyHostToDevice,
+                            ctx->stream) == hipSuccess;
+        if (ok && c->nnz > 0) {
+            ok = hipMemcpyAsync(c->indices, cols, sizeof(int32_t) * z, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+            if (ok && counts_are_f64)
+                ok = hipMemcpyAsync(c->data, counts, sizeof(double) * z, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+            else if (ok)
+                ok = hipMemcpyAsync(d_cnt, counts, sizeof(int32_t) * z, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                     pk_launch_counts_to_f64(ctx, d_cnt, c->data, c->nnz) == PK_OK;
+        }
+        if (!ok && !g_err[0]) pk_set_error("pk_csr_upload_upper: upload failed");
+        if (ok) ok = upload_bias(ctx, c, bias, "pk_csr_upload_upper");
+        if (ok) ok = csr_scan(ctx, c, "pk_csr_upload_upper");
+    }
+    if (d_cnt) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(d_cnt);
+    }
+    if (!ok) {
+        pk_csr_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" pk_csr *pk_csr_view(pk_csr *src, const double *bias)
+{
+    PK_DEV_LOCK(src ? src->device : 0);
+    if (!src || !src->pix) {
+        pk_set_error("pk_csr_view: bad arguments");
+        return nullptr;
+    }
+    pk_device_ctx *ctx = pk_ctx(src->device);
+    if (!ctx) return nullptr;
+    pk_csr *c = new pk_csr();
+    memset(c, 0, sizeof(*c));
+    c->device = src->device;
+    c->n = src->n;
+    c->nnz = src->nnz;
+    c->upper = src->upper;
+    c->pix = src->pix;
+    c->pix->refs++;
+    c->indptr = c->pix->indptr, c->indices = c->pix->indices, c->data = c->pix->data;
+    if (!upload_bias(ctx, c, bias, "pk_csr_view") || !csr_scan(ctx, c, "pk_csr_view")) {
         pk_csr_destroy(c);
         return nullptr;
     }
@@ -852,9 +959,15 @@ extern "C" void pk_csr_destroy(pk_csr *c)
     PK_DEV_LOCK(c ? c->device : 0);
     if (!c) return;
     hipSetDevice(c->device);
-    void *ptrs[] = {c->indptr, c->indices, c->data, c->valid_raw, c->valid_bal};
+    void *ptrs[] = {c->valid_raw, c->valid_bal, c->bias};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (c->pix && --c->pix->refs == 0) {
+        void *shared[] = {c->pix->indptr, c->pix->indices, c->pix->data};
+        for (void *p : shared)
+            if (p) hipFree(p);
+        delete c->pix;
+    }
     delete c;
 }
 
@@ -894,7 +1007,8 @@ extern "C" pk_matrix *pk_matrix_from_csr(pk_csr *c, int32_t dlo, int32_t dhi, in
     if (!ok) pk_set_error("pk_matrix_from_csr: device allocation of %zu band bytes failed", band_bytes);
     if (ok && with_norm) m->norm = m->band + band_bytes / sizeof(double);
     if (ok)
-        ok = pk_launch_band_build(ctx, m, c->indptr, c->indices, c->data, c->nnz, keep_nan ? 2 : 1) == PK_OK &&
+        ok = pk_launch_band_build(ctx, m, c->indptr, c->indices, c->data, c->nnz, keep_nan ? 2 : 1, c->bias,
+                                  c->upper ? 1 : 0) == PK_OK &&
              hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (!ok) {
         if (!g_err[0]) pk_set_error("pk_matrix_from_csr: band build failed");

@@ -353,14 +353,24 @@ struct pk_matrix {
 
 // a contact matrix uploaded once (CSR); bands, validity flags and value facts are made
 // from it on the device
+// the stored entries of an uploaded matrix; shared by a pk_csr and the views made of it
+struct pk_pixels {
+    int32_t *indptr, *indices;   // device
+    double *data;                // device
+    int refs;                    // handles that point here (under the device lock)
+};
+
 struct pk_csr {
     int device;
     int32_t n;
     int64_t nnz;
-    int32_t *indptr, *indices;   // device
+    int32_t *indptr, *indices;   // device (= pix->...)
     double *data;                // device
     uint8_t *valid_raw, *valid_bal;  // device [n], see csr_info_kernel
-    unsigned long long info[5];  // host copy: finite, non-finite, non-integer, negative, max bits
+    unsigned long long info[6];  // host copy: finite, non-finite, non-integer, negative, max bits, entries out of order
+    pk_pixels *pix;              // owner of indptr / indices / data
+    bool upper;                  // the arrays hold the upper triangle of a symmetric matrix (a .cool's pixel table)
+    double *bias;                // device [n] or nullptr: entry values are (bias[row] * bias[col]) * data
 };
 
 struct pk_cands {
@@ -389,10 +399,12 @@ struct pk_cands {
 // ------------------------------------------------------------ kernel entry
 // (implemented in the .hip files; all launch on ctx->stream)
 int pk_launch_band_build(pk_device_ctx *, pk_matrix *, const int32_t *d_indptr,
-                         const int32_t *d_indices, const double *d_data, int64_t nnz, int filter);
+                         const int32_t *d_indices, const double *d_data, int64_t nnz, int filter,
+                         const double *d_bias = nullptr, int upper = 0);
 int pk_launch_csr_info(pk_device_ctx *, const int32_t *d_indptr, const int32_t *d_indices,
-                       const double *d_data, int64_t nnz, int n, unsigned long long *d_info5,
-                       uint8_t *d_valid_raw, uint8_t *d_valid_bal);
+                       const double *d_data, int64_t nnz, int n, unsigned long long *d_info6,
+                       uint8_t *d_valid_raw, uint8_t *d_valid_bal, const double *d_bias = nullptr, int upper = 0);
+int pk_launch_counts_to_f64(pk_device_ctx *, const int32_t *d_src, double *d_dst, int64_t n);
 
 // features of candidates [c0, c0+cn) -> tiles (tile width BLK) + status.
 // If fea64_rows != nullptr also writes row-major float64 features [cn][F].

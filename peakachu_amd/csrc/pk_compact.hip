@@ -22,21 +22,29 @@ __device__ __forceinline__ int csr_row_of(const int32_t *__restrict__ indptr, in
 // ---- CSR -> diagonal-major band: one thread per stored entry ------------
 // filter: 0 = every stored entry (the host has filtered already), 1 = finite non-zero
 // entries only (the band filter of peakachu/scoreUtils.py:30-33 done here), 2 = non-zero
-// entries including NaN (what utils.calculate_expected keeps in balanced mode)
+// entries including NaN (what utils.calculate_expected keeps in balanced mode).
+// bias != nullptr: the value of an entry is (bias[row] * bias[col]) * data -- what cooler's
+// matrix(balance=name) hands peakachu/score_genome.py:55, the two biases multiplied first.
+// upper: the arrays hold the UPPER triangle only, as a .cool stores a chromosome (col >= row;
+// entries with col >= n are pixels of other chromosomes and are skipped); the matrix is its
+// mirror image, so an entry off the diagonal is written twice.
 __global__ void band_build_kernel(const int32_t *__restrict__ indptr,
                                   const int32_t *__restrict__ indices,
                                   const double *__restrict__ data, int64_t nnz, int n, int dlo,
-                                  int dhi, int64_t ld, double *__restrict__ band, int filter)
+                                  int dhi, int64_t ld, double *__restrict__ band, int filter,
+                                  const double *__restrict__ bias, int upper)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nnz) return;
     const int col = indices[e];
-    const double v = data[e];
-    if (filter && (v == 0.0 || (filter == 1 && !(v - v == 0.0)))) return;  // (v - v != 0: inf or NaN)
+    double v = data[e];
+    if (col < 0 || col >= n) return;
     const int r = csr_row_of(indptr, n, e);
+    if (bias) v = (bias[r] * bias[col]) * v;
+    if (filter && (v == 0.0 || (filter == 1 && !(v - v == 0.0)))) return;  // (v - v != 0: inf or NaN)
     const int k = col - r;
-    if (k < dlo || k > dhi || col < 0 || col >= n) return;
-    band[(int64_t)(k - dlo) * ld + r] = v;
+    if (k >= dlo && k <= dhi) band[(int64_t)(k - dlo) * ld + r] = v;
+    if (upper && k > 0 && -k >= dlo && -k <= dhi) band[(int64_t)(-k - dlo) * ld + col] = v;
 }
 
 // ---- facts about the stored values, and the bins calculate_expected calls valid -------
@@ -49,44 +57,69 @@ __global__ void csr_info_kernel(const int32_t *__restrict__ indptr, const int32_
                                 const double *__restrict__ data, int64_t nnz, int n,
                                 unsigned long long *__restrict__ info,
                                 unsigned long long *__restrict__ vmax_bits,
-                                uint8_t *__restrict__ valid_raw, uint8_t *__restrict__ valid_bal)
+                                uint8_t *__restrict__ valid_raw, uint8_t *__restrict__ valid_bal,
+                                const double *__restrict__ bias, int upper,
+                                unsigned long long *__restrict__ bad_order)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned c_fin = 0, c_non = 0, c_frac = 0, c_neg = 0;
+    unsigned c_fin = 0, c_non = 0, c_frac = 0, c_neg = 0, c_off = 0;
     unsigned long long mx = 0;
     if (e < nnz) {
-        const double v = data[e];
+        double v = data[e];
         const int col = indices[e];
-        if (!(v - v == 0.0)) {
+        const bool inside = col >= 0 && col < n;
+        int r = -1;
+        if (upper || bias) {
+            r = csr_row_of(indptr, n, e);
+            // an upper-triangle table must be what a .cool holds: columns strictly ascending
+            // inside a row, none left of the diagonal (a duplicate pixel would be written, not summed)
+            if (upper && (col < r || (e > (int64_t)indptr[r] && indices[e - 1] >= col))) atomicAdd(bad_order, 1ull);
+            if (bias && inside) v = (bias[r] * bias[col]) * v;
+        }
+        if (upper && !inside) {
+            // a pixel of another chromosome: not part of this matrix
+        } else if (!(v - v == 0.0)) {
             c_non = 1;
+            c_off = upper && col != r;
         } else if (v != 0.0) {
             c_fin = 1;
+            c_off = upper && col != r;
             if (v < 0.0) c_neg = 1;
             if (v < 0.0 || v != __builtin_floor(v)) c_frac = 1;
+            if (r < 0 && inside) r = csr_row_of(indptr, n, e);
             if (v > 0.0) {
                 mx = (unsigned long long)__double_as_longlong(v);
-                if (col >= 0 && col < n) valid_raw[col] = 1;
+                if (inside) valid_raw[col] = 1;
+                if (upper) valid_raw[r] = 1;  // (the mirrored entry sits in column r)
             }
-            if (col >= 0 && col < n) {
+            if (inside) {
                 valid_bal[col] = 1;
-                valid_bal[csr_row_of(indptr, n, e)] = 1;
+                valid_bal[r] = 1;
             }
         }
     }
-    // wave-level reduction, one atomic per wave and counter
+    // wave-level reduction, one atomic per wave and counter (an off-diagonal entry of an
+    // upper-triangle table stands for two entries of the matrix)
     const unsigned long long m_fin = __ballot(c_fin), m_non = __ballot(c_non), m_frac = __ballot(c_frac),
-                             m_neg = __ballot(c_neg);
+                             m_neg = __ballot(c_neg), m_off = __ballot(c_off);
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned long long other = __shfl_xor(mx, o);
         mx = other > mx ? other : mx;
     }
     if ((threadIdx.x & 63) == 0) {
-        if (m_fin) atomicAdd(&info[0], (unsigned long long)__popcll(m_fin));
-        if (m_non) atomicAdd(&info[1], (unsigned long long)__popcll(m_non));
-        if (m_frac) atomicAdd(&info[2], (unsigned long long)__popcll(m_frac));
-        if (m_neg) atomicAdd(&info[3], (unsigned long long)__popcll(m_neg));
+        if (m_fin) atomicAdd(&info[0], (unsigned long long)(__popcll(m_fin) + __popcll(m_fin & m_off)));
+        if (m_non) atomicAdd(&info[1], (unsigned long long)(__popcll(m_non) + __popcll(m_non & m_off)));
+        if (m_frac) atomicAdd(&info[2], (unsigned long long)(__popcll(m_frac) + __popcll(m_frac & m_off)));
+        if (m_neg) atomicAdd(&info[3], (unsigned long long)(__popcll(m_neg) + __popcll(m_neg & m_off)));
         if (mx) atomicMax(vmax_bits, mx);
     }
+}
+
+// int32 counts of a pixel table -> the float64 values every other kernel reads
+__global__ void counts_to_f64_kernel(const int32_t *__restrict__ src, double *__restrict__ dst, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
 }
 
 // ---- survivors per reference batch (scoreUtils.py:104-108) --------------
@@ -515,17 +548,27 @@ int pk_launch_expected_means(pk_device_ctx *ctx, const pk_matrix *m, int first, 
 }
 
 int pk_launch_csr_info(pk_device_ctx *ctx, const int32_t *d_indptr, const int32_t *d_indices,
-                       const double *d_data, int64_t nnz, int n, unsigned long long *d_info5,
-                       uint8_t *d_valid_raw, uint8_t *d_valid_bal)
+                       const double *d_data, int64_t nnz, int n, unsigned long long *d_info6,
+                       uint8_t *d_valid_raw, uint8_t *d_valid_bal, const double *d_bias, int upper)
 {
     pk_prof_scope prof(ctx, PK_K_BAND);
-    PK_HIP(hipMemsetAsync(d_info5, 0, 5 * sizeof(unsigned long long), ctx->stream));
+    PK_HIP(hipMemsetAsync(d_info6, 0, 6 * sizeof(unsigned long long), ctx->stream));
     PK_HIP(hipMemsetAsync(d_valid_raw, 0, (size_t)n, ctx->stream));
     PK_HIP(hipMemsetAsync(d_valid_bal, 0, (size_t)n, ctx->stream));
     if (nnz > 0) {
         hipLaunchKernelGGL(csr_info_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream,
-                           d_indptr, d_indices, d_data, nnz, n, d_info5, d_info5 + 4, d_valid_raw,
-                           d_valid_bal);
+                           d_indptr, d_indices, d_data, nnz, n, d_info6, d_info6 + 4, d_valid_raw,
+                           d_valid_bal, d_bias, upper, d_info6 + 5);
+        PK_HIP(hipGetLastError());
+    }
+    return PK_OK;
+}
+
+int pk_launch_counts_to_f64(pk_device_ctx *ctx, const int32_t *d_src, double *d_dst, int64_t n)
+{
+    if (n > 0) {
+        hipLaunchKernelGGL(counts_to_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_src,
+                           d_dst, n);
         PK_HIP(hipGetLastError());
     }
     return PK_OK;
@@ -560,7 +603,8 @@ int pk_launch_candidates(pk_device_ctx *ctx, const pk_matrix *raw, int lower, in
 }
 
 int pk_launch_band_build(pk_device_ctx *ctx, pk_matrix *m, const int32_t *d_indptr,
-                         const int32_t *d_indices, const double *d_data, int64_t nnz, int filter)
+                         const int32_t *d_indices, const double *d_data, int64_t nnz, int filter,
+                         const double *d_bias, int upper)
 {
     pk_prof_scope prof(ctx, PK_K_BAND);
     const size_t bytes = (size_t)(m->dhi - m->dlo + 1) * m->ld * sizeof(double);
@@ -568,7 +612,7 @@ int pk_launch_band_build(pk_device_ctx *ctx, pk_matrix *m, const int32_t *d_indp
     if (nnz > 0) {
         hipLaunchKernelGGL(band_build_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0,
                            ctx->stream, d_indptr, d_indices, d_data, nnz, m->n, m->dlo, m->dhi,
-                           m->ld, m->band, filter);
+                           m->ld, m->band, filter, d_bias, upper);
         PK_HIP(hipGetLastError());
     }
     return PK_OK;

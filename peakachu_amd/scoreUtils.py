@@ -37,30 +37,56 @@ def _device_forest(model, device):
 class Chromosome():
     def __init__(self, M, model, raw_M=None, weights=None,
                  lower=6, upper=300, cname='chrm', res=10000, width=5, device=0):
-        # peakachu/scoreUtils.py:13-14
-        lower = max(lower, width + 1)
-        upper = min(upper, M.shape[0] - 2 * width)
-        self.raw_M = raw_M
-        self.weights = weights
+        self._common(M.shape, model, weights, lower, upper, cname, res, width, device)
+        self._raw_val = raw_M
         self._raw_is_M = M is raw_M
+        self._M_src, self._M_val = M, None   # self.M (the band-filtered CSR) is made on demand
+        self._pixels = self._bias = None
+        self._prepare()
+
+    @classmethod
+    def from_upper(cls, pixels, model, bias=None, weights=None,
+                   lower=6, upper=300, cname='chrm', res=10000, width=5, device=0):
+        """The same object from a chromosome AS THE CONTACT-MAP FILE STORES IT (utils.UpperPixels:
+        the upper triangle, pixels sorted by bin1, bin2) instead of the mirrored, balanced
+        matrices the reference has cooler make on the host first (peakachu/score_genome.py:55-57):
+        one upload of the pixel table, mirrored and balanced on the device
+        (pk_csr_upload_upper / pk_csr_view).  `bias` = the vector cooler multiplies the counts with
+        (None: raw mode, M is raw_M), `weights` = the bin-weight column handed to get_candidate.
+        `M` / `raw_M` are made on the host only when somebody reads them."""
+        self = cls.__new__(cls)
+        self._common(pixels.shape, model, weights, lower, upper, cname, res, width, device)
+        self._pixels, self._bias = pixels, (None if bias is None else np.ascontiguousarray(bias, np.float64))
+        self._raw_is_M = bias is None
+        self._raw_val = self._M_src = self._M_val = None
+        self._prepare()
+        return self
+
+    def _common(self, shape, model, weights, lower, upper, cname, res, width, device):
+        # peakachu/scoreUtils.py:13-14
+        self.lower = max(lower, width + 1)
+        self.upper = min(upper, shape[0] - 2 * width)
+        self.weights = weights
         self.chromname = cname
         self.r = res
         self.w = width
         self.model = model
-        self.lower, self.upper = lower, upper
         self.device = device
         self._hm = None
         self._hf = None
         self._cands = None
-        self._M_src, self._M_val = M, None   # self.M (the band-filtered CSR) is made on demand
-        self._shape = M.shape
+        self._shape = shape
         self._raw_facts = None
+
+    def _prepare(self):
+        upper, width, weights, device = self.upper, self.w, self.weights, self.device
         # expected values (peakachu/scoreUtils.py:16-24), band filter (:30-33): on the device
         # from one upload of the matrix when its values allow it, else on the host
-        if not self._prepare_on_device(M, raw_M, weights, upper, width):
+        if not self._prepare_on_device(upper, width):
+            M, raw_M = self._source(), self.raw_M
             if weights is None:
                 self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=True, device=device)
-                if M is raw_M:
+                if self._raw_is_M:
                     self.background = self.exp_arr
                 else:
                     self.background = utils.calculate_expected(raw_M, upper + 2 * width, raw=True,
@@ -68,7 +94,29 @@ class Chromosome():
             else:
                 self.exp_arr = utils.calculate_expected(M, upper + 2 * width, raw=False, device=device)
                 self.background = self.exp_arr
-        self.get_candidate(lower, upper)
+        self.get_candidate(self.lower, self.upper)
+
+    # raw_M: what the caller handed in; from_upper makes it when somebody reads it
+    @property
+    def raw_M(self):
+        if self._raw_val is None and self._pixels is not None:
+            with stage("host copy of the mirrored matrix (on demand)"):
+                self._raw_val = self._pixels.symmetric()
+        return self._raw_val
+
+    @raw_M.setter
+    def raw_M(self, value):
+        self._raw_val = value
+
+    def _source(self):
+        """The unfiltered matrix M of the constructor (None once self.M has been made from it)."""
+        if self._M_src is None and self._M_val is None and self._pixels is not None:
+            if self._bias is None:
+                self._M_src = self.raw_M
+            else:
+                with stage("host copy of the mirrored matrix (on demand)"):
+                    self._M_src = self._pixels.symmetric(self._bias)
+        return self._M_src
 
     # self.M: peakachu/scoreUtils.py:30-33 (finite entries with -2w < col-row < upper+2w).
     # The device builds its band straight from the unfiltered matrix with the same filter,
@@ -76,7 +124,7 @@ class Chromosome():
     @property
     def M(self):
         if self._M_val is None:
-            self._M_val = utils.band_filter(self._M_src, self.w, self.upper)
+            self._M_val = utils.band_filter(self._source(), self.w, self.upper)
             self._M_src = None  # the reference keeps the filtered copy only (scoreUtils.py:29)
         return self._M_val
 
@@ -105,18 +153,61 @@ class Chromosome():
                 extra.close()
         return utils.isotonic_expected(exp_arr)
 
-    def _prepare_on_device(self, M, raw_M, weights, upper, width):
+    def _open_on_device(self):
+        """(csr of M, csr of raw_M or None when M is raw_M, stored entries of M / of raw_M)."""
+        if self._pixels is not None:
+            px = self._pixels
+            try:
+                with stage("prepare: H2D of the pixel table + facts (pk_csr_upload_upper)"):
+                    base = _lib.HipCsr.from_upper(px.n, px.indptr, px.cols, px.counts, device=self.device)
+            except _lib.PeakachuHipError as e:
+                if "out of order" not in str(e):
+                    raise
+                # not the table a conforming file holds (unsorted or duplicate pixels): mirror it on
+                # the host, where the conversion sorts and sums like the reference's (utils.py:10-15)
+                self._raw_val = px.symmetric()
+                self._M_src = self._raw_val if self._bias is None else px.symmetric(self._bias)
+                self._pixels = None
+                return self._open_on_device()
+            if self._bias is None:
+                return base, None, px.nnz, px.nnz
+            try:
+                with stage("prepare: balanced view of the pixels (pk_csr_view)"):
+                    return base.view(self._bias), base, px.nnz, px.nnz
+            except Exception:
+                base.close()
+                raise
         with stage("prepare: canonical_csr"):
-            Mc = utils.canonical_csr(M)
-        n = Mc.shape[0]
-        if Mc.nnz == 0 or n <= 2 * width:
+            Mc = utils.canonical_csr(self._M_src)
+        if Mc.nnz == 0:
+            return None, None, 0, 0
+        with stage("prepare: H2D of the CSR + facts (pk_csr_upload)"):
+            csr = _lib.HipCsr(Mc, device=self.device)
+        if self._raw_is_M:
+            return csr, None, Mc.nnz, Mc.nnz
+        try:
+            with stage("prepare: canonical_csr"):
+                Rc = utils.canonical_csr(self.raw_M)
+            if Rc.nnz == 0:
+                return csr, None, Mc.nnz, 0
+            with stage("prepare: H2D of the CSR + facts (pk_csr_upload)"):
+                return csr, _lib.HipCsr(Rc, device=self.device), Mc.nnz, Rc.nnz
+        except Exception:
+            csr.close()
+            raise
+
+    def _prepare_on_device(self, upper, width):
+        weights = self.weights
+        n = self._shape[0]
+        if n <= 2 * width or (self._pixels is not None and self._pixels.nnz == 0):
             return False
         maxdis = upper + 2 * width
         dlo, dhi = -2 * width + 1, max(upper + 2 * width - 1, -2 * width + 1)
         csr = rcsr = None
         try:
-            with stage("prepare: H2D of the CSR + facts (pk_csr_upload)"):
-                csr = _lib.HipCsr(Mc, device=self.device)
+            csr, rcsr, nnz_m, nnz_r = self._open_on_device()
+            if csr is None:
+                return False
             balanced = weights is not None
             if not balanced and csr.n_negative:
                 return False  # the validity test is a sign of a column sum: host path
@@ -130,18 +221,14 @@ class Chromosome():
             if balanced or self._raw_is_M:
                 self.background = self.exp_arr
             if self._raw_is_M:
-                self._raw_facts = dict(integer=csr.n_noninteger == 0, vmax=csr.vmax, nnz=Mc.nnz, band=band)
+                self._raw_facts = dict(integer=csr.n_noninteger == 0, vmax=csr.vmax, nnz=nnz_m, band=band)
             else:
-                with stage("prepare: canonical_csr"):
-                    Rc = utils.canonical_csr(raw_M)
-                if Rc.nnz == 0:
+                if nnz_r == 0:
                     if not balanced:
                         self._hm = None
                         return False
                     self._raw_facts = dict(integer=True, vmax=0.0, nnz=0, band=None)
                     return True
-                with stage("prepare: H2D of the CSR + facts (pk_csr_upload)"):
-                    rcsr = _lib.HipCsr(Rc, device=self.device)
                 if not balanced:
                     # .hic style: M holds normalised values, the background comes from the raw counts
                     if rcsr.n_negative:
@@ -154,7 +241,7 @@ class Chromosome():
                     with stage("prepare: band build (pk_matrix_from_csr)"):
                         rband = rcsr.band(self.lower, hi)
                         rband.dlo, rband.dhi = self.lower, hi
-                self._raw_facts = dict(integer=rcsr.n_noninteger == 0, vmax=rcsr.vmax, nnz=Rc.nnz,
+                self._raw_facts = dict(integer=rcsr.n_noninteger == 0, vmax=rcsr.vmax, nnz=nnz_r,
                                        band=rband, own=True)
             return True
         finally:

@@ -26,7 +26,13 @@ def select_chromosomes(chromnames, chroms):
 
 
 def fetch_inputs(Lib, key, correct):
-    """The reads of peakachu/score_genome.py:55-57 (balanced) / :63 (raw) for one chromosome."""
+    """The reads of peakachu/score_genome.py:55-57 (balanced) / :63 (raw) for one chromosome.
+    A reader that can hand out the chromosome as the file stores it (cool.CoolFile.upper: the
+    upper triangle, no mirroring, no balancing) does so, and the device mirrors and balances
+    (scoreUtils.Chromosome.from_upper); PK_UPPER=0 keeps the host matrices of the reference."""
+    if hasattr(Lib, "upper") and os.environ.get("PK_UPPER", "1") != "0":
+        bias, column = Lib.bias(correct, key) if correct else (None, None)
+        return UpperInputs(Lib.upper(key), bias, column)
     if correct:
         # the built-in reader keeps the chromosome's pixels for the second fetch (cooler has
         # no such notion: nullcontext)
@@ -36,6 +42,11 @@ def fetch_inputs(Lib, key, correct):
                     Lib.matrix(balance=False, sparse=True).fetch(key),
                     Lib.bins().fetch(key)[correct].values)
     return Lib.matrix(balance=False, sparse=True).fetch(key), None, None
+
+
+class UpperInputs:
+    def __init__(self, pixels, bias, weights):
+        self.pixels, self.bias, self.weights = pixels, bias, weights
 
 
 def prefetched(Lib, keys, correct):
@@ -63,7 +74,13 @@ def prefetched(Lib, keys, correct):
 
 def build_chromosome(Lib, key, cname, model, correct, args, width, device, inputs=None):
     """peakachu/score_genome.py:53-67 (the .cool branch)."""
-    M, raw_M, weights = inputs if inputs is not None else fetch_inputs(Lib, key, correct)
+    if inputs is None:
+        inputs = fetch_inputs(Lib, key, correct)
+    if isinstance(inputs, UpperInputs):
+        return scoreUtils.Chromosome.from_upper(inputs.pixels, model=model, bias=inputs.bias, weights=inputs.weights,
+                                                cname=cname, lower=args.lower, upper=args.upper,
+                                                res=args.resolution, width=width, device=device)
+    M, raw_M, weights = inputs
     if correct:
         with stage("tocsr"):
             M, raw_M = utils.tocsr(M), utils.tocsr(raw_M)

@@ -31,6 +31,110 @@ def tocsr(X):
     return sparse.csr_matrix((X.data, (X.row, X.col)), shape=X.shape, dtype=float)
 
 
+def mirror_upper(i, j, v, n):
+    """(row, col, value, indptr) of the symmetric matrix whose upper triangle is the pixel list
+    (i, j, v) -- sorted by (i, j), j >= i, no duplicates: a conforming .cool's -- in CANONICAL
+    order (row-major, columns ascending) without a sort of the list: the upper part U is a
+    canonical CSR as it stands, the lower part the transpose of U without its diagonal (scipy's
+    csc -> csr, a counting sort), rows merged by scipy's sorted-row addition (which drops explicit
+    zeros: a table that holds any takes the numpy route)."""
+    if v.size and not np.all(v != 0):
+        return _mirror_by_scatter(i, j, v, n)
+    indptr_u = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(i, minlength=n), out=indptr_u[1:])
+    U = sparse.csr_matrix((v, j, indptr_u.astype(np.int32)), shape=(n, n))
+    off_diag = i != j
+    indptr_s = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(i[off_diag], minlength=n), out=indptr_s[1:])
+    Us = sparse.csr_matrix((v[off_diag], j[off_diag], indptr_s.astype(np.int32)), shape=(n, n))
+    M = Us.T.tocsr() + U
+    row = np.repeat(np.arange(n, dtype=np.int32), np.diff(M.indptr))
+    return row, M.indices, M.data, M.indptr
+
+
+def _mirror_by_scatter(i, j, v, n):
+    """The same canonical (row, col, value, indptr) with numpy alone: row r = its lower entries
+    (the pixels of column r above the diagonal, ordered by their row = a stable sort by
+    column) followed by its upper entries (already in order)."""
+    strict = np.flatnonzero(i != j)
+    lo_order = strict[np.argsort(j[strict], kind="stable")]
+    cnt_u = np.bincount(i, minlength=n)
+    cnt_l = np.bincount(j[strict], minlength=n)
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(cnt_u + cnt_l, out=indptr[1:])
+    start_l = np.cumsum(cnt_l) - cnt_l
+    start_u = np.cumsum(cnt_u) - cnt_u
+    total = int(indptr[-1])
+    row = np.empty(total, np.int32)
+    col = np.empty(total, np.int32)
+    val = np.empty(total, v.dtype)
+    rl = j[lo_order]                       # row of a lower entry = the pixel's column
+    pos_l = indptr[:-1][rl] + (np.arange(rl.size, dtype=np.int64) - start_l[rl])
+    row[pos_l], col[pos_l], val[pos_l] = rl, i[lo_order], v[lo_order]
+    pos_u = indptr[:-1][i] + cnt_l[i] + (np.arange(i.size, dtype=np.int64) - start_u[i])
+    row[pos_u], col[pos_u], val[pos_u] = i, j, v
+    return row, col, val, indptr.astype(np.int32)
+
+
+def is_canonical(row, col):
+    """Rows in order, columns strictly ascending inside a row (no duplicates)."""
+    if col.size < 2:
+        return True
+    return bool(np.all(row[1:] >= row[:-1])) and bool(np.all((col[1:] > col[:-1]) | (row[1:] != row[:-1])))
+
+
+class UpperPixels:
+    """A chromosome as a contact-map file stores it: the upper triangle, pixels sorted by
+    (bin1, bin2).  `indptr[n+1]` = first pixel of each bin1, `cols` = bin2 relative to the
+    chromosome's first bin -- entries with cols >= n are pixels of OTHER chromosomes that share
+    the rows (a .cool keeps a row's trans pixels behind its cis ones) and are not part of the
+    matrix -- `counts` = the stored counts.  The reference has cooler mirror (and balance) these
+    on the host (peakachu/score_genome.py:55-57); `Chromosome.from_upper` sends them to the
+    device as they are, and `symmetric()` makes the host matrix for whoever asks."""
+
+    def __init__(self, n, indptr, cols, counts):
+        self.n = int(n)
+        self.indptr, self.cols, self.counts = indptr, cols, counts
+        self.shape = (self.n, self.n)
+
+    @property
+    def nnz(self):
+        return int(self.indptr[-1])
+
+    def cis(self):
+        """(row, col, count) of the pixels inside the chromosome."""
+        i = np.repeat(np.arange(self.n, dtype=np.int32), np.diff(self.indptr))
+        j, v = self.cols, self.counts
+        inside = j < self.n
+        if not inside.all():
+            i, j, v = i[inside], j[inside], v[inside]
+        return i, j, v
+
+    def symmetric(self, bias=None):
+        """The CSR the reference's driver would hold: cooler's mirrored matrix through
+        utils.tocsr; with `bias` the values are (bias[row] * bias[col]) * count."""
+        i, j, v = self.cis()
+        if is_canonical(i, j):
+            row, col, data, indptr = mirror_upper(i, j, v, self.n)
+        else:  # not a conforming table: sort and sum like the reference's conversion
+            off = i != j
+            coo = sparse.coo_matrix((np.concatenate([v, v[off]]), (np.concatenate([i, j[off]]),
+                                                                  np.concatenate([j, i[off]]))), shape=self.shape)
+            M = sparse.csr_matrix(coo, dtype=float)
+            M.sort_indices()
+            row = np.repeat(np.arange(self.n, dtype=np.int32), np.diff(M.indptr))
+            col, data, indptr = M.indices, M.data, M.indptr
+        if bias is not None:
+            f = np.repeat(np.asarray(bias, np.float64), np.diff(indptr))
+            f *= np.take(bias, col)
+            f *= data
+            data = f
+        out = sparse.csr_matrix((np.asarray(data, np.float64), col, indptr), shape=self.shape)
+        out.has_sorted_indices = True
+        out.has_canonical_format = True
+        return out
+
+
 def canonical_csr(M):
     M = sparse.csr_matrix(M, dtype=np.float64)
     if not M.has_canonical_format:
@@ -207,23 +311,28 @@ def _diagonal_means_device(M, keep, n, top, valid_cols, device):
 def _poisson_count_thresholds(mu):
     """For each expected count mu[i] > 0 the smallest integer k >= 1 with
     scipy.stats.poisson.sf(k, mu[i]) < 0.01, found with scipy's own sf so the
-    decision is the reference's (sf is non-increasing in k)."""
+    decision is the reference's (sf is non-increasing in k).  One sf call evaluates the
+    counts 1..mu + 10 sqrt(mu) + 30 of every diagonal at once (a chromosome has ~300
+    diagonals; one call per diagonal cost 7-30 ms per chromosome)."""
     mu = np.asarray(mu, np.float64)
     out = np.full(mu.size, np.iinfo(np.int64).max, np.int64)
-    good = np.isfinite(mu) & (mu > 0)
-    for i in np.flatnonzero(good):
-        hi = int(mu[i] + 10.0 * np.sqrt(mu[i]) + 30)
-        while True:
-            ks = np.arange(1, hi + 1, dtype=np.float64)
-            with np.errstate(all="ignore"):
-                p = stats.poisson.sf(ks, mu[i])
-            hit = np.flatnonzero(p < 0.01)
-            if hit.size:
-                out[i] = int(ks[hit[0]])
-                break
-            hi *= 2
-            if hi > 1 << 24:
-                break
+    pending = np.flatnonzero(np.isfinite(mu) & (mu > 0))
+    hi = (mu[pending] + 10.0 * np.sqrt(mu[pending]) + 30).astype(np.int64)
+    while pending.size:
+        # bounded work per call: diagonals in groups of at most ~4 M (count, mu) pairs
+        cut = max(1, int(np.searchsorted(np.cumsum(hi), 1 << 22, side="right")))
+        grp, glen = pending[:cut], hi[:cut]
+        starts = np.cumsum(glen) - glen
+        ks = (np.arange(int(glen.sum()), dtype=np.int64) - np.repeat(starts, glen) + 1).astype(np.float64)
+        with np.errstate(all="ignore"):
+            p = stats.poisson.sf(ks, np.repeat(mu[grp], glen))
+        first = np.minimum.reduceat(np.where(p < 0.01, ks, np.inf), starts)
+        found = np.isfinite(first)
+        out[grp[found]] = first[found].astype(np.int64)
+        again = glen[~found] * 2   # no such count below the bound: look further
+        ok = again <= 1 << 24
+        pending = np.concatenate([grp[~found][ok], pending[cut:]])
+        hi = np.concatenate([again[ok], hi[cut:]])
     return out
 
 

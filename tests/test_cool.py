@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 from scipy import sparse
 
-from peakachu_amd import cool, h5lite, io
+from peakachu_amd import cool, h5lite, io, utils
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -159,7 +159,7 @@ def test_mirror_by_scatter_equals_the_transposed_sum():
     key = np.unique(i.astype(np.int64) * n + j)
     i, j = (key // n).astype(np.int32), (key % n).astype(np.int32)
     v = rng.integers(0, 5, i.size).astype(np.int32)  # zeros among them
-    row, col, val, indptr = cool.CoolFile._mirror_by_scatter(i, j, v, n)
+    row, col, val, indptr = utils._mirror_by_scatter(i, j, v, n)
     off = i != j
     R, Cc, V = np.r_[i, j[off]], np.r_[j, i[off]], np.r_[v, v[off]]
     o = np.lexsort((Cc, R))
@@ -172,10 +172,10 @@ def test_row_pointer_is_only_trusted_for_canonical_untouched_matrices():
     the reader made and its entries are in canonical order; anything else takes the reference's
     conversion (peakachu/utils.py:10-15), which sorts and sums duplicates."""
     from peakachu_amd import utils
-    assert cool.CoolFile._is_canonical(np.array([0, 0, 1, 2, 2]), np.array([1, 4, 0, 2, 3]))
-    assert not cool.CoolFile._is_canonical(np.array([0, 0, 1]), np.array([4, 1, 0]))      # columns out of order
-    assert not cool.CoolFile._is_canonical(np.array([0, 0, 1]), np.array([2, 2, 0]))      # a duplicate
-    assert not cool.CoolFile._is_canonical(np.array([1, 0, 2]), np.array([0, 1, 2]))      # rows out of order
+    assert utils.is_canonical(np.array([0, 0, 1, 2, 2]), np.array([1, 4, 0, 2, 3]))
+    assert not utils.is_canonical(np.array([0, 0, 1]), np.array([4, 1, 0]))      # columns out of order
+    assert not utils.is_canonical(np.array([0, 0, 1]), np.array([2, 2, 0]))      # a duplicate
+    assert not utils.is_canonical(np.array([1, 0, 2]), np.array([0, 1, 2]))      # rows out of order
     row = np.array([0, 0, 1, 2], np.int32); col = np.array([0, 2, 1, 2], np.int32)
     data = np.array([1.0, 2.0, 3.0, 4.0]); indptr = np.array([0, 2, 3, 4], np.int32)
     X = cool.sparse_coo(data, row, col, 3, indptr)
@@ -194,11 +194,14 @@ def test_row_pointer_is_only_trusted_for_canonical_untouched_matrices():
     assert utils.tocsr(Z).shape == (4, 4) and not np.shares_memory(utils.tocsr(Z).indices, Z.col)
 
 
-def test_chromosomes_read_on_two_threads_and_shared_arrays():
+def test_chromosomes_read_on_two_threads_and_shared_arrays(monkeypatch):
     """score_genome reads the next two chromosomes on background threads (positional reads, a
     locked pixel cache): what they deliver equals what one thread reads one after the other.
-    The matrices of one chromosome share its cached index arrays, which are read-only."""
+    The matrices of one chromosome share its cached index arrays, which are read-only.
+    (PK_UPPER=0: the host matrices of the reference's flow; the default hands the device the
+    pixel table as it is, see test_upper_pixels_equal_the_mirrored_matrices.)"""
     from peakachu_amd import score_genome
+    monkeypatch.setenv("PK_UPPER", "0")
     path = os.path.join(G, "cool_small.cool")
     ref = cool.CoolFile(path)
     names = ref.chromnames * 3
@@ -226,3 +229,42 @@ def test_chromosomes_read_on_two_threads_and_shared_arrays():
             M.data[0] = M.data[0]  # the balanced values are the caller's own
         c.close()
     ref.close()
+
+
+@pytest.mark.parametrize("uri", ["cool_small.cool", "cool_small_latest.cool"])
+def test_upper_pixels_equal_the_mirrored_matrices(uri):
+    """What score_genome hands the device by default -- the chromosome as the file stores it
+    (CoolFile.upper: upper triangle incl. the trans pixels that share its rows, CoolFile.bias) --
+    mirrors on the host (UpperPixels.symmetric, the on-demand copy behind Chromosome.M / raw_M)
+    into exactly the matrices of the reference's flow: matrix(balance=...).fetch -> utils.tocsr."""
+    from peakachu_amd import score_genome
+    c = cool.CoolFile(os.path.join(G, uri))
+    saw_trans = False
+    for name in c.chromnames:
+        px = c.upper(name)
+        assert px.cols.dtype == np.int32 and px.indptr[0] == 0 and px.indptr[-1] == px.cols.size
+        saw_trans |= bool((px.cols >= px.n).any())
+        raw = utils.tocsr(c.matrix(balance=False, sparse=True).fetch(name))
+        got = px.symmetric()
+        assert np.array_equal(got.indptr, raw.indptr) and np.array_equal(got.indices, raw.indices)
+        assert np.array_equal(got.data, raw.data)
+        for col in ("weight", "KR", "DIV", "VC"):
+            bias, column = c.bias(col, name)
+            assert np.array_equal(column, c.bins().fetch(name)[col].values, equal_nan=True)
+            bal = utils.tocsr(c.matrix(balance=col, sparse=True).fetch(name))
+            got = px.symmetric(bias)
+            assert np.array_equal(got.indices, bal.indices)
+            assert np.array_equal(got.data.view(np.uint64), bal.data.view(np.uint64))
+        inp = score_genome.fetch_inputs(c, name, "weight")
+        assert isinstance(inp, score_genome.UpperInputs) and inp.pixels.n == px.n
+    assert saw_trans  # the fixture holds trans pixels: they ride along and are not part of the matrix
+    c.close()
+
+
+def test_upper_pixels_of_a_non_conforming_table_are_sorted_and_summed():
+    """A pixel table with unsorted columns and a duplicate: the host copy equals the reference's
+    conversion (COO -> CSR sums duplicates, peakachu/utils.py:10-15)."""
+    indptr = np.array([0, 3, 4, 4], np.int32)
+    px = utils.UpperPixels(3, indptr, np.array([2, 0, 2, 1], np.int32), np.array([5, 1, 7, 3], np.int32))
+    M = px.symmetric().toarray()
+    assert np.array_equal(M, np.array([[1., 0., 12.], [0., 3., 0.], [12., 0., 0.]]))

@@ -64,3 +64,83 @@ def test_score_chromosome_chr21_on_an_hg19_shaped_map(genome, tmp_path):
     got = open(out, "rb").read()
     assert got == open(ref, "rb").read()
     assert got.count(b"\n") > 300
+
+
+def _same_chromosome(A, B, thre=0.3):
+    import numpy as np
+    bits = lambda a: np.ascontiguousarray(a, np.float64).view(np.uint64)
+    assert np.array_equal(bits(A.exp_arr), bits(B.exp_arr)) and np.array_equal(bits(A.background), bits(B.background))
+    assert np.array_equal(A.ridx, B.ridx) and np.array_equal(A.cidx, B.cidx)
+    (pa, sa), (pb, sb) = A.score(thre), B.score(thre)
+    for X, Y in ((pa, pb), (sa, sb)):
+        X, Y = X.tocsr(), Y.tocsr()
+        X.sort_indices(), Y.sort_indices()
+        assert np.array_equal(X.indptr, Y.indptr) and np.array_equal(X.indices, Y.indices)
+        assert np.array_equal(bits(X.data), bits(Y.data))
+    return pa.nnz
+
+
+@pytest.mark.parametrize("mode", ["raw", "weight", "float_counts"])
+def test_chromosome_from_the_pixel_table_equals_the_mirrored_flow(hip_lib, mode):
+    """Chromosome.from_upper (one upload of the upper triangle as a .cool stores it, mirrored and
+    balanced on the device: pk_csr_upload_upper / pk_csr_view) against the reference's flow, the
+    mirrored and balanced host matrices handed to Chromosome(...) (peakachu/score_genome.py:55-58):
+    expected curve, candidates, scored pixels bit for bit -- with trans pixels riding in the rows,
+    explicit zero counts and NaN weights."""
+    import numpy as np
+    from peakachu_amd import scoreUtils, synth, utils
+    from peakachu_amd.forest import load_model
+    n, band, w = 3000, 150, 6
+    cnt = synth.band_counts(n, band, seed=21)
+    cnt[5, 3] = 0
+    i, d = np.nonzero(cnt)
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(i, minlength=n), out=indptr[1:])
+    cols, counts = (i + d).astype(np.int32), cnt[i, d].astype(np.int32)
+    # trans pixels behind every 7th row's cis pixels, and a stored zero count
+    rows = np.arange(0, n, 7)
+    ins = indptr[rows + 1]
+    cols = np.insert(cols, ins, n + 5 + (rows % 11)).astype(np.int32)
+    counts = np.insert(counts, ins, 3).astype(np.int32)
+    indptr = indptr + np.searchsorted(rows, np.arange(n + 1), side="left")
+    counts[int(indptr[40])] = 0
+    if mode == "float_counts":
+        counts = counts.astype(np.float64)
+    px = utils.UpperPixels(n, indptr.astype(np.int32), cols, counts)
+    model = load_model(MODEL)
+    kw = dict(lower=6, upper=120, cname="chr1", res=10000, width=w)
+    if mode == "weight":
+        wts = synth.synth_weights(n, 3, n_nan=7)
+        A = scoreUtils.Chromosome.from_upper(px, model, bias=wts, weights=wts, **kw)
+        B = scoreUtils.Chromosome(px.symmetric(wts), model, raw_M=px.symmetric(), weights=wts, **kw)
+    else:
+        A = scoreUtils.Chromosome.from_upper(px, model, **kw)
+        raw = px.symmetric()
+        B = scoreUtils.Chromosome(raw, model, raw_M=raw, weights=None, **kw)
+    assert A._cands is not None and B._cands is not None   # both on the device path
+    assert A._raw_val is None                               # no host matrix was made
+    assert _same_chromosome(A, B) > 100
+    # the host copies exist for whoever reads them, as the reference's attributes do
+    assert (A.raw_M != px.symmetric()).nnz == 0
+
+
+def test_a_pixel_table_out_of_order_is_mirrored_on_the_host(hip_lib):
+    import numpy as np
+    from peakachu_amd import scoreUtils, synth, utils
+    from peakachu_amd.forest import load_model
+    n, band, w = 900, 80, 6
+    cnt = synth.band_counts(n, band, seed=4)
+    i, d = np.nonzero(cnt)
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(i, minlength=n), out=indptr[1:])
+    cols, counts = (i + d).astype(np.int32), cnt[i, d].astype(np.int32)
+    a = int(indptr[10])
+    cols[a], cols[a + 1] = cols[a + 1], cols[a]          # two pixels of a row swapped
+    px = utils.UpperPixels(n, indptr.astype(np.int32), cols, counts)
+    model = load_model(MODEL)
+    kw = dict(lower=6, upper=60, cname="chr1", res=10000, width=w)
+    A = scoreUtils.Chromosome.from_upper(px, model, **kw)
+    assert A._pixels is None                               # the device refused the table
+    raw = px.symmetric()
+    B = scoreUtils.Chromosome(raw, model, raw_M=raw, weights=None, **kw)
+    assert _same_chromosome(A, B) > 10

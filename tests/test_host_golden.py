@@ -224,3 +224,26 @@ def test_host_side_runs_without_sklearn_joblib_cooler_h5py(tmp_path):
     """) % (root, os.path.join(gio.GOLD, "old_sklearn_rf_plain.xz.joblib"), os.path.join(gio.GOLD, "cool_small.cool"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_count_thresholds_in_one_call_equal_one_call_per_diagonal():
+    """utils._poisson_count_thresholds evaluates scipy's sf for every diagonal's counts in one
+    call; the answers are those of a call per diagonal (peakachu/scoreUtils.py:59-60,67: the
+    decision is scipy's)."""
+    from scipy import stats
+    from peakachu_amd import utils
+    rng = np.random.default_rng(11)
+    mu = np.concatenate([200 / (1 + np.arange(320)) ** 0.9 + 0.3, rng.uniform(0, 5, 150), 10 ** rng.uniform(-12, 4, 150),
+                         [0, -1, np.nan, np.inf, 1e-300, 3e5]])
+    want = np.full(mu.size, np.iinfo(np.int64).max, np.int64)
+    for i in np.flatnonzero(np.isfinite(mu) & (mu > 0)):
+        hi = int(mu[i] + 10.0 * np.sqrt(mu[i]) + 30)
+        while hi <= 1 << 24:
+            ks = np.arange(1, hi + 1, dtype=np.float64)
+            with np.errstate(all="ignore"):
+                hit = np.flatnonzero(stats.poisson.sf(ks, mu[i]) < 0.01)
+            if hit.size:
+                want[i] = int(ks[hit[0]])
+                break
+            hi *= 2
+    assert np.array_equal(utils._poisson_count_thresholds(mu), want)
