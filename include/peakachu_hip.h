@@ -255,6 +255,18 @@ int pk_debug_forest_image(int T, int F, const int32_t *tree_off, const int32_t *
                           int64_t *n_words, int64_t cap_groups, int32_t *gtab,
                           int32_t *n_groups, uint64_t *troot, int32_t *tdepth);
 
+/* ---- host-side helper of the contact-map reader (no device involved) ------------------
+ * The reference reads a .cool through cooler -> h5py -> libhdf5, whose C filter pipeline inflates
+ * and un-shuffles the chunks of the pixel table (peakachu/score_genome.py:55-57).  The package's
+ * own reader parses the container in Python and hands the chunk pipeline of a ranged read to this
+ * call: chunk i = src[i] (src_len[i] bytes as stored); inflate to chunk_bytes when `deflate`
+ * (zlib, looked up at run time); un-shuffle with element size shuffle_es when > 1; bytes
+ * [skip[i], skip[i] + take[i]) of the result go to dst[i].  Chunks run side by side on `threads`
+ * host threads.  PK_E_UNSUPPORTED when no zlib can be found (the caller then inflates itself). */
+int pk_host_unfilter_chunks(int n_chunks, const void *const *src, const int64_t *src_len, int deflate,
+                            int shuffle_es, int64_t chunk_bytes, const int64_t *skip, const int64_t *take,
+                            void *const *dst, int threads);
+
 /* ---- multi-GPU: one process per GPU, one gather of the scored pixels -----
  * Chromosomes / candidate blocks are scored independently per rank
  * (peakachu/score_genome.py:46-84 shares nothing between iterations); the

@@ -25,6 +25,15 @@ import zlib
 _POOL = None
 
 
+def _pool_size():
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(8, n))
+
+
 def _inflate_pool():
     """Worker threads for chunk inflation (made on first use; sized to the CPUs this process
     may use, at most 8)."""
@@ -40,6 +49,22 @@ def _inflate_pool():
     return _POOL
 
 import numpy as np
+
+
+_NATIVE = False  # False: not looked up yet; None: not available
+
+
+def _native_unfilter():
+    """pk_host_unfilter_chunks of the package's C library (inflate + un-shuffle of chunks on host
+    threads), or None when the library has not been built: the Python pipeline then does it."""
+    global _NATIVE
+    if _NATIVE is False:
+        try:
+            from . import _lib
+            _NATIVE = _lib.load().pk_host_unfilter_chunks
+        except Exception:
+            _NATIVE = None
+    return _NATIVE
 
 SIGNATURE = b"\x89HDF\r\n\x1a\n"
 
@@ -428,6 +453,31 @@ class Dataset:
             if b <= a:
                 continue
             todo.append((a, b, offs[0], r.at(addr, nbytes), mask))  # (file reads stay on this thread)
+
+        # The chunk pipeline in C when it is the usual one (shuffle + deflate, no chunk exempt from
+        # a filter) and the type is a plain number: numpy's byte transpose of a chunk costs three
+        # times its inflate and holds the interpreter lock
+        ids = [fid for fid, _ in filters]
+        native = _native_unfilter() if (todo and ids in ([2, 1], [1], [2]) and self._type.kind not in ("vlen", "string")
+                                        and all(t[4] == 0 for t in todo)) else None
+        if native is not None:
+            import ctypes as C
+            shuffle_es = 0
+            if 2 in ids:
+                cv = filters[ids.index(2)][1]
+                shuffle_es = cv[0] if cv else es
+            m = len(todo)
+            src = (C.c_char_p * m)(*[t[3] for t in todo])
+            src_len = np.array([len(t[3]) for t in todo], np.int64)
+            skip = np.array([(t[0] - t[2]) * es for t in todo], np.int64)
+            take = np.array([(t[1] - t[0]) * es for t in todo], np.int64)
+            dst = (C.c_void_p * m)(*[out.ctypes.data + (t[0] - lo) * es for t in todo])
+            rc = native(m, C.cast(src, C.c_void_p), src_len, 1 if 1 in ids else 0, shuffle_es, c * es, skip, take,
+                        C.cast(dst, C.c_void_p), _pool_size())
+            if rc == 0:
+                return f._decode(self._type, out, n, (n,))
+            if rc != -5:  # (PK_E_UNSUPPORTED = no zlib found: the Python pipeline below)
+                raise H5FormatError("chunks of %s do not pass the filter pipeline (code %d)" % (self.name, rc))
 
         def place(item):
             a, b, o0, raw, mask = item
@@ -839,7 +889,10 @@ class File(Group):
                 vals.append("" if (n == 0 or addr == 0) else
                             self._global_heap_object(addr, idx)[:n].decode("utf-8", "replace"))
             return vals[0] if not shape else np.array(vals, dtype=object).reshape(shape)
-        arr = np.frombuffer(buf, typ.dtype, count).copy()
+        if isinstance(buf, np.ndarray):  # (a buffer of the reader's own: no copy)
+            arr = buf.view(typ.dtype)[:count]
+        else:
+            arr = np.frombuffer(buf, typ.dtype, count).copy()
         if typ.kind == "string":
             if not shape:
                 return arr[0].split(b"\x00")[0].decode("utf-8", "replace")

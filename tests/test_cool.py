@@ -268,3 +268,35 @@ def test_upper_pixels_of_a_non_conforming_table_are_sorted_and_summed():
     px = utils.UpperPixels(3, indptr, np.array([2, 0, 2, 1], np.int32), np.array([5, 1, 7, 3], np.int32))
     M = px.symmetric().toarray()
     assert np.array_equal(M, np.array([[1., 0., 12.], [0., 3., 0.], [12., 0., 0.]]))
+
+
+def test_chunk_pipeline_in_c_equals_the_python_one(monkeypatch):
+    """A ranged read runs its chunks through pk_host_unfilter_chunks (inflate + un-shuffle on host
+    threads, include/peakachu_hip.h); without the library h5lite does the same in Python.  Same
+    arrays, whatever the range's position inside the chunks."""
+    for name in ("cool_small.cool", "cool_small_latest.cool", "h5lite_types.h5", "h5lite_latest_many.h5"):
+        f = h5lite.File(os.path.join(G, name))
+        sets = []
+
+        def walk(g):
+            for k in g.keys():
+                o = g[k]
+                if isinstance(o, h5lite.Group):
+                    walk(o)
+                elif len(o.shape) == 1 and o.shape[0] > 3 and o._type.kind not in ("vlen", "string"):
+                    sets.append(o)
+        walk(f)
+        assert sets
+        rng = np.random.default_rng(3)
+        for d in sets:
+            n = d.shape[0]
+            for _ in range(4):
+                lo = int(rng.integers(0, n - 1))
+                hi = int(rng.integers(lo + 1, n + 1))
+                assert h5lite._native_unfilter() is not None
+                fast = d[lo:hi]
+                monkeypatch.setattr(h5lite, "_NATIVE", None)
+                slow = d[lo:hi]
+                monkeypatch.undo()
+                assert fast.dtype == slow.dtype and np.array_equal(fast.view(np.uint8), slow.view(np.uint8)), (name, d.name)
+        f.close()
