@@ -6,9 +6,16 @@ command lines keep working; help texts are this build's own.  `pool` is host-onl
 reference runs it on the CPU as well).  `train` and `depth` are outside this build.
 """
 import argparse
+import importlib
 import sys
 
-from . import call_loops, score_chromosome, score_genome
+
+def _lazy(module):
+    """`main` of a sub-command's module, imported when the command runs: `pool` pulls in
+    scipy.signal (0.7 s), which the scoring commands never use."""
+    def main(args):
+        return importlib.import_module("." + module, __package__).main(args)
+    return main
 
 # (flags, keyword arguments) per option group; a group is attached to the listed commands
 _COMMON_SCORING = [
@@ -31,9 +38,9 @@ def _build_parser():
         formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     sub = parser.add_subparsers(dest="subcommands")
     commands = {
-        "score_chromosome": (score_chromosome.main, "score the candidate pixels of one chromosome"),
-        "score_genome": (score_genome.main, "score every selected chromosome of a contact map"),
-        "pool": (call_loops.main, "cluster scored pixels into loop calls"),
+        "score_chromosome": (_lazy("score_chromosome"), "score the candidate pixels of one chromosome"),
+        "score_genome": (_lazy("score_genome"), "score every selected chromosome of a contact map"),
+        "pool": (_lazy("call_loops"), "cluster scored pixels into loop calls"),
     }
     parsers = {}
     for name, (func, text) in commands.items():

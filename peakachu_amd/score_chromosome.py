@@ -6,11 +6,12 @@ import numpy as np
 
 from . import io
 from .forest import load_model
-from .score_genome import build_chromosome
+from .score_genome import build_chromosome, warm_imports
 
 
 def main(args):
     np.seterr(divide='ignore', invalid='ignore')
+    warm_imports()
     if os.path.exists(args.output):
         os.remove(args.output)
     model = load_model(args.model)

@@ -94,8 +94,23 @@ def build_chromosome(Lib, key, cname, model, correct, args, width, device, input
                                  width=width, device=device)
 
 
+def warm_imports():
+    """scikit-learn's isotonic module (the expected curve's fit, peakachu/utils.py:173) and the
+    device library take a few tenths of a second to import / initialise; started on a thread
+    here, that happens while the main thread opens the model and the first chromosome is read."""
+    import threading
+
+    def work():
+        try:
+            import sklearn.isotonic  # noqa: F401
+        except ImportError:
+            pass
+    threading.Thread(target=work, name="pk-warm-imports", daemon=True).start()
+
+
 def main(args):
     np.seterr(divide='ignore', invalid='ignore')
+    warm_imports()
     rank, local_rank, world = dist.rank_info()
     if rank == 0 and os.path.exists(args.output):
         os.remove(args.output)

@@ -43,14 +43,26 @@ def have_h5py_writer():
     return os.path.exists(H5PY_PYTHON)
 
 
-def synthesize(work, binsize=10000, band=320, seed=0, chroms=synth.HG19_CHROMS, n_nan=5):
-    """Pixel tables (bin1, bin2, count sorted as a .cool holds them), weights and a manifest."""
+def synthesize(work, binsize=10000, band=320, seed=0, chroms=synth.HG19_CHROMS, n_nan=5, trans=0):
+    """Pixel tables (bin1, bin2, count sorted as a .cool holds them), weights and a manifest.
+    trans: pixels per bin whose second bin lies on a LATER chromosome (a real map's rows carry
+    them behind their cis pixels; the scoring path reads past them)."""
     os.makedirs(work, exist_ok=True)
     table, off = [], 0
+    total = sum((int(length) + binsize - 1) // binsize for _, length in chroms)
     for i, (name, length) in enumerate(chroms):
         n = (int(length) + binsize - 1) // binsize
         cnt = synth.band_counts(n, band, seed=seed + i)
         b1, b2, c = synth.band_counts_to_pixels(cnt, off)
+        if trans and off + n < total:
+            rng = np.random.default_rng(seed + 1000 + i)
+            t1 = np.repeat(np.arange(off, off + n, dtype=np.int64), trans)
+            t2 = rng.integers(off + n, total, size=t1.size).astype(np.int64)
+            key = np.unique(t1 * total + t2)
+            t1, t2 = key // total, key % total
+            b1, b2, c = np.concatenate([b1, t1]), np.concatenate([b2, t2]), np.concatenate([c, np.ones(t1.size, c.dtype)])
+            o = np.lexsort((b2, b1))
+            b1, b2, c = b1[o], b2[o], c[o]
         np.savez(os.path.join(work, "pixels_%d.npz" % i), bin1=b1, bin2=b2, count=c)
         np.save(os.path.join(work, "weights_%d.npy" % i), synth.synth_weights(n, seed + i, n_nan=min(n_nan, n // 4)))
         table.append(dict(name=name, length=int(length), bins=n, offset=off, pixels=int(b1.size)))
@@ -165,7 +177,7 @@ def e2e(a):
     cool = os.path.join(work, "standin.cool")
     say = lambda s: (print(s), sys.stdout.flush())
     t0 = time.perf_counter()
-    man = synthesize(work, band=a.band, seed=a.seed)
+    man = synthesize(work, band=a.band, seed=a.seed, trans=a.trans)
     sel = selected(man)
     say("synthesised hg19-shaped genome: %d chromosomes (%d selected by -C '#' X: %d bins), band %d bins, "
         "%d pixels, %.0f s" % (len(man["chroms"]), len(sel), sum(man["chroms"][i]["bins"] for i in sel), a.band,
@@ -221,5 +233,6 @@ if __name__ == "__main__":
     ap.add_argument("--gzip", type=int, default=6)
     ap.add_argument("--chunk", type=int, default=1 << 20)
     ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--trans", type=int, default=0, help="trans pixels per bin")
     ap.add_argument("--keep", action="store_true")
     sys.exit(e2e(ap.parse_args()))
