@@ -40,6 +40,13 @@ def b_alg(F):
     return 16 * F + 16
 
 
+def own_alg_bytes(kernel, F):
+    """The share of B_alg that passes through one kernel class: the extractor reads
+    8F of window cells and the coordinates and writes 4F of features; the forest reads those 4F
+    and writes the probability; the rank quantizer re-encodes an intermediate and owns none."""
+    return {"extract": 12 * F + 8, "forest": 4 * F + 8}.get(kernel)
+
+
 def build_workload(seed, n, band, w, lower, upper):
     from peakachu_amd import synth, utils
     M, _ = synth.synth_band(n, band, seed=seed)
@@ -47,7 +54,7 @@ def build_workload(seed, n, band, w, lower, upper):
     exp_arr = utils.calculate_expected(M, upper + 2 * w, raw=True)
     Mf = utils.band_filter(M, w, upper)
     x, y = synth.all_band_pixels(Mf, max(lower, w + 1), upper)
-    return Mf, exp_arr, x, y, upper
+    return Mf, exp_arr, x, y, upper, M
 
 
 def load_forest(spec, w, F):
@@ -241,7 +248,7 @@ def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, step
     from peakachu_amd import _lib
     F = (2 * w + 1) ** 2
     fo = load_forest(forest_spec, w, F)
-    Mf, exp_arr, x, y, upper = build_workload(0, n, band, w, 6, upper)
+    Mf, exp_arr, x, y, upper, _ = build_workload(0, n, band, w, 6, upper)
     hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], exp_arr, -2 * w + 1, upper + 2 * w - 1,
                         device=dev)
     hf = _lib.HipForest(fo, device=dev)
@@ -422,6 +429,10 @@ def main():
                     help="N > 1: fall back to a gloo gather when the RCCL communicator cannot be built "
                          "(otherwise the run fails)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive extra leg")
+    ap.add_argument("--full-evaluation", action="store_true",
+                    help="headline on the kernels without the exact early exit (every candidate's complete "
+                         "probability; rounds 1-4's headline); default: as Chromosome.score runs them")
+    ap.add_argument("--no-real-regime", action="store_true", help="skip the short / scattered candidate-list legs")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal only: all ranks use device 0 and the RCCL gather is skipped "
                          "(RCCL refuses two ranks on one GPU); the result is not a valid measurement")
@@ -467,7 +478,7 @@ def main():
     # ranks hold chromosome 0 and rank r scores block r of its candidate list, cut at
     # multiples of the reference batch so that the batch rule sees the same batches
     strong = a.scaling == "strong" and world > 1
-    Mf, exp_arr, x, y, upper = build_workload(0 if strong else rank, a.n, a.band, w, 6, a.upper or a.band)
+    Mf, exp_arr, x, y, upper, M_full = build_workload(0 if strong else rank, a.n, a.band, w, 6, a.upper or a.band)
     if a.stride > 1:
         x, y = x[::a.stride].copy(), y[::a.stride].copy()
     x_all, y_all = x, y
@@ -480,6 +491,10 @@ def main():
                         -2 * w + 1, upper + 2 * w - 1, device=dev)
     hf = _lib.HipForest(fo, device=dev)
     cd = _lib.HipCands(x, y, device=dev)
+    # what ships: Chromosome.score switches the exact early exit on for its candidate list
+    # (peakachu_amd/scoreUtils.py: cd.set_prune(True)); --full-evaluation measures the other
+    # instantiation (every candidate's complete probability) as the headline instead
+    cd.set_prune(not a.full_evaluation)
     _lib.check(L.pk_device_synchronize(dev), "sync")
     upload_s = time.perf_counter() - t0
 
@@ -586,29 +601,37 @@ def main():
             cd.run(hm, hf, w, a.thre, a.batch)
             busy_steps += 1
 
-    # extra, not the headline: the same pass with exact early termination (option
-    # early_exit: candidates that provably end at p <= thre stop walking; same pixels)
+    # extra, not the headline: the same pass with the OTHER early-exit setting (the headline runs what
+    # Chromosome.score runs: exact early termination on; here every candidate gets its full probability)
     early = None
     if world == 1:
-        cd.set_option("early_exit", 1)   # (this candidate list's own option)
+        cd.set_prune(bool(a.full_evaluation))
         step()
         sync()
         e_steps = min(a.steps, 20)
+        L.pk_prof_enable(1)
+        L.pk_prof_reset()
         t0 = time.perf_counter()
         for _ in range(e_steps):
             n_early = step()
         sync()
         e_el = time.perf_counter() - t0
-        cd.set_option("early_exit", 0)
-        early = {"value": int(x.size) * e_steps / e_el, "ms_per_step": e_el / e_steps * 1e3, "steps": e_steps,
-                 "scored_pixels": int(n_early), "same_pixels_as_full_evaluation": bool(n_early == n_out),
-                 "note": "opt-in exact pruning at threshold %g; NOT the headline value" % a.thre}
+        L.pk_prof_enable(0)
+        e_forest = _lib.prof_get("forest")
+        cd.set_prune(not a.full_evaluation)
+        early = {"early_exit": bool(a.full_evaluation), "value": int(x.size) * e_steps / e_el,
+                 "ms_per_step": e_el / e_steps * 1e3, "steps": e_steps,
+                 "forest_avg_launch_ms": e_forest[0] / e_forest[1] if e_forest[1] else None,
+                 "scored_pixels": int(n_early), "same_pixels_as_headline": bool(n_early == n_out),
+                 "note": "the headline's pass with the early exit %s" % ("on" if a.full_evaluation else
+                         "off (every candidate's complete probability: the headline of rounds 1-4)")}
 
     # extra, not the headline: SURVEY.md 8d's literal metric -- the same steps through
     # pk_score with HOST coordinate / result buffers (H2D of the candidates and D2H of the
     # scored pixels inside the timed region; matrix and forest stay resident)
     pcie = None
     if world == 1 and not a.no_pcie:
+        hm.set_option("early_exit", 0 if a.full_evaluation else 1)  # (pk_score: the matrix handle's pipeline options)
         hm.score(hf, w, a.thre, x, y, batch=a.batch)
         sync()
         p_steps = min(a.steps, 20)
@@ -618,13 +641,15 @@ def main():
         sync()
         p_el = time.perf_counter() - t0
         n_local_rate = int(x.size) * a.steps / elapsed
+        hm.set_option("early_exit", 0)
         pcie = {"value": int(x.size) * p_steps / p_el, "unit": "candidates/s", "steps": p_steps,
                 "ms_per_step": p_el / p_steps * 1e3, "scored_pixels": int(r_pcie[0].size),
                 "frac_of_device_resident": (int(x.size) * p_steps / p_el) / (n_local_rate or 1.0),
                 "note": "SURVEY 8d's literal metric: pk_score with HOST coordinate and result buffers -- upload "
                         "of the candidates (8 B each, chunk by chunk behind the kernels, checked on the device) "
-                        "and download of the scored pixels inside the timed region; `value` is the same pass "
-                        "over a device-resident list"}
+                        "and download of the scored pixels inside the timed region, same early-exit setting as "
+                        "the headline; `value` is the same pass over a device-resident list (the bench contract: "
+                        "inputs resident in HBM when the timed region starts)"}
 
     # extra, not the headline: the other single-GPU shapes of BASELINE.json, a few steps each
     extras = None
@@ -652,6 +677,15 @@ def main():
                 extras.append(extra_config(L, dev, name, thre=a.thre, batch=a.batch, **kw))
             except Exception as e:  # reported, never fatal for the headline
                 extras.append({"workload": name, "error": "%s: %s" % (type(e).__name__, e)})
+
+    # extra, not the headline: the regime the CLI runs in -- get_candidate's Poisson-filtered list and
+    # short strided lists, plus the cold cost of a Chromosome(...) + .score() of this matrix
+    regime = None
+    if world == 1 and not a.no_real_regime and a.stride == 1:
+        try:
+            regime = real_regime(L, dev, M_full, fo, w, 6, upper, a.thre, a.batch, x, y, hm, hf)
+        except Exception as e:  # reported, never fatal for the headline
+            regime = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # strong scaling: the merged result must equal the single-GPU result of the whole list
     strong_check = None
@@ -696,6 +730,8 @@ def main():
         dom_ms, dom_n = kern[dom]
         alg_bytes_total = float(n_local) * a.steps * b_alg(F)
         achieved = alg_bytes_total / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        own = own_alg_bytes(dom, F)
+        own_achieved = (float(n_local) * a.steps * own / (dom_ms * 1e-3) / 1e9) if (own and dom_ms > 0) else None
         # HBM bytes per launch of the dominant kernel and its binding rooflines, from the
         # committed PMC passes (profiles/pmc.json); only valid for the default workload and
         # reported as stale (traffic = null) when the kernel sources changed since
@@ -720,8 +756,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "synthetic %dx%d band-diagonal (%d-bin band) CSR, w=%d, %d-tree RF%s, "
-                            "%s non-zero band pixels %d<=d<=%d; value = device-resident candidate list "
-                            "(pk_score_run: what Chromosome.score runs on); SURVEY 8d's literal metric "
+                            "%s non-zero band pixels %d<=d<=%d; value = device-resident candidate list through "
+                            "pk_score_run with the exact early exit AS Chromosome.score sets it (same scored "
+                            "pixels; other_early_exit_setting = the full evaluation); SURVEY 8d's literal metric "
                             "(host coordinate / result buffers) is the pcie_inclusive leg%s"
                             % (a.n, a.n, a.band, w, fo.T,
                                " (untrained random trees)" if (a.forest or "").startswith("random:") else "",
@@ -761,12 +798,18 @@ def main():
                 "avg_launch_ms": dom_ms / dom_n if dom_n else None,
                 "launches": dom_n,
                 "candidates_per_launch": n_local * a.steps / dom_n if dom_n else None,
+                # that kernel's OWN share of B_alg (extract: 12F+8, forest: 4F+8) over its time
+                "kernel_own_alg_bytes_per_candidate": own,
+                "kernel_own_frac": own_achieved / HBM_PEAK_GBS if own_achieved is not None else None,
                 # the same algorithmic bytes over (i) the forest STAGE = rank quantizer + forest
                 # kernel, (ii) the WHOLE path = SURVEY 8d's definition, value x B_alg / peak
                 "stage_frac": (alg_bytes_total / ((kern["forest"][0] + kern["quant"][0]) * 1e-3) / 1e9
                                / HBM_PEAK_GBS) if (kern["forest"][0] + kern["quant"][0]) > 0 else None,
                 "whole_path_frac": value / world * b_alg(F) / 1e9 / HBM_PEAK_GBS,
             },
+            # SURVEY 8d's definition: candidates/s x B_alg / peak (per GPU) -- the WHOLE path, not one kernel
+            "roofline_whole_path_frac": value / world * b_alg(F) / 1e9 / HBM_PEAK_GBS,
+            "early_exit": not a.full_evaluation,
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kern.items()},
             "whole_path_alg_GBs": value * b_alg(F) / 1e9,
             "upload_s": upload_s,
@@ -782,7 +825,11 @@ def main():
         if strong_check is not None:
             out["strong_check"] = strong_check
         if early is not None:
-            out["early_exit"] = early
+            out["other_early_exit_setting"] = early
+        if regime is not None:
+            out["real_regime"] = regime
+        if world > 1:
+            out["rccl_ranks"] = int(rccl_ranks)
         if extras is not None:
             out["other_configs"] = extras
         if world == 1 and not a.no_cpu_baseline:

@@ -276,6 +276,12 @@ int pk_host_unfilter_chunks(int n_chunks, const void *const *src, const int64_t 
 int pk_comm_unique_id(uint8_t id[128]);
 pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8_t id[128]);
 void pk_comm_destroy(pk_comm *);
+/* ranks RCCL itself counts in the communicator (ncclCommCount), or PK_E_COMM */
+int pk_comm_ranks(pk_comm *);
+/* No gather waits without bound: a rank polls its stream for PK_COMM_TIMEOUT seconds (environment,
+ * default 120); when a peer went away between its "ready" and its send the wait runs out, the
+ * communicator is aborted (ncclCommAbort), the call returns PK_E_COMM and so does every later call
+ * on that communicator -- the process should report and exit non-zero (a retry is a fresh process). */
 /* every rank passes its pk_cands after pk_score_run; on rank 0 `counts`
  * (nranks entries) and the concatenated outputs (capacity `cap` pixels) are
  * filled in rank order; other ranks may pass NULL outputs. */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pk_comm_unique_id": (C.c_int, [_u8p]),
     "pk_comm_create": (_vp, [C.c_int, C.c_int, C.c_int, _u8p]),
     "pk_comm_destroy": (None, [_vp]),
+    "pk_comm_ranks": (C.c_int, [_vp]),
     "pk_comm_gather_scored": (C.c_int, [_vp, _vp, _i64p, C.c_int64, _vp, _vp, _vp, _vp]),
     "pk_comm_gatherv_bytes": (C.c_int, [_vp, _vp, C.c_int64, _i64p, _vp, C.c_int64]),
 }

@@ -26,6 +26,7 @@ struct pk_comm {
     // part of the timed step of a multi-GPU run and must not allocate
     void *stage[2];     // [0] send bytes / root's gathered pixels, [1] root's gathered bytes
     size_t stage_cap[2];
+    bool aborted;       // a wait ran out: the communicator was torn down (ncclCommAbort), every later call is refused
 };
 
 // makes stage[i] at least `bytes` large (grows by half again so that repeated gathers of
@@ -62,15 +63,61 @@ struct rccl_fabric {
         pk_set_error("%s failed: %s", what, hipGetErrorString(e));
         return PK_E_HIP;
     }
+    // The one place a rank waits for its peers: the stream holds a collective / the sends / the
+    // receives.  hipStreamSynchronize would wait for ever for a peer that died between its "ready"
+    // and its send; this polls the stream (and RCCL's own asynchronous error state) against
+    // PK_COMM_TIMEOUT and, when that runs out, aborts the communicator so that the stream drains.
+    int wait(const char *what)
+    {
+        const double limit = pk_proto::comm_timeout_seconds();
+        const int rc = pk_proto::wait_until(
+            [&]() -> int {
+                const hipError_t e = hipStreamQuery(s);
+                if (e == hipSuccess) return 1;
+                if (e != hipErrorNotReady) {
+                    pk_set_error("%s failed: %s", what, hipGetErrorString(e));
+                    return PK_E_HIP;
+                }
+                ncclResult_t ar = ncclSuccess;
+                if (ncclCommGetAsyncError(c->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                    pk_set_error("%s: RCCL reports %s", what, ncclGetErrorString(ar));
+                    return PK_E_COMM;
+                }
+                return 0;
+            },
+            limit);
+        (void)hipGetLastError();  // (hipErrorNotReady of the polls is not an error of the next launch)
+        if (rc == pk_proto::WAIT_TIMED_OUT || rc == PK_E_COMM) {
+            if (rc == pk_proto::WAIT_TIMED_OUT)
+                pk_set_error("%s: rank %d of %d waited %.0f s (PK_COMM_TIMEOUT) for its peers -- one of them is gone or "
+                             "stuck; the communicator was aborted, this process should report and exit",
+                             what, c->rank, c->nranks, limit);
+            ncclCommAbort(c->comm);
+            c->comm = nullptr;
+            c->aborted = true;
+            return PK_E_COMM;
+        }
+        return rc;
+    }
     int allgather(const int64_t *mine, int words, int64_t *all)
     {
+        if (c->aborted) return refused();
         int rc = hip(hipMemcpyAsync(c->d_mine, mine, 8 * (size_t)words, hipMemcpyHostToDevice, s), "count upload");
         if (!rc) rc = nccl(ncclAllGather(c->d_mine, c->d_counts, (size_t)words, ncclInt64, c->comm, s), "ncclAllGather");
+        // (the bounded wait comes BEFORE the copy to pageable host memory: such a copy may wait for the
+        // stream inside the HIP call, where no deadline reaches)
+        if (!rc) rc = wait("all-gather of the counts");
         if (!rc)
             rc = hip(hipMemcpyAsync(all, c->d_counts, 8 * (size_t)words * (size_t)c->nranks, hipMemcpyDeviceToHost, s),
                      "count download");
-        if (!rc) rc = hip(hipStreamSynchronize(s), "stream sync");
+        if (!rc) rc = hip(hipStreamSynchronize(s), "count download");  // (this rank's own copy: no peer involved)
         return rc;
+    }
+    int refused()
+    {
+        pk_set_error("the communicator was aborted after a timed-out wait (rank %d of %d): no further exchange", c->rank,
+                     c->nranks);
+        return PK_E_COMM;
     }
     size_t stage_cap(int i) const { return c->stage_cap[i]; }
     int reserve(int i, size_t bytes) { return comm_reserve(c, i, bytes); }
@@ -78,11 +125,17 @@ struct rccl_fabric {
     int copy_dd(void *dst, const void *src, size_t n) { return hip(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s), "local copy"); }
     int upload(void *dst, const void *src, size_t n) { return hip(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, s), "upload"); }
     int download(void *dst, const void *src, size_t n) { return hip(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, s), "download"); }
-    int group_begin() { return nccl(ncclGroupStart(), "ncclGroupStart"); }
-    int group_end() { return nccl(ncclGroupEnd(), "ncclGroupEnd"); }
-    int send(const void *p, size_t n, int peer) { return nccl(ncclSend(p, n, ncclUint8, peer, c->comm, s), "ncclSend"); }
-    int recv(void *p, size_t n, int peer) { return nccl(ncclRecv(p, n, ncclUint8, peer, c->comm, s), "ncclRecv"); }
-    int sync() { return hip(hipStreamSynchronize(s), "stream sync"); }
+    int group_begin() { return c->aborted ? refused() : nccl(ncclGroupStart(), "ncclGroupStart"); }
+    int group_end() { return c->aborted ? refused() : nccl(ncclGroupEnd(), "ncclGroupEnd"); }
+    int send(const void *p, size_t n, int peer)
+    {
+        return c->aborted ? refused() : nccl(ncclSend(p, n, ncclUint8, peer, c->comm, s), "ncclSend");
+    }
+    int recv(void *p, size_t n, int peer)
+    {
+        return c->aborted ? refused() : nccl(ncclRecv(p, n, ncclUint8, peer, c->comm, s), "ncclRecv");
+    }
+    int sync() { return c->aborted ? refused() : wait("gather of the scored pixels"); }
     template <typename... A>
     void error(const char *fmt, A... a) { pk_set_error(fmt, a...); }
 };
@@ -118,6 +171,7 @@ extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8
     c->d_mine = nullptr;
     c->stage[0] = c->stage[1] = nullptr;
     c->stage_cap[0] = c->stage_cap[1] = 0;
+    c->aborted = false;
     ncclUniqueId u;
     memcpy(&u, id, 128);
     ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
@@ -134,6 +188,22 @@ extern "C" pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8
         return nullptr;
     }
     return c;
+}
+
+extern "C" int pk_comm_ranks(pk_comm *c)
+{
+    PK_DEV_LOCK(c ? c->device : 0);
+    if (!c || c->aborted || !c->comm) {
+        pk_set_error("pk_comm_ranks: no live communicator");
+        return PK_E_COMM;
+    }
+    int n = 0;
+    const ncclResult_t r = ncclCommCount(c->comm, &n);
+    if (r != ncclSuccess) {
+        pk_set_error("ncclCommCount failed: %s", ncclGetErrorString(r));
+        return PK_E_COMM;
+    }
+    return n;
 }
 
 extern "C" void pk_comm_destroy(pk_comm *c)

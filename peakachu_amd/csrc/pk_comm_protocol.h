@@ -15,7 +15,12 @@
 //   * the only thing that needs a second round is a staging area that has to GROW on the root once
 //     the total is known (first call, or a larger result than ever before): then, and only then,
 //     all ranks vote again, and the root copies its own part before that vote;
-//   * behind the last vote nothing can fail locally any more: the peers send, the root receives.
+//   * behind the last vote nothing can fail locally any more: the peers send, the root receives;
+//   * no wait is unbounded: what a fabric waits for (a stream that holds a collective, a send, a
+//     receive) is polled through wait_until() against PK_COMM_TIMEOUT seconds (default 120); a rank
+//     whose peer went away between its "ready" and its send gives up with PK_E_COMM, tears its
+//     side of the fabric down (RCCL: ncclCommAbort) and refuses further calls -- the process is
+//     expected to report and exit non-zero, a retry is a fresh process.
 //
 // Fabric (all sizes in bytes, all calls return PK_OK or an error code):
 //   int rank(), nranks();
@@ -32,11 +37,47 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/peakachu_hip.h"
 
 namespace pk_proto {
+
+constexpr int WAIT_TIMED_OUT = -100;  // wait_until's own code: never leaves a fabric
+
+// seconds a fabric waits for its peers before it gives up: PK_COMM_TIMEOUT, default 120
+inline double comm_timeout_seconds()
+{
+    const char *e = getenv("PK_COMM_TIMEOUT");
+    if (e && *e) {
+        char *end = nullptr;
+        const double v = strtod(e, &end);
+        if (end != e && v > 0) return v;
+    }
+    return 120.0;
+}
+
+// Polls `poll()` -- 1: done, 0: not yet, < 0: an error code to hand on -- until it is done, fails or
+// `seconds` have passed (WAIT_TIMED_OUT).  Spins for the first 200 us (a healthy gather of a few MB
+// is over by then), then yields, then sleeps in 50-us steps: the step of a multi-GPU run waits
+// here once, a hung one costs no core.
+template <class Poll>
+int wait_until(Poll poll, double seconds)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const int r = poll();
+        if (r != 0) return r < 0 ? r : PK_OK;
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt >= seconds) return WAIT_TIMED_OUT;
+        if (dt > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        else if (dt > 2e-4) std::this_thread::yield();
+    }
+}
 
 // the first rank with a non-zero word at `at` of its `words`-wide row, -1 if none
 inline int first_bad(const std::vector<int64_t> &all, int R, int words, int at, int64_t *code)
@@ -175,6 +216,10 @@ int gather_scored(F &fb, int64_t mine, const int32_t *dx, const int32_t *dy, con
         fb.sync();
         return local;
     }
+    // (what the peers send has arrived -- or the bounded wait has run out -- BEFORE anything is
+    // copied to the host: a copy to pageable memory may wait for the stream where no deadline reaches)
+    rc = fb.sync();
+    if (rc) return rc;
     if (total > 0) {
         const size_t t = (size_t)total;
         rc = fb.download(ox, gx, t * 4);
@@ -258,6 +303,8 @@ int gatherv_bytes(F &fb, const void *send, int64_t nbytes, int64_t *counts, void
         fb.sync();
         return local;
     }
+    rc = fb.sync();  // (as above: the receives first, under the deadline)
+    if (rc) return rc;
     if (total > 0) {
         rc = fb.download(recv, d_recv, (size_t)total);
         if (rc) return rc;
