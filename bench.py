@@ -531,6 +531,7 @@ def main():
                 dist.barrier()
                 dist.destroy_process_group()
                 sys.exit(3)
+    rccl_ranks = L.pk_comm_ranks(comm) if comm else 0   # what RCCL itself counts (ncclCommCount)
     cap = int(x_all.size) * (1 if strong else world)
     cap = max(cap, int(x.size) * world)
     counts = np.zeros(world, np.int64)
@@ -757,13 +758,15 @@ def main():
             "config": {
                 "workload": "synthetic %dx%d band-diagonal (%d-bin band) CSR, w=%d, %d-tree RF%s, "
                             "%s non-zero band pixels %d<=d<=%d; value = device-resident candidate list through "
-                            "pk_score_run with the exact early exit AS Chromosome.score sets it (same scored "
-                            "pixels; other_early_exit_setting = the full evaluation); SURVEY 8d's literal metric "
+                            "pk_score_run %s; SURVEY 8d's literal metric "
                             "(host coordinate / result buffers) is the pcie_inclusive leg%s"
                             % (a.n, a.n, a.band, w, fo.T,
                                " (untrained random trees)" if (a.forest or "").startswith("random:") else "",
                                "all" if a.stride == 1 else "every %d-th of the" % a.stride,
                                max(6, w + 1), upper,
+                               ("WITHOUT the early exit (every candidate's complete probability)" if a.full_evaluation
+                                else "with the exact early exit AS Chromosome.score sets it (same scored pixels; "
+                                     "other_early_exit_setting = the full evaluation)"),
                                "" if world == 1 else
                                ("; strong scaling: every rank holds chromosome seed 0" if strong else
                                 "; weak scaling: rank r scores its own synthetic chromosome, seed = r "
@@ -845,5 +848,27 @@ def main():
         dist.destroy_process_group()
 
 
+def guarded_main():
+    """A library error inside a run (a gather that gave up on its peers after PK_COMM_TIMEOUT, a HIP
+    failure) ends the process with a diagnostic and a non-zero code instead of leaving the other ranks
+    -- and the driver -- waiting: every failing rank writes one JSON diagnostic line to STDERR (stdout
+    carries a JSON line only for a run that measured something), exit code 4.  (No re-exec, no retry: the process has touched the GPU; a retry is a fresh one.)"""
+    try:
+        main()
+    except Exception as e:
+        from peakachu_amd import _lib
+        if not isinstance(e, _lib.PeakachuHipError):
+            raise
+        rank = int(os.environ.get("RANK", "0"))
+        sys.stderr.write("bench.py: rank %d of %s: %s\n" % (rank, os.environ.get("WORLD_SIZE", "1"), e))
+        sys.stderr.write(json.dumps({"bench_error": str(e), "rank": rank,
+                                     "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "exit_code": 4}) + "\n")
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if os.environ.get("PK_BENCH_EXIT_FILE"):
+            open(os.environ["PK_BENCH_EXIT_FILE"], "w").write("4")
+        os._exit(4)
+
+
 if __name__ == "__main__":
-    main()
+    guarded_main()

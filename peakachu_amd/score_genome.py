@@ -159,7 +159,16 @@ def main(args):
             raise RuntimeError("score_genome failed on %d of %d ranks: %s"
                                % (len(failures), world, "; ".join(failures)))
         local = np.concatenate(recs) if recs else np.empty(0, dist.RECORD)
-        allrec = dist.gather_records(local, transport)
+        try:
+            allrec = dist.gather_records(local, transport)
+        except Exception as e:
+            # e.g. PK_E_COMM: a peer went away and the bounded wait inside the gather ran out
+            # (PK_COMM_TIMEOUT).  Say so and leave with a code of its own; nothing is retried here
+            # (this process has touched the GPU: a retry is a fresh process)
+            import sys
+            sys.stderr.write("peakachu-amd score_genome: rank %d of %d: the gather of the scored pixels failed: %s\n"
+                             % (rank, world, e))
+            raise SystemExit(5)
         if rank == 0:
             write_gathered(args.output, allrec, queue, args.resolution, Lib)
         transport.barrier()

@@ -19,7 +19,11 @@
 
 #include "../../peakachu_amd/csrc/pk_comm_protocol.h"
 
-static const int TIMEOUT_MS = 4000;
+// how long a blocked operation waits: the protocol's own bound (PK_COMM_TIMEOUT, seconds), which
+// the scenarios below set -- 4 s where nobody may ever be left waiting (a timeout there is counted
+// as a deadlock), a fraction of a second where a peer is MADE to vanish
+static int timeout_ms() { return (int)(pk_proto::comm_timeout_seconds() * 1000.0); }
+#define TIMEOUT_MS timeout_ms()
 
 struct World {
     int R;
@@ -44,6 +48,8 @@ struct ThreadFabric {
     std::vector<char> st[2];
     // injected failures
     bool fail_reserve[2] = {false, false}, fail_upload = false, fail_copy = false;
+    bool vanish_before_send = false;  // this rank votes "ready" and is gone before its sends (a process that died)
+    bool aborted = false;             // a wait ran out: like rccl_fabric after ncclCommAbort, every later call is refused
     int n_allgather = 0;
     std::string last_error;
     // grouped operations are started at group_end, like NCCL's
@@ -54,8 +60,10 @@ struct ThreadFabric {
 
     int rank() const { return me; }
     int nranks() const { return w->R; }
+    int refused() { error("the fabric was aborted after a timed-out wait"); return PK_E_COMM; }
     int allgather(const int64_t *mine, int words, int64_t *all)
     {
+        if (aborted) return refused();
         n_allgather++;
         std::unique_lock<std::mutex> lk(w->mu);
         const long g = w->gen;
@@ -71,6 +79,8 @@ struct ThreadFabric {
             w->cv.notify_all();
         } else if (!w->cv.wait_for(lk, std::chrono::milliseconds(TIMEOUT_MS), [&] { return w->gen != g; })) {
             w->deadlocks++;
+            w->arrived--;   // (this rank leaves the round it was waiting in)
+            aborted = true;
             error("all-gather timed out: a rank never arrived");
             return PK_E_COMM;
         }
@@ -103,7 +113,9 @@ struct ThreadFabric {
     int run(const Op &op)
     {
         std::unique_lock<std::mutex> lk(w->mu);
+        if (aborted) return refused();
         if (op.is_send) {
+            if (vanish_before_send) { error("injected: this rank is gone"); return PK_E_HIP; }
             auto key = std::make_pair(me, op.peer);
             w->box[key].emplace_back((const char *)op.sp, (const char *)op.sp + op.n);
             my_sends.emplace_back(op.peer, ++w->posted[key]);
@@ -113,6 +125,7 @@ struct ThreadFabric {
         auto key = std::make_pair(op.peer, me);
         if (!w->cv.wait_for(lk, std::chrono::milliseconds(TIMEOUT_MS), [&] { return !w->box[key].empty(); })) {
             w->deadlocks++;
+            aborted = true;
             error("recv timed out: rank %d never sent", op.peer);
             return PK_E_COMM;
         }
@@ -146,12 +159,14 @@ struct ThreadFabric {
         return run(op);
     }
     int sync()
-    {   // a send is complete when its receiver has taken it: an unmatched one waits (RCCL: for ever)
+    {   // a send is complete when its receiver has taken it: an unmatched one waits (RCCL: until PK_COMM_TIMEOUT)
+        if (aborted) return refused();
         std::unique_lock<std::mutex> lk(w->mu);
         for (auto &s : my_sends) {
             auto key = std::make_pair(me, s.first);
             if (!w->cv.wait_for(lk, std::chrono::milliseconds(TIMEOUT_MS), [&] { return w->consumed[key] >= s.second; })) {
                 w->deadlocks++;
+                aborted = true;
                 error("send to rank %d was never received", s.first);
                 my_sends.clear();
                 return PK_E_COMM;
@@ -343,8 +358,64 @@ static void scenario_bytes(int R)
     CHECK(w.deadlocks.load() == 0, "%d operations timed out (a rank was left waiting)", w.deadlocks.load());
 }
 
+// A peer votes "ready" and is gone before its sends (what a process that dies between the count
+// all-gather and its ncclSend looks like to the others): nobody may wait longer than the bound, the
+// ranks that were served finish, the others leave with PK_E_COMM and their side of the fabric
+// refuses every later call.
+static void scenario_vanishing_peer(int R)
+{
+    setenv("PK_COMM_TIMEOUT", "0.3", 1);
+    World w(R);
+    std::vector<ThreadFabric> fb((size_t)R);
+    for (int r = 0; r < R; r++) { fb[(size_t)r].w = &w; fb[(size_t)r].me = r; }
+    std::vector<int64_t> n((size_t)R, 500), counts;
+    int64_t total = 500 * (int64_t)R;
+    Data out;
+    auto rcs = run_scored(w, fb, n, total, &out, &counts);   // healthy first call (staging areas exist afterwards)
+    for (int c : rcs) CHECK(c == PK_OK, "healthy gather code %d", c);
+    CHECK(w.deadlocks.load() == 0, "healthy gather timed out");
+    const int gone = R - 1;
+    fb[(size_t)gone].vanish_before_send = true;
+    const auto t0 = std::chrono::steady_clock::now();
+    rcs = run_scored(w, fb, n, total, &out, &counts);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(rcs[(size_t)gone] == PK_E_HIP, "vanished peer code %d", rcs[(size_t)gone]);
+    CHECK(rcs[0] == PK_E_COMM, "root code %d (must give up, not wait)", rcs[0]);
+    for (int r = 1; r < gone; r++) CHECK(rcs[(size_t)r] == PK_OK, "served peer %d code %d", r, rcs[(size_t)r]);
+    CHECK(dt < 1.5, "the gather took %.2f s with a 0.3 s bound", dt);
+    CHECK(fb[0].aborted, "the root's fabric must refuse further calls");
+    CHECK(fb[0].last_error.find("never sent") != std::string::npos, "root message: %s", fb[0].last_error.c_str());
+    // the next call: the root refuses at once, the others run into their own bound -- everybody returns
+    fb[(size_t)gone].vanish_before_send = false;
+    const auto t1 = std::chrono::steady_clock::now();
+    rcs = run_scored(w, fb, n, total, &out, &counts);
+    const double dt2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    for (int r = 0; r < R; r++) CHECK(rcs[(size_t)r] == PK_E_COMM, "call after an abort: rank %d code %d", r, rcs[(size_t)r]);
+    CHECK(dt2 < 1.5, "the call after an abort took %.2f s", dt2);
+    setenv("PK_COMM_TIMEOUT", "4", 1);
+}
+
+static void scenario_wait_until()
+{
+    int calls = 0;
+    CHECK(pk_proto::wait_until([&] { return ++calls >= 3 ? 1 : 0; }, 1.0) == PK_OK && calls == 3, "done after three polls");
+    CHECK(pk_proto::wait_until([] { return (int)PK_E_HIP; }, 1.0) == PK_E_HIP, "an error is handed on");
+    const auto t0 = std::chrono::steady_clock::now();
+    CHECK(pk_proto::wait_until([] { return 0; }, 0.05) == pk_proto::WAIT_TIMED_OUT, "the bound");
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(dt >= 0.05 && dt < 0.5, "waited %.3f s for a 0.05 s bound", dt);
+    setenv("PK_COMM_TIMEOUT", "7.5", 1);
+    CHECK(pk_proto::comm_timeout_seconds() == 7.5, "PK_COMM_TIMEOUT is read");
+    setenv("PK_COMM_TIMEOUT", "nonsense", 1);
+    CHECK(pk_proto::comm_timeout_seconds() == 120.0, "default bound");
+}
+
 int main()
 {
+    scenario_wait_until();
+    setenv("PK_COMM_TIMEOUT", "4", 1);
+    for (int R : {2, 3, 8}) scenario_vanishing_peer(R);
+    printf("vanishing peer done, failures so far %d\n", failures);
     for (int R : {1, 2, 3, 8}) {
         scenario_scored(R);
         scenario_bytes(R);
