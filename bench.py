@@ -47,14 +47,16 @@ def own_alg_bytes(kernel, F):
     return {"extract": 12 * F + 8, "forest": 4 * F + 8}.get(kernel)
 
 
-def build_workload(seed, n, band, w, lower, upper):
+def build_workload(seed, n, band, w, lower, upper, with_matrix=False):
+    """(band-filtered matrix, expected curve, candidate coordinates, clamped upper[, the
+    unfiltered matrix]) of one synthetic chromosome."""
     from peakachu_amd import synth, utils
     M, _ = synth.synth_band(n, band, seed=seed)
     upper = min(upper, n - 2 * w)
     exp_arr = utils.calculate_expected(M, upper + 2 * w, raw=True)
     Mf = utils.band_filter(M, w, upper)
     x, y = synth.all_band_pixels(Mf, max(lower, w + 1), upper)
-    return Mf, exp_arr, x, y, upper, M
+    return (Mf, exp_arr, x, y, upper, M) if with_matrix else (Mf, exp_arr, x, y, upper)
 
 
 def load_forest(spec, w, F):
@@ -248,7 +250,7 @@ def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, step
     from peakachu_amd import _lib
     F = (2 * w + 1) ** 2
     fo = load_forest(forest_spec, w, F)
-    Mf, exp_arr, x, y, upper, _ = build_workload(0, n, band, w, 6, upper)
+    Mf, exp_arr, x, y, upper = build_workload(0, n, band, w, 6, upper)
     hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], exp_arr, -2 * w + 1, upper + 2 * w - 1,
                         device=dev)
     hf = _lib.HipForest(fo, device=dev)
@@ -478,7 +480,8 @@ def main():
     # ranks hold chromosome 0 and rank r scores block r of its candidate list, cut at
     # multiples of the reference batch so that the batch rule sees the same batches
     strong = a.scaling == "strong" and world > 1
-    Mf, exp_arr, x, y, upper, M_full = build_workload(0 if strong else rank, a.n, a.band, w, 6, a.upper or a.band)
+    Mf, exp_arr, x, y, upper, M_full = build_workload(0 if strong else rank, a.n, a.band, w, 6, a.upper or a.band,
+                                                       with_matrix=True)
     if a.stride > 1:
         x, y = x[::a.stride].copy(), y[::a.stride].copy()
     x_all, y_all = x, y

@@ -384,6 +384,7 @@ extern "C" int64_t pk_forest_get_option(pk_forest *f, const char *name)
 {
     if (!f || !name) return -1;
     // read-only: what the rank plan of this forest came to (0 before the first scoring call plans it)
+    if (!strcmp(name, "stat_family")) return f->last_family;
     if (!strcmp(name, "stat_q_mode")) return f->q_state == 1 ? f->q_mode : -1;   // PK_Q_NARROW / _WIDE / _NARROW12
     if (!strcmp(name, "stat_q_rows")) return f->q_state == 1 ? f->q_F : -1;
     if (!strcmp(name, "stat_q_shape")) return f->q_state == 1 ? f->q_ch : -1;

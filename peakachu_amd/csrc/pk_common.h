@@ -205,6 +205,12 @@ struct pk_forest {
     int32_t *img_tdepth = nullptr; // device
     // how pk_forest_plan_blk decided to evaluate this forest: 0 preorder kernels, 1 LDS image, 2 rank image
     int plan_kind = 0;
+    // the kernel family that walked this forest last (read-only option "stat_family"):
+    // 1 forest_qr_kernel (rank image, 256 candidates, the default for <= 255 features), 2 forest_q_kernel
+    // (rank image, generic), 3 forest_q2_kernel (rank image, two 64-candidate tiles: wide forests),
+    // 4 forest_img_kernel (8-byte LDS image), 5 forest_pipe_kernel, 6 forest_lds_kernel, 7 forest_gmem_kernel,
+    // 8 forest_l2_kernel (preorder 8-byte nodes); 0 none yet
+    int last_family = 0;
     // rank image (forest_q_kernel): 0 = not tried, 1 = built, -1 = does not apply
     int q_state = 0;
     int q_slots = 0, q_ch = 0, q_n_grp = 0;

@@ -738,6 +738,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
             pslots = (int)f->opt.forest_pipe_slots;
         const size_t lds = fea_bytes + (size_t)PIPE_R * LDS_C * sizeof(double) + 256 +
                            (size_t)pslots * region_words * sizeof(uint2);
+        f->last_family = 5;
         switch (pslots) {
         case 4: PK_LAUNCH_PIPE(4); break;
         case 5: PK_LAUNCH_PIPE(5); break;
@@ -746,6 +747,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         default: PK_LAUNCH_PIPE(8); break;
         }
     } else if (blk == LDS_C && f->opt.forest_lds > 0) {
+        f->last_family = 6;
         int slots = (int)f->opt.forest_slots;
         if (slots == 0) {
             // auto: as many slots as average trees fit beside the tile (a slot without a tree
@@ -764,6 +766,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         }
     } else if (blk < LDS_C && (!f->opt.forest_l2_tile || fea_bytes > (size_t)156 * 1024)) {
         // large F (w = 11): no LDS, features from the L2-resident tile
+        f->last_family = 7;
         const unsigned g2 = (unsigned)((cn + 255) / 256);
         switch (ilp) {
         case 1: hipLaunchKernelGGL(forest_gmem_kernel<1>, dim3(g2), dim3(256), 0, ctx->stream, f->nodes, f->root, f->big_roff, f->T, f->F, tiles, blk, d_status, c0, cn, d_prob); break;
@@ -773,6 +776,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         }
     } else {
         const size_t lds = fea_bytes;
+        f->last_family = 8;
         switch (ilp) {
         case 1: PK_LAUNCH_L2(1); break;
         case 2: PK_LAUNCH_L2(2); break;

@@ -349,6 +349,7 @@ int pk_launch_forest_img(pk_device_ctx *ctx, pk_forest *f, const float *tiles,
         return PK_E_INVALID;
     }
     pk_prof_scope prof(ctx, PK_K_FOREST);
+    f->last_family = 4;
     const pk_img_layout &L = *f->img_layout;
     const unsigned grid = (unsigned)((cn + IMG_C - 1) / IMG_C);
     switch (f->img_slots) {

@@ -1657,6 +1657,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     } while (0)
         // forest_q_rsv bits: 1 on, 2 PREF0 (the next tile's first group prefetched with the tile)
         const bool prune = prune_sum > -1e300;
+        f->last_family = 1;
         if (L.half1 == 32768) {
             if (prune) QR_LAUNCH_NR(32768, true);
             else QR_LAUNCH_NR(32768, false);
@@ -1667,19 +1668,25 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
 #undef QR_LAUNCH_NR
 #undef QR_LAUNCH
     } else if (L.ch == 4 && L.half1 == 32768) {
+        f->last_family = 2;
         if (early) Q_LAUNCH(4, 2, 32768, true);
         else if (wpt2) Q_LAUNCH(4, 2, 32768, false);
         else Q_LAUNCH(4, 1, 32768, false);
     } else if (L.ch == 4 && L.half1 == 49152) {
+        f->last_family = 2;
         if (early) Q_LAUNCH(4, 2, 49152, true);
         else if (wpt2) Q_LAUNCH(4, 2, 49152, false);
         else Q_LAUNCH(4, 1, 49152, false);
     } else if (L.ch == 2) {
+        f->last_family = 2;
         Q_LAUNCH(2, 1, 32768, false);
-    } else if (L.ch == 1 && f->opt.forest_q_two && !(prune_sum > -1e300) && cn > 64 && f->q_F <= 639 &&
-               f->q_max_group_bytes <= 6 * 16384) {
+    } else if (L.ch == 1 && f->opt.forest_q_two && cn > 64 && f->q_F <= 639 && f->q_max_group_bytes <= 6 * 16384) {
         // two rank tiles per trip (see forest_q2_kernel); the waves that walk load their share of
-        // the next group behind the first walk (option forest_q_help, on)
+        // the next group behind the first walk (option forest_q_help, on).  The kernel has no early
+        // exit: a run that ALLOWS pruning (Chromosome.score's, pk_cands_set_prune) gets every
+        // candidate's full probability here -- the scored pixels are the same either way, and the
+        // one-tile kernel with its early exit is the slower of the two on these forests (round 5)
+        f->last_family = 3;
         const int late_below = f->opt.forest_q_help ? f->q_slots : 0;
         int rc2 = q_set_max_lds(forest_q2_kernel, 163840);
         if (rc2) return rc2;
@@ -1690,6 +1697,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
                            f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.val_off, L.img_off,
                            ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)f->opt.forest_dbg, late_below);
     } else if (L.ch == 1) {
+        f->last_family = 2;
         Q_LAUNCH(1, 1, 32768, false);
     } else {
         pk_set_error("forest rank kernel: layout not instantiated");
