@@ -286,16 +286,6 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
     } else if (!strcmp(name, "forest_slots")) {
         if (value < 0 || value == 1 || value > 16) return PK_E_INVALID;
         o.forest_slots = value;
-    } else if (!strcmp(name, "forest_pipe")) {
-        if (value < 0 || value > 2) return PK_E_INVALID;
-        o.forest_pipe = value;
-    } else if (!strcmp(name, "forest_pipe_slots")) {
-        if (value != 0 && (value < 4 || value > 8)) return PK_E_INVALID;
-        o.forest_pipe_slots = value;
-    } else if (!strcmp(name, "early_exit")) {
-        o.early_exit = value != 0;
-    } else if (!strcmp(name, "forest_l2_tile")) {
-        o.forest_l2_tile = value != 0;
     } else if (!strcmp(name, "forest_q_two")) {
         o.forest_q_two = value != 0;
     } else if (!strcmp(name, "forest_q_help")) {
@@ -342,10 +332,7 @@ static int64_t opt_read(const pk_options &o, const char *name)
     if (!strcmp(name, "overlap")) return o.overlap;
     if (!strcmp(name, "sub_chunk")) return o.sub_chunk;
     if (!strcmp(name, "forest_q_rank12")) return o.forest_q_rank12;
-    if (!strcmp(name, "forest_pipe")) return o.forest_pipe;
-    if (!strcmp(name, "forest_l2_tile")) return o.forest_l2_tile;
     if (!strcmp(name, "early_exit")) return o.early_exit;
-    if (!strcmp(name, "forest_pipe_slots")) return o.forest_pipe_slots;
     if (!strcmp(name, "forest_img")) return o.forest_img;
     if (!strcmp(name, "forest_q")) return o.forest_q;
     if (!strcmp(name, "forest_q_ch")) return o.forest_q_ch;
@@ -616,8 +603,6 @@ extern "C" pk_forest *pk_forest_create(int device, int T, int F, const int32_t *
     fo->nodes = nullptr;
     fo->root = nullptr;
     fo->big_roff = nullptr;
-    fo->tree_staged = nullptr;
-    fo->staged_words = -1;
     fo->grp = nullptr;
     fo->n_grp = 0;
     fo->grp_words = fo->grp_slots = -1;
@@ -696,18 +681,6 @@ int pk_forest_groups(pk_forest *f, int tree_words, int slots)
     return PK_OK;
 }
 
-int pk_forest_stage_flags(pk_forest *f, int region_words)
-{
-    if (f->tree_staged && f->staged_words == region_words) return PK_OK;
-    std::vector<int32_t> fl((size_t)f->T);
-    for (int t = 0; t < f->T; t++)
-        fl[(size_t)t] = (!f->h_big[(size_t)t] && f->h_root[t + 1] - f->h_root[t] <= region_words) ? 1 : 0;
-    if (!f->tree_staged) PK_HIP(hipMalloc((void **)&f->tree_staged, sizeof(int32_t) * (size_t)f->T));
-    PK_HIP(hipMemcpy(f->tree_staged, fl.data(), sizeof(int32_t) * (size_t)f->T, hipMemcpyHostToDevice));
-    f->staged_words = region_words;
-    return PK_OK;
-}
-
 extern "C" void pk_forest_destroy(pk_forest *f)
 {
     PK_DEV_LOCK(f ? f->device : 0);
@@ -716,7 +689,6 @@ extern "C" void pk_forest_destroy(pk_forest *f)
     if (f->nodes) hipFree(f->nodes);
     if (f->root) hipFree(f->root);
     if (f->big_roff) hipFree(f->big_roff);
-    if (f->tree_staged) hipFree(f->tree_staged);
     if (f->grp) hipFree(f->grp);
     pk_forest_img_release(f);
     pk_forest_q_release(f);

@@ -88,9 +88,6 @@ struct pk_options {
     int64_t extract_row16 = 1;  // w = 11 on clean matrices: four register-blocked windows per wave
     int64_t forest_warm = 1;    // last tree group: pull the tile of workgroup id + N into this XCD's L2
                                 // (0 = off, 1 = N = number of CUs: the workgroup that follows on this XCD)
-    int64_t forest_pipe = 1;    // barrier-free tree pipeline (v3): 0 never, 1 when 8 slots fit, 2 when >= 4 fit
-    int64_t forest_pipe_slots = 0;  // 0 = as many as fit (max 8)
-    int64_t forest_l2_tile = 0; // large F: 1 = keep the LDS feature tile (one wave per CU), 0 = no-LDS kernel
     int64_t early_exit = 0;     // pk_score_run: stop walking candidates that provably end at p <= thre
                                 // (identical output pixels; per-candidate probabilities of pruned pixels read 0)
     // diagnostics of the rank kernels (pk_forest_q.hip), bits: 2 no walk, 4 no commit stores, 8 every
@@ -182,8 +179,6 @@ struct pk_forest {
     uint2 *nodes;          // device, n_nodes x 8 B
     int32_t *root;         // device, T+1 offsets of each tree's root
     int32_t *big_roff;     // device side table [n_nodes] or nullptr
-    int32_t *tree_staged;  // device [T]: tree fits a pipeline region (see pk_forest_stage_flags)
-    int staged_words;      // region size tree_staged was computed for (-1 = none)
     std::vector<int32_t> h_root;
     std::vector<uint8_t> h_big;   // per tree: uses the side table (never staged in LDS)
     // LDS-kernel tree groups for one (tree_words, slots) launch shape, cached
@@ -208,8 +203,8 @@ struct pk_forest {
     // the kernel family that walked this forest last (read-only option "stat_family"):
     // 1 forest_qr_kernel (rank image, 256 candidates, the default for <= 255 features), 2 forest_q_kernel
     // (rank image, generic), 3 forest_q2_kernel (rank image, two 64-candidate tiles: wide forests),
-    // 4 forest_img_kernel (8-byte LDS image), 5 forest_pipe_kernel, 6 forest_lds_kernel, 7 forest_gmem_kernel,
-    // 8 forest_l2_kernel (preorder 8-byte nodes); 0 none yet
+    // 4 forest_img_kernel (8-byte LDS image), 6 forest_lds_kernel, 7 forest_gmem_kernel (preorder 8-byte nodes);
+    // 0 none yet (5 and 8 were the pipe and L2 kernels of rounds 1-4, removed)
     int last_family = 0;
     // rank image (forest_q_kernel): 0 = not tried, 1 = built, -1 = does not apply
     int q_state = 0;
@@ -337,7 +332,6 @@ int pk_launch_forest_q_walk(pk_device_ctx *, pk_forest *f, const uint8_t *d_stat
 // (re)build f->grp for this launch shape; returns PK_OK or an error code
 int pk_forest_groups(pk_forest *f, int tree_words, int slots);
 // per-tree flag: words <= region_words and no side-table offsets
-int pk_forest_stage_flags(pk_forest *f, int region_words);
 
 // Diagonal-major dense band: cell (r, r+k), dlo <= k <= dhi, lives at
 // band[(k - dlo) * ld + r]; everything else reads 0.

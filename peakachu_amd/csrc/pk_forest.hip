@@ -18,11 +18,11 @@
 // Kernels in this file:
 //    forest_lds_kernel<SLOTS, PRUNE>  (default) trees streamed through LDS in groups,
 //        16 waves per CU, two barriers per group; PRUNE = exact early termination
-//    forest_pipe_kernel<S>            the same without workgroup barriers (per-slot LDS
-//        regions + an LDS ring); chosen automatically only when 8 regions fit
-//    forest_l2_kernel<ILP>            feature tile in LDS, nodes read through L2
 //    forest_gmem_kernel<ILP>          no LDS at all, for feature counts whose tile
-//        cannot share the LDS with trees (w = 11 ... 15)
+//        cannot share the LDS with trees (w = 11 ... 15), and for option forest_lds = 0
+// (rounds 1-4 also carried forest_pipe_kernel, a barrier-free variant of the LDS kernel, and
+// forest_l2_kernel, the LDS-tile / L2-node variant: no model reached either by default --
+// DESIGN.md "Forest routes" -- and both were removed in round 5; EXPERIMENTS.md keeps their numbers)
 #include "pk_common.h"
 
 namespace {
@@ -61,72 +61,6 @@ __device__ __forceinline__ int node_roff(uint2 n, const int32_t *__restrict__ bi
 __device__ __forceinline__ unsigned node_kind(uint2 n, bool left)
 {
     return (n.y >> (left ? PK_NODE_LKIND_SHIFT : PK_NODE_RKIND_SHIFT)) & 3u;
-}
-
-// ------------------------------------------------------------------------
-// v1: nodes read through the cache hierarchy, ILP trees in flight per lane.
-// Kept for feature counts whose tile leaves no room for an LDS tree buffer
-// (w = 11) and as an independent second implementation for the tests.
-// ------------------------------------------------------------------------
-template <int ILP>
-__global__ void forest_l2_kernel(const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
-                                 const int32_t *__restrict__ big_roff, int T, int F,
-                                 const float *__restrict__ tiles,
-                                 const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
-                                 double *__restrict__ prob)
-{
-    extern __shared__ __attribute__((aligned(16))) float fea[];  // [F][blk]
-    const int blk = blockDim.x;
-    const int lane = threadIdx.x;
-    const int64_t tile = blockIdx.x;
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(tiles + (size_t)tile * F * blk);
-        float4 *dst = reinterpret_cast<float4 *>(fea);
-        const int nvec = F * blk / 4;
-        for (int i = lane; i < nvec; i += blk) dst[i] = src[i];
-    }
-    __syncthreads();
-    const int64_t local = tile * blk + lane;
-    if (local >= cn) return;
-    const int64_t c = c0 + local;
-    if (!status[c]) {
-        prob[c] = 0.0;
-        return;
-    }
-    double acc = 0.0;
-    for (int t = 0; t < T; t += ILP) {
-        int idx[ILP];
-        unsigned kind[ILP];
-#pragma unroll
-        for (int k = 0; k < ILP; k++) {
-            idx[k] = root[min(t + k, T - 1)];
-            kind[k] = PK_KIND_NODE;
-        }
-        bool all_done = false;
-        while (!all_done) {
-            uint2 nd[ILP];
-#pragma unroll
-            for (int k = 0; k < ILP; k++) nd[k] = nodes[idx[k]];
-            all_done = true;
-#pragma unroll
-            for (int k = 0; k < ILP; k++) {
-                if (kind[k] == PK_KIND_NODE) {
-                    const float x = fea[node_feat(nd[k]) * blk + lane];
-                    const bool gl = goes_left(x, nd[k]);
-                    kind[k] = node_kind(nd[k], gl);
-                    idx[k] += gl ? 1 : node_roff(nd[k], big_roff, idx[k]);
-                }
-                all_done = all_done && (kind[k] != PK_KIND_NODE);
-            }
-        }
-        double v[ILP];
-#pragma unroll
-        for (int k = 0; k < ILP; k++) v[k] = leaf_value(kind[k], nodes[idx[k]]);
-#pragma unroll
-        for (int k = 0; k < ILP; k++)
-            if (t + k < T) acc += v[k];  // tree order: sklearn's sequential sum
-    }
-    prob[c] = acc / (double)T;
 }
 
 // ------------------------------------------------------------------------
@@ -432,173 +366,6 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
 #undef PK_STAMP
 }
 
-// ------------------------------------------------------------------------
-// v3: barrier-free tree pipeline.
-//
-// In v2 about 40 % of a tree group's time is lost to the two workgroup
-// barriers and the exposed LDS commit between them (in-kernel stamps,
-// DESIGN.md).  Here every tree SLOT (a pair of waves covering the workgroup's
-// 128 candidates, one candidate per lane) runs on its own: slot s walks trees
-// s, s+S, s+2S, ... from a private LDS region sized for the largest tree.
-// While a wave walks tree t it holds its half of tree t+S in registers
-// (global loads issued before the walk); when BOTH waves of the slot have
-// finished walking (an LDS counter, not a workgroup barrier) each writes its
-// half into the region, and when both halves have landed they walk on.  Slots
-// never wait for each other, so one slot's commit overlaps the other slots'
-// walks.  Leaf values go through an LDS ring of R trees with generation
-// flags; the two waves of slot 0 consume the ring in tree order (each its own
-// 64 candidates), which keeps the float64 sum sequential as in sklearn.
-// Producers wait only when they are R trees ahead of the consumer.  Every
-// spin is bounded; on a timeout the kernel raises an error word instead of
-// hanging.  (A first version with one wave per slot and two candidates per
-// lane ran 2.3x slower than v2: 6 waves per CU issue too slowly.)
-// ------------------------------------------------------------------------
-constexpr int PIPE_R = 16;                        // ring entries (trees)
-constexpr int PIPE_REGION_MAX = 2 * 64 * 8 * 2;   // words a region can hold (2 waves x 8 uint4/lane)
-constexpr int PIPE_SPIN_LIMIT = 1 << 22;
-
-__device__ __forceinline__ bool spin_until_ge(const int *ctr, int target)
-{
-    for (int spin = 0; spin <= PIPE_SPIN_LIMIT; spin++) {
-        if (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target)
-            return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-
-template <int S>
-__global__ __launch_bounds__(LDS_C *S) void forest_pipe_kernel(
-    const uint2 *__restrict__ nodes, const int32_t *__restrict__ root,
-    const int32_t *__restrict__ big_roff, const int32_t *__restrict__ tree_staged, int T, int F,
-    const float *__restrict__ tiles, const uint8_t *__restrict__ status, int64_t c0, int64_t cn,
-    double *__restrict__ prob, int region_words, int dbg, long long *__restrict__ errword)
-{
-    constexpr int THREADS = LDS_C * S;
-    extern __shared__ __attribute__((aligned(16))) float fea[];     // [F][128]
-    double *val = reinterpret_cast<double *>(fea + (size_t)F * LDS_C);  // [R][128]
-    int *ready = reinterpret_cast<int *>(val + PIPE_R * LDS_C);     // [R][2] tree published, per half
-    int *cons = ready + 2 * PIPE_R;                                 // [2] trees consumed, per half
-    int *walked = cons + 2;                                         // [S] waves done walking (counts up)
-    int *landed = walked + 8;                                       // [S] waves done committing
-    uint2 *regions = reinterpret_cast<uint2 *>(ready + 64);         // S regions (256 B of flags)
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = wave >> 1, half = wave & 1;
-    const int cl = half * 64 + lane;
-    const int64_t tile = blockIdx.x;
-    uint2 *reg = regions + (size_t)slot * region_words;
-    if (tid < 64) ready[tid] = tid < 2 * PIPE_R ? -1 : 0;  // ready = -1, cons/walked/landed = 0
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(tiles + (size_t)tile * F * LDS_C);
-        float4 *dst = reinterpret_cast<float4 *>(fea);
-        const int nvec = F * LDS_C / 4;
-        for (int i = tid; i < nvec; i += THREADS) dst[i] = src[i];
-    }
-    // this slot's first tree: each wave moves its half (uint4 index = half*64 + lane + 128 q)
-    PK_PF8(PK_PF_DECL)
-    const int pf_tid = cl, pf_stride = LDS_C;
-    const uint4 *pf_src;
-    uint4 *const pf_dst = reinterpret_cast<uint4 *>(reg);
-    int pf_nv = 1;
-    int t = slot;
-    if (t < T && tree_staged[t]) {
-        pf_src = reinterpret_cast<const uint4 *>(nodes + root[t]);
-        pf_nv = (root[t + 1] - root[t]) >> 1;
-        PK_PF8(PK_PF_LOAD)
-        PK_PF8(PK_PF_STORE)
-    }
-    __syncthreads();  // the only workgroup barrier: tile + flags + first trees are in LDS
-
-    const int64_t local = tile * LDS_C + cl;
-    const bool valid = local < cn;
-    const unsigned st = valid ? status[c0 + local] : 0;
-    // walk_tree_lds addresses the tile as LDS offset 0 (no static LDS in this kernel)
-    const bool tile_at_zero =
-        (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const void *)fea == 0u;
-    if (!tile_at_zero && tid == 0) errword[0] = 2;
-    const bool active = st != 0 && tile_at_zero;
-    const bool wave_nan = __any(st == 2);
-    const char *fea_b = reinterpret_cast<const char *>(fea);
-    const int cl4 = cl << 2;
-
-    double acc = 0.0;  // slot 0 only
-    int next = 0;      // slot 0 only: next tree to add
-    bool ok = true;
-    // slot 0: add every published tree of this half, in tree order
-    auto consume = [&]() {
-        while (next < T &&
-               __hip_atomic_load(&ready[2 * (next & (PIPE_R - 1)) + half], __ATOMIC_ACQUIRE,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP) == next) {
-            acc += val[(next & (PIPE_R - 1)) * LDS_C + cl];
-            next++;
-        }
-        __hip_atomic_store(&cons[half], next, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
-    int round = 0;
-    for (; t < T; t += S, round++) {  // wave-uniform
-        // scalar (SGPR) tree index: the root / flag lookups become s_loads and do
-        // not share the vector-memory counter with the prefetch below
-        t = __builtin_amdgcn_readfirstlane(t);
-        const int tn = t + S;
-        const bool cur_staged = tree_staged[t] != 0;
-        const bool nxt_staged = tn < T && tree_staged[tn] != 0;
-        if (nxt_staged) {  // loads fly while this tree is walked
-            pf_src = reinterpret_cast<const uint4 *>(nodes + root[tn]);
-            pf_nv = (root[tn + 1] - root[tn]) >> 1;
-            PK_PF8(PK_PF_LOAD)
-        }
-        double v = 0.0;
-        if (active && !(dbg & 2)) {
-            if (cur_staged) {
-                const char *ra = reinterpret_cast<const char *>(reg);
-                v = wave_nan ? walk_tree_lds<true>(fea_b, cl4, ra) : walk_tree_lds<false>(fea_b, cl4, ra);
-            } else {
-                v = walk_tree_global(nodes, big_roff, root[t], fea, cl);
-            }
-        }
-        // this wave no longer reads the region
-        if (lane == 0)
-            __hip_atomic_fetch_add(&walked[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // ring space: tree t may be published once tree t-R has been consumed (this half)
-        if (slot == 0) {
-            consume();
-            for (int spin = 0; t >= next + PIPE_R && ok; spin++) {
-                __builtin_amdgcn_s_sleep(1);
-                consume();
-                ok = spin <= PIPE_SPIN_LIMIT;
-            }
-        } else {
-            ok = ok && spin_until_ge(&cons[half], t - PIPE_R + 1);
-        }
-        val[(t & (PIPE_R - 1)) * LDS_C + cl] = v;
-        __hip_atomic_store(&ready[2 * (t & (PIPE_R - 1)) + half], t, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (tn < T) {
-            // both waves of the slot are done with tree t -> the next tree may move in
-            ok = ok && spin_until_ge(&walked[slot], 2 * (round + 1));
-            if (nxt_staged) { PK_PF8(PK_PF_STORE) }
-            if (lane == 0)
-                __hip_atomic_fetch_add(&landed[slot], 1, __ATOMIC_RELEASE,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (slot == 0) consume();
-            // both halves of tree t+S are in the region
-            ok = ok && spin_until_ge(&landed[slot], 2 * (round + 1));
-        }
-    }
-    if (slot == 0) {
-        for (int spin = 0; next < T && ok; spin++) {
-            consume();
-            if (next < T) __builtin_amdgcn_s_sleep(2);
-            ok = spin <= PIPE_SPIN_LIMIT;
-        }
-        if (valid) prob[c0 + local] = active ? acc / (double)T : 0.0;
-    }
-    if (!ok && lane == 0) errword[0] = 1;  // host turns this into PK_E_HIP
-}
-
 // row-major [N][F] float32 -> [tile][F][blk] tiles (pk_predict's input path):
 // one wave per row, which also notes whether the row holds a NaN.
 __global__ void tile_rows_kernel(const float *__restrict__ rows, int64_t N, int F,
@@ -653,15 +420,6 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
     return PK_OK;
 }
 
-#define PK_LAUNCH_L2(ILP)                                                                     \
-    do {                                                                                      \
-        int rc__ = set_max_lds(forest_l2_kernel<ILP>, lds);                                   \
-        if (rc__) return rc__;                                                                \
-        hipLaunchKernelGGL(forest_l2_kernel<ILP>, dim3(grid), dim3(blk), lds, ctx->stream,    \
-                           f->nodes, f->root, f->big_roff, f->T, f->F, tiles, d_status, c0,   \
-                           cn, d_prob);                                                       \
-    } while (0)
-
 #define PK_LAUNCH_LDS_P(SLOTS, PRUNE)                                                         \
     do {                                                                                      \
         const size_t val_bytes = (size_t)((SLOTS) + ((PRUNE) ? 1 : 0)) * LDS_C * sizeof(double); \
@@ -687,34 +445,6 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
         else PK_LAUNCH_LDS_P(SLOTS, false);                                                   \
     } while (0)
 
-#define PK_LAUNCH_PIPE(SS)                                                                    \
-    do {                                                                                      \
-        int rc__ = set_max_lds(forest_pipe_kernel<SS>, lds);                                  \
-        if (rc__) return rc__;                                                                \
-        hipLaunchKernelGGL(forest_pipe_kernel<SS>, dim3(grid), dim3(LDS_C * (SS)), lds,       \
-                           ctx->stream, f->nodes, f->root, f->big_roff, f->tree_staged, f->T, \
-                           f->F, tiles, d_status, c0, cn, d_prob, region_words,               \
-                           (int)f->opt.forest_dbg, ctx->dbg_buf + 65535);                      \
-    } while (0)
-
-// The barrier-free pipeline needs a private region per slot that holds the
-// largest (stageable) tree.  Measured on config 2 (largest tree 13.7 KB, only 6
-// regions fit): 9.05 ms vs 7.5 ms for the barrier-separated groups with 16
-// waves; its time scales as 1/slots, so it is chosen automatically only when 8
-// regions fit (forest_pipe=1), or forced for experiments (forest_pipe=2, >= 4).
-static int pipe_shape(pk_forest *f, size_t fea_bytes, int *slots, int *region_words)
-{
-    int rw = f->max_tree_words > PIPE_REGION_MAX ? PIPE_REGION_MAX : f->max_tree_words;
-    rw = ((rw + 1) & ~1) + 2;
-    const size_t fixed = fea_bytes + (size_t)PIPE_R * LDS_C * sizeof(double) + 256;
-    if (fixed >= (size_t)160 * 1024) return 0;
-    int s = (int)(((size_t)160 * 1024 - fixed) / ((size_t)rw * sizeof(uint2)));
-    if (s > 8) s = 8;
-    *slots = s;
-    *region_words = rw;
-    return f->opt.forest_pipe >= 2 ? s >= 4 : s >= 8;
-}
-
 int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int blk,
                      const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob,
                      double prune_sum)
@@ -729,24 +459,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
     const unsigned grid = (unsigned)((cn + blk - 1) / blk);
     const size_t fea_bytes = (size_t)f->F * blk * sizeof(float);
     const int ilp = (int)f->opt.forest_ilp;
-    int pslots = 0, region_words = 0;
-    if (blk == LDS_C && f->opt.forest_lds > 0 && f->opt.forest_pipe && !(prune_sum > -1e300) &&
-        pipe_shape(f, fea_bytes, &pslots, &region_words)) {
-        int rc = pk_forest_stage_flags(f, region_words - 2);
-        if (rc) return rc;
-        if (f->opt.forest_pipe_slots >= 4 && f->opt.forest_pipe_slots < pslots)
-            pslots = (int)f->opt.forest_pipe_slots;
-        const size_t lds = fea_bytes + (size_t)PIPE_R * LDS_C * sizeof(double) + 256 +
-                           (size_t)pslots * region_words * sizeof(uint2);
-        f->last_family = 5;
-        switch (pslots) {
-        case 4: PK_LAUNCH_PIPE(4); break;
-        case 5: PK_LAUNCH_PIPE(5); break;
-        case 6: PK_LAUNCH_PIPE(6); break;
-        case 7: PK_LAUNCH_PIPE(7); break;
-        default: PK_LAUNCH_PIPE(8); break;
-        }
-    } else if (blk == LDS_C && f->opt.forest_lds > 0) {
+    if (blk == LDS_C && f->opt.forest_lds > 0) {
         f->last_family = 6;
         int slots = (int)f->opt.forest_slots;
         if (slots == 0) {
@@ -764,7 +477,7 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         case 7: PK_LAUNCH_LDS(7); break;
         default: PK_LAUNCH_LDS(8); break;
         }
-    } else if (blk < LDS_C && (!f->opt.forest_l2_tile || fea_bytes > (size_t)156 * 1024)) {
+    } else {
         // large F (w = 11): no LDS, features from the L2-resident tile
         f->last_family = 7;
         const unsigned g2 = (unsigned)((cn + 255) / 256);
@@ -773,15 +486,6 @@ int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int b
         case 2: hipLaunchKernelGGL(forest_gmem_kernel<2>, dim3(g2), dim3(256), 0, ctx->stream, f->nodes, f->root, f->big_roff, f->T, f->F, tiles, blk, d_status, c0, cn, d_prob); break;
         case 8: hipLaunchKernelGGL(forest_gmem_kernel<8>, dim3(g2), dim3(256), 0, ctx->stream, f->nodes, f->root, f->big_roff, f->T, f->F, tiles, blk, d_status, c0, cn, d_prob); break;
         default: hipLaunchKernelGGL(forest_gmem_kernel<4>, dim3(g2), dim3(256), 0, ctx->stream, f->nodes, f->root, f->big_roff, f->T, f->F, tiles, blk, d_status, c0, cn, d_prob); break;
-        }
-    } else {
-        const size_t lds = fea_bytes;
-        f->last_family = 8;
-        switch (ilp) {
-        case 1: PK_LAUNCH_L2(1); break;
-        case 2: PK_LAUNCH_L2(2); break;
-        case 8: PK_LAUNCH_L2(8); break;
-        default: PK_LAUNCH_L2(4); break;
         }
     }
     PK_HIP(hipGetLastError());

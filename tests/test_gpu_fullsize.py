@@ -96,10 +96,8 @@ def test_config2_properties(config2):
                      dict(forest_q_ch=2, forest_slots=7), dict(forest_q_persist=0), dict(forest_q_persist=2),
                      dict(forest_q_persist=-7), dict(forest_q_persist=1, chunk=65536),
                      dict(forest_q=0), dict(forest_q=0, forest_slots=5),
-                     dict(forest_q=0, forest_img=0, forest_pipe=0),
-                     dict(forest_q=0, forest_img=0, forest_pipe=0, forest_slots=4),
-                     dict(forest_q=0, forest_img=0, forest_pipe=2),
-                     dict(forest_q=0, forest_img=0, forest_pipe=2, forest_pipe_slots=4),
+                     dict(forest_q=0, forest_img=0),
+                     dict(forest_q=0, forest_img=0, forest_slots=4),
                      dict(forest_lds=0), dict(extract_pair=0), dict(overlap=1), dict(overlap=1, chunk=65536),
                      dict(sub_chunk=262144), dict(sub_chunk=100000, chunk=1000000)):
             with handle_options(opts, c["hm"], c["hf"]):

@@ -94,32 +94,29 @@ def test_extract_any_coordinates_golden(hip_lib, w):
 
 
 @pytest.mark.parametrize("tag", ["plain", "balanced", "subsample"])
-@pytest.mark.parametrize("ilp,lds,slots,pipe,img,q", [
-    (4, 0, 8, 0, 0, 0), (1, 0, 8, 0, 0, 0), (8, 0, 8, 0, 0, 0),
-    (4, 160, 8, 0, 0, 0), (4, 160, 4, 0, 0, 0), (4, 160, 2, 0, 0, 0),
-    (4, 160, 6, 0, 0, 0), (4, 2, 8, 0, 0, 0), (4, 1, 4, 0, 0, 0),
-    (4, 160, 8, 1, 0, 0), (4, 160, 4, 4, 0, 0), (4, 160, 8, 6, 0, 0),
-    (4, 160, 0, 0, 1, 0), (4, 160, 2, 0, 1, 0), (4, 160, 4, 0, 1, 0),
-    (4, 160, 5, 0, 1, 0), (4, 160, 6, 0, 1, 0), (4, 160, 7, 0, 1, 0),
-    (4, 160, 8, 0, 1, 0),
+@pytest.mark.parametrize("ilp,lds,slots,img,q", [
+    (4, 0, 8, 0, 0), (1, 0, 8, 0, 0), (8, 0, 8, 0, 0),
+    (4, 160, 8, 0, 0), (4, 160, 4, 0, 0), (4, 160, 2, 0, 0),
+    (4, 160, 6, 0, 0), (4, 2, 8, 0, 0), (4, 1, 4, 0, 0),
+    (4, 160, 0, 1, 0), (4, 160, 2, 1, 0), (4, 160, 4, 1, 0),
+    (4, 160, 5, 1, 0), (4, 160, 6, 1, 0), (4, 160, 7, 1, 0),
+    (4, 160, 8, 1, 0),
     # q = walks per lane of the rank kernel + 1 (1 = automatic)
-    (4, 160, 0, 0, 1, 1), (4, 160, 4, 0, 1, 5), (4, 160, 9, 0, 1, 5), (4, 160, 16, 0, 1, 5),
-    (4, 160, 0, 0, 1, 3), (4, 160, 2, 0, 1, 3), (4, 160, 3, 0, 1, 3), (4, 160, 13, 0, 1, 3),
-    (4, 160, 16, 0, 1, 3)])
-def test_forest_golden(hip_lib, tag, ilp, lds, slots, pipe, img, q):
-    """Every forest kernel variant: nodes via L2 (lds=0) with 1/4/8 chains per
+    (4, 160, 0, 1, 1), (4, 160, 4, 1, 5), (4, 160, 9, 1, 5), (4, 160, 16, 1, 5),
+    (4, 160, 0, 1, 3), (4, 160, 2, 1, 3), (4, 160, 3, 1, 3), (4, 160, 13, 1, 3),
+    (4, 160, 16, 1, 3)])
+def test_forest_golden(hip_lib, tag, ilp, lds, slots, img, q):
+    """Every forest kernel variant: no LDS at all (lds=0: the gmem kernel) with 1/4/8 chains per
     lane; trees streamed through LDS in barrier-separated groups with 2..8
     tree slots; a tree buffer so small (1-2 KiB) that some trees are walked
-    from global memory; the barrier-free per-wave pipeline (pipe>0: number of
-    waves, 1 = as many as fit); the LDS-image kernel (img=1: fixed-depth walks
+    from global memory; the LDS-image kernel (img=1: fixed-depth walks
     over absolute LDS addresses) with automatic and forced slot counts; the rank kernel (q>0: 16-bit rank
     codes, 4-byte nodes, 2 or 4 walks per lane) with automatic and forced shapes."""
     z = gio.load("g2_forest_%s.npz" % tag)
     X = gio.load("g2_forest_plain.npz")["X"]
     hf = _lib.HipForest(flat(gio.forest(z)), options={
         "forest_img": img, "forest_q": 1 if q else 0, "forest_q_ch": q - 1 if q > 1 else 0, "forest_ilp": ilp,
-        "forest_lds": lds, "forest_slots": slots, "forest_pipe": 2 if pipe else 0,
-        "forest_pipe_slots": pipe if pipe >= 4 else 0})
+        "forest_lds": lds, "forest_slots": slots})
     p = hf.predict(X)
     assert np.array_equal(gio.bits(p), gio.bits(z["p"]))
 
@@ -764,9 +761,8 @@ def big_tree_forest(F, seed, n_small=5, big_nodes=60001):
                 p1=np.array(cols["p1"], np.float64), F=np.int32(F))
 
 
-@pytest.mark.parametrize("lds,pipe,img,q", [(160, 0, 0, 0), (160, 2, 0, 0), (0, 0, 0, 0), (160, 0, 1, 0),
-                                            (160, 0, 1, 1)])
-def test_giant_tree_side_table(hip_lib, lds, pipe, img, q):
+@pytest.mark.parametrize("lds,img,q", [(160, 0, 0), (0, 0, 0), (160, 1, 0), (160, 1, 1)])
+def test_giant_tree_side_table(hip_lib, lds, img, q):
     F = 121
     fo = big_tree_forest(F, seed=9)
     rng = np.random.default_rng(3)
@@ -775,7 +771,7 @@ def test_giant_tree_side_table(hip_lib, lds, pipe, img, q):
     X[11, rng.integers(0, F, 40)] = np.nan
     ref = onp.predict(fo, X)
     # q=1: the tree exceeds the rank format -> falls back; img=1: the tree does not fit the LDS -> falls back
-    hf = _lib.HipForest(flat(fo), options={"forest_q": q, "forest_lds": lds, "forest_pipe": pipe, "forest_img": img})
+    hf = _lib.HipForest(flat(fo), options={"forest_q": q, "forest_lds": lds, "forest_img": img})
     info = hf.info()
     p = hf.predict(X)
     assert info["n_nodes"] > 30000

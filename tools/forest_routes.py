@@ -13,7 +13,25 @@ from oracle import oracle_np as onp
 from fuzz_forest import random_forest
 
 FAMILY = {0: "-", 1: "forest_qr_kernel", 2: "forest_q_kernel", 3: "forest_q2_kernel", 4: "forest_img_kernel",
-          5: "forest_pipe_kernel", 6: "forest_lds_kernel", 7: "forest_gmem_kernel", 8: "forest_l2_kernel"}
+          6: "forest_lds_kernel", 7: "forest_gmem_kernel"}
+
+
+def replicated_forest(F, T, nodes, depth, seed):
+    """T trees of one random shape (nodes, depth) with their own random features, thresholds and
+    leaf values: what decides a model's route -- features, trees, nodes per tree, distinct
+    thresholds per feature -- without a Python loop per node."""
+    rng = np.random.default_rng(seed)
+    one = random_forest(rng, F, 1, nodes, depth, 0.0)
+    n = one["left"].size
+    inner = np.tile(one["left"] >= 0, T)
+    fo = {k: np.tile(one[k], T) for k in ("left", "right", "miss_left")}
+    feat, thr, p1 = np.tile(one["feat"], T), np.tile(one["thr"], T), np.tile(one["p1"], T)
+    k = int(inner.sum())
+    feat[inner] = rng.integers(0, F, k)
+    thr[inner] = rng.random(k)
+    p1[~inner] = rng.integers(0, 2, inner.size - k)
+    fo.update(feat=feat.astype(np.int32), thr=thr, p1=p1, tree_off=(np.arange(T + 1) * n).astype(np.int32))
+    return FlatForest(F, *[fo[k] for k in FlatForest.FIELDS])
 
 
 def committed(name):
