@@ -286,6 +286,8 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
     } else if (!strcmp(name, "forest_slots")) {
         if (value < 0 || value == 1 || value > 16) return PK_E_INVALID;
         o.forest_slots = value;
+    } else if (!strcmp(name, "early_exit")) {
+        o.early_exit = value != 0;
     } else if (!strcmp(name, "forest_q_two")) {
         o.forest_q_two = value != 0;
     } else if (!strcmp(name, "forest_q_help")) {

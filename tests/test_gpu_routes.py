@@ -32,8 +32,10 @@ ROUTES = [
     # (what the model is, how it is made, family, node word of the rank image or None)
     ("the benchmark forests' shape, w = 5 (<= 192 features, groups of <= 80 KiB)", committed("forest_w5_t100.npz"), QR, NARROW),
     ("w = 6: the released 5 / 10 kb models' window", committed("forest_w6_t100.npz"), QR, NARROW),
-    ("a model fitted on far more windows: > 2 047 thresholds per feature, trees beyond the pair field (12-bit ranks, "
-     "cut trees)", rep(121, 100, 8001, 30), QR, NARROW12),
+    ("more than 2 047 thresholds per feature (a model fitted on more windows): the 12-bit rank word keeps one row "
+     "per feature", rep(121, 300, 2501, 22), QR, NARROW12),
+    ("trees of 5 000 .. 8 000 nodes each: a group of them exceeds five 16-KiB rows -- the generic rank kernel",
+     rep(121, 100, 8001, 30), Q, NARROW12),
     ("tens of thousands of stumps", rep(121, 20000, 3, 1), QR, NARROW),
     ("trees of 20 000 nodes: two rows per feature, 128-candidate workgroups", rep(121, 60, 20001, 40), Q, NARROW12),
     ("193 .. 255 features (w = 7): 128-candidate workgroups", rep(225, 100, 2501, 22), Q, NARROW),
