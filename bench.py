@@ -494,9 +494,10 @@ def main():
                         -2 * w + 1, upper + 2 * w - 1, device=dev)
     hf = _lib.HipForest(fo, device=dev)
     cd = _lib.HipCands(x, y, device=dev)
-    # what ships: Chromosome.score switches the exact early exit on for its candidate list
-    # (peakachu_amd/scoreUtils.py: cd.set_prune(True)); --full-evaluation measures the other
-    # instantiation (every candidate's complete probability) as the headline instead
+    # what ships: Chromosome.score ALLOWS the exact early exit on its candidate list
+    # (peakachu_amd/scoreUtils.py: cd.set_prune(True)) and the library applies it where it pays
+    # (thre >= 0.55 on long lists; at the default 0.5 it does not: pk_api.hip score_run_impl);
+    # --full-evaluation withdraws the permission
     cd.set_prune(not a.full_evaluation)
     _lib.check(L.pk_device_synchronize(dev), "sync")
     upload_s = time.perf_counter() - t0
@@ -605,11 +606,11 @@ def main():
             cd.run(hm, hf, w, a.thre, a.batch)
             busy_steps += 1
 
-    # extra, not the headline: the same pass with the OTHER early-exit setting (the headline runs what
-    # Chromosome.score runs: exact early termination on; here every candidate gets its full probability)
+    # extra, not the headline: the same pass with the exact early exit FORCED (option early_exit = 1;
+    # the headline leaves the decision to the library, which at this threshold does not prune)
     early = None
     if world == 1:
-        cd.set_prune(bool(a.full_evaluation))
+        cd.set_option("early_exit", 1)
         step()
         sync()
         e_steps = min(a.steps, 20)
@@ -622,20 +623,18 @@ def main():
         e_el = time.perf_counter() - t0
         L.pk_prof_enable(0)
         e_forest = _lib.prof_get("forest")
-        cd.set_prune(not a.full_evaluation)
-        early = {"early_exit": bool(a.full_evaluation), "value": int(x.size) * e_steps / e_el,
-                 "ms_per_step": e_el / e_steps * 1e3, "steps": e_steps,
+        cd.set_option("early_exit", 0)
+        early = {"value": int(x.size) * e_steps / e_el, "ms_per_step": e_el / e_steps * 1e3, "steps": e_steps,
                  "forest_avg_launch_ms": e_forest[0] / e_forest[1] if e_forest[1] else None,
                  "scored_pixels": int(n_early), "same_pixels_as_headline": bool(n_early == n_out),
-                 "note": "the headline's pass with the early exit %s" % ("on" if a.full_evaluation else
-                         "off (every candidate's complete probability: the headline of rounds 1-4)")}
+                 "note": "the headline's pass with the exact early exit FORCED at threshold %g (the library applies "
+                         "it by itself from 0.55 on long lists: profiles/r05_prune_ab.log)" % a.thre}
 
     # extra, not the headline: SURVEY.md 8d's literal metric -- the same steps through
     # pk_score with HOST coordinate / result buffers (H2D of the candidates and D2H of the
     # scored pixels inside the timed region; matrix and forest stay resident)
     pcie = None
     if world == 1 and not a.no_pcie:
-        hm.set_option("early_exit", 0 if a.full_evaluation else 1)  # (pk_score: the matrix handle's pipeline options)
         hm.score(hf, w, a.thre, x, y, batch=a.batch)
         sync()
         p_steps = min(a.steps, 20)
@@ -645,14 +644,12 @@ def main():
         sync()
         p_el = time.perf_counter() - t0
         n_local_rate = int(x.size) * a.steps / elapsed
-        hm.set_option("early_exit", 0)
         pcie = {"value": int(x.size) * p_steps / p_el, "unit": "candidates/s", "steps": p_steps,
                 "ms_per_step": p_el / p_steps * 1e3, "scored_pixels": int(r_pcie[0].size),
                 "frac_of_device_resident": (int(x.size) * p_steps / p_el) / (n_local_rate or 1.0),
                 "note": "SURVEY 8d's literal metric: pk_score with HOST coordinate and result buffers -- upload "
                         "of the candidates (8 B each, chunk by chunk behind the kernels, checked on the device) "
-                        "and download of the scored pixels inside the timed region, same early-exit setting as "
-                        "the headline; `value` is the same pass over a device-resident list (the bench contract: "
+                        "and download of the scored pixels inside the timed region; `value` is the same pass over a device-resident list (the bench contract: "
                         "inputs resident in HBM when the timed region starts)"}
 
     # extra, not the headline: the other single-GPU shapes of BASELINE.json, a few steps each
@@ -767,9 +764,9 @@ def main():
                                " (untrained random trees)" if (a.forest or "").startswith("random:") else "",
                                "all" if a.stride == 1 else "every %d-th of the" % a.stride,
                                max(6, w + 1), upper,
-                               ("WITHOUT the early exit (every candidate's complete probability)" if a.full_evaluation
-                                else "with the exact early exit AS Chromosome.score sets it (same scored pixels; "
-                                     "other_early_exit_setting = the full evaluation)"),
+                               ("without permission to stop early (every candidate's complete probability)" if a.full_evaluation
+                                else "AS Chromosome.score runs it: the exact early exit allowed, which the library "
+                                     "applies from thresholds of 0.55 on (not at this one; forced_early_exit = forced)"),
                                "" if world == 1 else
                                ("; strong scaling: every rank holds chromosome seed 0" if strong else
                                 "; weak scaling: rank r scores its own synthetic chromosome, seed = r "
@@ -815,7 +812,7 @@ def main():
             },
             # SURVEY 8d's definition: candidates/s x B_alg / peak (per GPU) -- the WHOLE path, not one kernel
             "roofline_whole_path_frac": value / world * b_alg(F) / 1e9 / HBM_PEAK_GBS,
-            "early_exit": not a.full_evaluation,
+            "early_exit_allowed": not a.full_evaluation,
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kern.items()},
             "whole_path_alg_GBs": value * b_alg(F) / 1e9,
             "upload_s": upload_s,
@@ -831,7 +828,7 @@ def main():
         if strong_check is not None:
             out["strong_check"] = strong_check
         if early is not None:
-            out["other_early_exit_setting"] = early
+            out["forced_early_exit"] = early
         if regime is not None:
             out["real_regime"] = regime
         if world > 1:

@@ -146,11 +146,13 @@ int pk_predict(pk_forest *, int64_t N, const float *fea32, double *p1);
  * peakachu/scoreUtils.py:68) and all per-candidate outputs in HBM. */
 pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y);
 void pk_cands_destroy(pk_cands *);
-/* exact early termination for the runs of THIS candidate list (what Chromosome.score
- * needs: only the pixels with p > thre, peakachu/scoreUtils.py:110-113): a candidate
- * stops walking the forest once its sum can no longer exceed thre * T.  The scored
- * pixels are identical; pk_score_fetch_all then reports 0 for pruned candidates.
- * Off by default (every candidate gets its full probability). */
+/* ALLOW exact early termination for the runs of THIS candidate list (what Chromosome.score
+ * needs: only the pixels with p > thre, peakachu/scoreUtils.py:110-113): a candidate may stop
+ * walking the forest once its sum can no longer exceed thre * T.  The scored pixels are
+ * identical; pk_score_fetch_all reports 0 for a candidate that was stopped.  The library uses the
+ * permission where it pays (thre >= 0.55 on lists of >= 2^19 candidates: at the default 0.5 no
+ * candidate can stop before half the forest and the test costs more than it saves); option
+ * "early_exit" = 1 on the list forces it.  Off by default (every candidate gets its full probability). */
 int pk_cands_set_prune(pk_cands *, int on);
 /* extract -> predict -> (p > thre) -> compact, with the reference's batch
  * rule (a batch of `batch` candidates with fewer than two surviving windows

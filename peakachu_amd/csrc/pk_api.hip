@@ -1528,9 +1528,14 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
         PK_HIP(hipMalloc((void **)&cd->batch_cnt, sizeof(int32_t) * (size_t)nb));
         cd->n_batches_cap = nb;
     }
-    // optional exact early termination (option early_exit): only meaningful for thre >= 0
-    const double prune_sum =
-        ((cd->opt.early_exit || cd->prune) && thre >= 0.0) ? thre * (double)f->T : -INFINITY;
+    // Exact early termination: a candidate stops walking once its sum can no longer exceed thre * T.
+    // Option early_exit = 1 forces it; pk_cands_set_prune ALLOWS it and the library applies it where it
+    // pays -- measured on config 2 (profiles/r05_prune_ab.log): at thre = 0.5 no wave can stop before
+    // half the forest and the kernel's extra test costs 1.5-4 %; from thre = 0.6 on lists of at least
+    // ~0.5 M candidates (two tiles per workgroup and more) it saves 7 % (0.6) to 35 % (0.9) of the
+    // forest's time; a list of one or two tiles per workgroup never gains.  Only meaningful for thre >= 0.
+    const bool prune_on = thre >= 0.0 && (cd->opt.early_exit || (cd->prune && thre >= 0.55 && cd->N >= (int64_t)1 << 19));
+    const double prune_sum = prune_on ? thre * (double)f->T : -INFINITY;
     TR("run:enter");
     int rc = run_pipeline(ctx, m, f, cd, w, prune_sum);
     if (rc) return rc;

@@ -287,6 +287,30 @@ def test_early_exit_same_pixels(config2, thre):
         assert np.all(same) or thre > 0.0
 
 
+@pytest.mark.parametrize("thre,n,prunes", [(0.5, 1_500_000, False), (0.9, 1_500_000, True), (0.9, 300_000, False),
+                                           (0.6, 1_500_000, True)])
+def test_permission_to_stop_early_is_used_where_it_pays(config2, thre, n, prunes):
+    """pk_cands_set_prune ALLOWS the early exit (what Chromosome.score sets); the library applies it
+    from thresholds of 0.55 on lists of at least 2^19 candidates (profiles/r05_prune_ab.log: below
+    that it costs more than it saves).  The scored pixels never depend on it."""
+    c = config2
+    w = c["w"]
+    x, y = c["x"][:n], c["y"][:n]
+    cd = _lib.HipCands(x, y)
+    n1 = cd.run(c["hm"], c["hf"], w, thre)
+    base = digest(*cd.fetch())
+    st, pr = cd.fetch_all()
+    cd2 = _lib.HipCands(x, y)
+    cd2.set_prune(True)
+    assert cd2.run(c["hm"], c["hf"], w, thre) == n1
+    assert digest(*cd2.fetch()) == base
+    st2, pr2 = cd2.fetch_all()
+    assert np.array_equal(st2, st)
+    same = gio.bits(pr2) == gio.bits(pr)
+    assert np.all(same | (pr2 == 0.0)) and np.all(pr[~same] <= thre)
+    assert bool((~same).any()) == prunes
+
+
 def test_extract_and_predict_across_chunks(config2):
     """pk_extract (65 536-candidate staging chunks) and pk_predict (512 k chunks)
     on inputs larger than one chunk: survivor order and sampled values vs the oracle."""
