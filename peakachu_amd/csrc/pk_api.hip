@@ -1537,11 +1537,20 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
     const bool prune_on = thre >= 0.0 && (cd->opt.early_exit || (cd->prune && thre >= 0.55 && cd->N >= (int64_t)1 << 19));
     const double prune_sum = prune_on ? thre * (double)f->T : -INFINITY;
     TR("run:enter");
+    // A call that fails half-way may have left the record of an out-of-contract coordinate (word 65533
+    // of the diagnostic buffer, coords_sanitize_kernel) behind: it belongs to THAT call and must not
+    // be read by the next one on this device
+    auto forget_offender = [&](int code) {
+        hipStreamSynchronize(ctx->stream2);
+        hipStreamSynchronize(ctx->stream);
+        hipMemset(ctx->dbg_buf + 65533, 0, sizeof(long long));
+        return code;
+    };
     int rc = run_pipeline(ctx, m, f, cd, w, prune_sum);
-    if (rc) return rc;
+    if (rc) return forget_offender(rc);
     TR("run:launched");
     rc = pk_launch_compact(ctx, m, cd, thre, batch);
-    if (rc) return rc;
+    if (rc) return forget_offender(rc);
     // One copy into pinned memory brings back the count, words 65533 (first coordinate outside
     // pk_score's contract, see coords_sanitize_kernel), 65534 (a sink that keeps the kernels' warm-up
     // loads alive) and 65535 (the forest kernels' error word) of the diagnostic buffer and -- for
@@ -1562,12 +1571,16 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
     const long long err = dbg3[2];
     if (dbg3[0]) {
         PK_HIP(hipMemset(ctx->dbg_buf + 65533, 0, sizeof(long long)));
-        const long long i = (long long)((1ull << 62) - (unsigned long long)dbg3[0]);
-        if (cd->h_x && i >= 0 && i < cd->N)
-            pk_set_error("pk_score: coordinate %lld = (%d, %d) violates 0 <= x <= y < n=%d", i, cd->h_x[i], cd->h_y[i], m->n);
-        else
-            pk_set_error("pk_score: coordinate %lld violates 0 <= x <= y < n=%d", i, m->n);
-        return PK_E_INVALID;
+        // only a call that streamed host coordinates through the check can have an offender of its
+        // own (a resident list was checked when it was made); anything else is a stale record
+        if (cd->h_x) {
+            const long long i = (long long)((1ull << 62) - (unsigned long long)dbg3[0]);
+            if (i >= 0 && i < cd->N)
+                pk_set_error("pk_score: coordinate %lld = (%d, %d) violates 0 <= x <= y < n=%d", i, cd->h_x[i], cd->h_y[i], m->n);
+            else
+                pk_set_error("pk_score: coordinate %lld violates 0 <= x <= y < n=%d", i, m->n);
+            return PK_E_INVALID;
+        }
     }
     if (err) {
         PK_HIP(hipMemset(ctx->dbg_buf + 65535, 0, sizeof(long long)));

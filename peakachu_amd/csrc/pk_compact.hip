@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(256) batch_count_kernel(const uint8_t *__restr
     if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
     __syncthreads();
     // thread t takes the BC_ITEMS = 16 consecutive flags base + 16 t ..: one 16-byte load (the list is
-    // allocated by hipMalloc and `base` is a multiple of 4 096), flags are 0, 1 or 2
+    // allocated by hipMalloc and `base` is a multiple of 4 096); a flag counts when it is not zero,
+    // whatever its value (the byte-wise test below is exact for all 256 values, like the slow paths)
     static_assert(BC_ITEMS == 16, "one uint4 of flags per thread");
     int mine0 = 0, mine1 = 0;
     const int64_t c0 = base + (int64_t)threadIdx.x * BC_ITEMS;
@@ -154,7 +155,8 @@ __global__ void __launch_bounds__(256) batch_count_kernel(const uint8_t *__restr
         if (c0 / batch == (c0 + BC_ITEMS - 1) / batch) {
             int k = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) k += __popc((w4[j] | (w4[j] >> 1)) & 0x01010101u);
+            for (int j = 0; j < 4; j++)   // bit 7 of a byte = "the byte is not zero"
+                k += __popc((((w4[j] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w4[j]) & 0x80808080u);
             if (c0 / batch == b0) mine0 = k;
             else mine1 = k;
         } else {

@@ -43,15 +43,39 @@ def visible_gpus():
     return n
 
 
+def probed_gpus():
+    """GPUs the HIP runtime itself opens, asked of a short-lived CHILD (pk_device_count of the
+    package's library): sysfs lists every GPU of the host even where a container or lease may only
+    open some of them.  The launcher itself stays free of HIP.  None when the probe cannot run."""
+    code = "from peakachu_amd import _lib; print(_lib.load().pk_device_count())"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=root)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+        return None
+
+
 def wanted_ranks():
-    """How many ranks a bare start should fan out to: PK_DEVICES (a number, or `all`), else every
-    visible GPU; 1 (no fan-out) when a launcher has set WORLD_SIZE already or PK_NO_SPAWN=1."""
+    """How many ranks a bare start should fan out to.  The fan-out is OPT-IN: PK_DEVICES=<n> or
+    PK_DEVICES=all asks for it (an N > 1 run over RCCL has not been seen on hardware by the builder:
+    the default stays the single process the reference is); 1 when a launcher has set WORLD_SIZE
+    already or PK_NO_SPAWN=1.  The count is what sysfs lists, confirmed by a probe child that asks the
+    HIP runtime; where the two disagree the command stays one process (and says why)."""
     if "WORLD_SIZE" in os.environ or os.environ.get("PK_NO_SPAWN") == "1":
         return 1
-    want = os.environ.get("PK_DEVICES", "all").strip().lower()
+    want = os.environ.get("PK_DEVICES", "").strip().lower()
+    if want in ("", "0", "1"):
+        return 1
     n = visible_gpus()
-    if want not in ("", "all"):
+    if want != "all":
         n = min(n, int(want)) if n else int(want)
+    if n > 1:
+        seen = probed_gpus()
+        if seen is None or seen < n:
+            sys.stderr.write("peakachu_amd.launch: %s GPUs are listed but the HIP runtime opens %s: staying one process\n"
+                             % (n, "none (probe failed)" if seen is None else seen))
+            return 1
     return max(1, n)
 
 
@@ -60,10 +84,25 @@ def spawn(n, argv=None, env_extra=None):
     the exit code to leave with: 0 when all ranks did, else the first failure's (the others are
     told to stop: a rank that is gone can no longer take part in the gather)."""
     argv = list(argv if argv is not None else sys.orig_argv[1:])
-    fd, rfile = tempfile.mkstemp(prefix="pk_rdzv_", suffix=".json")
-    os.close(fd)
-    os.unlink(rfile)  # (rank 0 creates it; the name is what the children share)
+    # a directory of the launcher's own (mode 0700): rank 0 creates the file in it, nobody else can
+    rdir = tempfile.mkdtemp(prefix="pk_rdzv_")
+    rfile = os.path.join(rdir, "rendezvous.json")
     procs = []
+    # a launcher that is told to stop tells its ranks (they hold the GPUs), then leaves with the
+    # signal's code; without this its `finally` never ran and the children lived on
+    import signal
+
+    def _forward(signum, _frame):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        raise SystemExit(128 + signum)
+    previous = {}
+    try:
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            previous[sig] = signal.signal(sig, _forward)
+    except ValueError:  # (not the main thread: the caller's own business)
+        previous = {}
     try:
         for r in range(n):
             env = dict(os.environ)
@@ -96,8 +135,21 @@ def spawn(n, argv=None, env_extra=None):
     finally:
         for p in procs:
             if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 5.0
+        for p in procs:
+            while p.poll() is None and time.monotonic() < deadline:
+                time.sleep(0.05)
+            if p.poll() is None:
                 p.kill()
+        for sig, old in previous.items():
+            signal.signal(sig, old)
+        for path in (rfile,):
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
         try:
-            os.unlink(rfile)
+            os.rmdir(rdir)
         except OSError:
             pass

@@ -21,8 +21,16 @@ Finding rank 0:
 Failure behaviour (tests/test_dist.py): a rank that dies closes its socket; rank 0 sees the
 end of stream in the next operation, tells everybody else (`abort` frame) and raises; the
 others raise RendezvousError on the abort frame -- or on the end of stream when rank 0
-itself died.  Nobody waits longer than `timeout` seconds (PK_RDZV_TIMEOUT, default 1800:
-a rank may legitimately score for minutes between two operations).
+itself died.  Two bounds: the SETUP (every rank arrives, the handshake) takes at most
+PK_RDZV_TIMEOUT seconds (default 1800); inside a collective a peer that is silent but whose
+socket is open is a peer that is still scoring -- a rank may legitimately work for a long time
+between two operations, and an unbalanced run must not be lost to a clock -- so the wait there
+ends with the socket (a process that dies closes it at once on one host; TCP keep-alive covers
+the rest) or after PK_RDZV_OP_TIMEOUT seconds (default 24 h).
+
+The published file holds the token that admits a rank: it is created exclusively
+(O_EXCL | O_NOFOLLOW, mode 0600: a planted symlink is refused, other users cannot read it) and a
+peer only trusts a regular file of its own user that nobody else can read or write.
 """
 import json
 import os
@@ -47,6 +55,34 @@ def default_file():
         os.getuid(), os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"),
         os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
     return os.path.join(tempfile.gettempdir(), "".join(c if c.isalnum() or c in "._-" else "_" for c in name))
+
+
+def _keepalive(sock):
+    """A peer on another host that vanishes without closing its socket is noticed within minutes."""
+    try:
+        sock.setsockopt(socket.SOL_SOCKET, socket.SO_KEEPALIVE, 1)
+        for name, val in (("TCP_KEEPIDLE", 60), ("TCP_KEEPINTVL", 20), ("TCP_KEEPCNT", 6)):
+            if hasattr(socket, name):
+                sock.setsockopt(socket.IPPROTO_TCP, getattr(socket, name), val)
+    except OSError:
+        pass
+
+
+def _read_published(path):
+    """The endpoint rank 0 published -- from a regular file of this user that no one else can read
+    or write (it holds the token that admits a rank); anything else is treated like a missing file."""
+    fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    try:
+        st = os.fstat(fd)
+        import stat
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise ValueError("%s is not a private file of this user" % path)
+        with os.fdopen(fd, "r") as fh:
+            fd = -1
+            return json.load(fh)
+    finally:
+        if fd >= 0:
+            os.close(fd)
 
 
 def _recv_exact(sock, n):
@@ -86,6 +122,8 @@ class Rendezvous:
         self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
         self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         self.timeout = float(os.environ.get("PK_RDZV_TIMEOUT", "1800")) if timeout is None else float(timeout)
+        # (an explicit `timeout` bounds the collectives too: tests; otherwise they wait for the socket)
+        self.op_timeout = float(os.environ.get("PK_RDZV_OP_TIMEOUT", "86400")) if timeout is None else float(timeout)
         self._seq = 0
         self._peers = {}      # rank 0: rank -> socket
         self._sock = None     # other ranks: the socket to rank 0
@@ -112,8 +150,9 @@ class Rendezvous:
         self._listener = ls
         if not ep:
             self._file = os.environ.get("PK_RDZV_FILE") or default_file()
-            tmp = "%s.%d.tmp" % (self._file, os.getpid())
-            with open(tmp, "w") as fh:
+            tmp = "%s.%s.tmp" % (self._file, secrets.token_hex(8))
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "w") as fh:
                 json.dump({"host": "127.0.0.1", "port": ls.getsockname()[1], "token": token,
                            "world": self.world, "pid": os.getpid()}, fh)
             os.replace(tmp, self._file)  # atomically: a peer sees the old file or the new one
@@ -138,7 +177,8 @@ class Rendezvous:
                     c.close()
                     continue
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(self.timeout)
+                _keepalive(c)
+                c.settimeout(self.op_timeout)
                 self._peers[r] = c
             except (OSError, struct.error):
                 c.close()
@@ -154,14 +194,14 @@ class Rendezvous:
                     host, _, port = ep.rpartition(":")
                     info = {"host": host or "127.0.0.1", "port": int(port), "token": os.environ.get("PK_RDZV_TOKEN", "")}
                 else:
-                    with open(path) as fh:
-                        info = json.load(fh)
+                    info = _read_published(path)
                 s = socket.create_connection((info["host"], int(info["port"])), timeout=5.0)
                 s.sendall(MAGIC + struct.pack("<II", self.rank, self.world) +
                           info["token"].encode("ascii").ljust(32, b"\0"))
                 if _recv_exact(s, 1) == b"\1":
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    s.settimeout(self.timeout)
+                    _keepalive(s)
+                    s.settimeout(self.op_timeout)
                     self._sock = s
                     return
                 s.close()

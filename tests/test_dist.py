@@ -162,8 +162,18 @@ def test_gpu_count_without_touching_hip(monkeypatch, tmp_path):
     monkeypatch.setenv("PK_NO_SPAWN", "1")
     assert launch.wanted_ranks() == 1
     monkeypatch.delenv("PK_NO_SPAWN")
+    # the fan-out is opt-in, and what sysfs lists must be confirmed by a probe child that asks HIP
+    assert launch.wanted_ranks() == 1
     monkeypatch.setenv("PK_DEVICES", "3")
-    assert launch.wanted_ranks() == (3 if n == 0 else min(n, 3))
+    want = 3 if n == 0 else min(n, 3)
+    monkeypatch.setattr(launch, "probed_gpus", lambda: 8)
+    assert launch.wanted_ranks() == want
+    monkeypatch.setattr(launch, "probed_gpus", lambda: None)       # the probe could not run
+    assert launch.wanted_ranks() == 1
+    monkeypatch.setattr(launch, "probed_gpus", lambda: want - 1)    # HIP opens fewer than are listed
+    assert launch.wanted_ranks() == (1 if want > 1 else want)
+    monkeypatch.undo()
+    assert launch.probed_gpus() in (None, 0) or launch.probed_gpus() >= 1   # (runs: a child, no HIP in this process)
 
 
 def test_bench_launches_itself_for_n_gpus():
