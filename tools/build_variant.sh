@@ -13,9 +13,9 @@ make -s -j8 >/dev/null
     -Wno-unused-function -Wno-unused-value -Wno-unused-result -Wno-pass-failed "$@" \
     -c "$src.hip" -o "$root/tools/ab/$name.$src.o" 2>&1 | grep -v "argument unused" || true
 objs=""
-for o in pk_api pk_extract pk_forest pk_forest_img pk_image pk_forest_q pk_qimage pk_compact pk_comm; do
+for o in pk_api pk_extract pk_forest pk_forest_img pk_image pk_forest_q pk_qimage pk_compact pk_comm pk_hostio; do
   if [ "$o" = "$src" ]; then objs="$objs $root/tools/ab/$name.$src.o"; else objs="$objs $o.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/ab/$name.so" $objs -L/opt/rocm/lib -lrccl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/ab/$name.so" $objs -L/opt/rocm/lib -lrccl -ldl -lpthread
 rm -f "$root/tools/ab/$name.$src.o"
 echo "built tools/ab/$name.so"
