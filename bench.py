@@ -224,7 +224,7 @@ def pmc_rooflines(dom, launches_per_step_live, pmc_file="pmc.json"):
              "source": note}
     # tools/micro/lds_indep.hip on MI355X (profiles/r03_lds_indep.log): INDEPENDENT ds_read_u16 /
     # b32 / b64 wave-instructions cost the CU 1.6-2.0 cycles each with >= 64 in flight (16 waves x
-    # 4), as the guide's LDS table says (2 LDS-array cycles) -- not the 4 cycles DESIGN.md round 2
+    # 4), as the guide's LDS table says (2 LDS-array cycles) -- not the 4 cycles EXPERIMENTS.md (round 2)
     # took from dependent chains.  The walk is a DEPENDENT chain (2 048 of them fit the LDS), so
     # the array-busy fraction is the roofline and the instruction count x 2 cycles its floor.
     lds = {"bound": "lds", "lds_wave_insts_per_launch": c.get("SQ_INSTS_LDS"),

@@ -991,7 +991,7 @@ __device__ __forceinline__ int reflect1(int q, int n)
 // WT > 0: the half-width is a compile-time constant (w = 11, the 23 x 23 stress
 // configuration): every loop unrolls, so the 12 gather loads of a lane are all in flight
 // together and the 121 LDS reads of the sequential top-left sum are issued back to back
-// instead of one round trip each (measured at w = 11: 6.9 -> see DESIGN.md).  WT = 0: any w.
+// instead of one round trip each (measured at w = 11: 6.9 -> see EXPERIMENTS.md 4.1).  WT = 0: any w.
 // ANY: coordinates of any kind (pk_extract / getwindow with x > y or off-matrix entries).
 // The reference's getwindow (scoreUtils.py:70-93) masks only `x-w >= 0 and y+w+1 <= n`; a
 // lower-triangle coordinate that passes reads its window from the stored diagonals

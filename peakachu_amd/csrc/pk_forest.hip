@@ -6,7 +6,7 @@
 // missing_go_to_left), leaf class-1 fractions added in tree order in float64
 // and divided by T.
 //
-// Design:
+// Design (the measurements: EXPERIMENTS.md §4.2):
 //  * one candidate per lane; the candidate's F float32 features sit in LDS as a
 //    [F][128] tile, so the per-node feature fetch `fea[f*128 + lane]` is
 //    bank-conflict-free whatever f each lane asks for;

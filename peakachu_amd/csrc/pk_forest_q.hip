@@ -4,7 +4,7 @@
 // ForestClassifier.predict_proba -> Tree._apply_dense) exactly; pk_qimage.hip
 // explains why ranks decide every split the same way as the float32 features.
 //
-// Why this shape (measured on MI355X, tools/micro/lds_chain.hip):
+// Why this shape (measured on MI355X, tools/micro/lds_chain.hip, EXPERIMENTS.md 4.2):
 // a level of a tree walk is one dependent LDS round trip, and with >= 12 waves
 // walking the LDS pipe is what binds: a wave-level costs the CU about 15 cycles
 // when it reads a float32 feature and two 8-byte child words, and about 9 when
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 // trees, two waves per tree -- with the STAGING REGISTERS TAKEN AWAY FROM THE COMPILER and a
 // walk path without scalar tests.
 //
-// Round 3 measured (DESIGN.md 4.2 iii): the 67 wave-loads of the next tree group, issued by all
+// Round 3 measured (EXPERIMENTS.md 4.2 iii): the 67 wave-loads of the next tree group, issued by all
 // sixteen waves at once in front of the walk, queue up in the CU's memory pipeline and every wave
 // stands still until its own are accepted; issued from INSIDE the walk, a few levels in and one
 // SIMD position at a time, the stage is 7 % faster -- but every C++ form of that either moved the

@@ -2,7 +2,7 @@
 // costs a CU when the reads are INDEPENDENT (nothing chained), by instruction kind, waves per
 // CU, reads in flight per wave and address pattern -- and the same for the forest walk's own
 // level (ds_read_u16 + ds_read_b64 + 5 VALU, dependent) by waves x chains per lane.
-// Settles DESIGN.md 4.2's "4 cycles per LDS instruction" against MI355X_MICROARCH.md's LDS
+// Settles EXPERIMENTS.md 4.2's "4 cycles per LDS instruction" against MI355X_MICROARCH.md's LDS
 // table (ds_read_b32 / b64: 2 LDS-array cycles).
 // Build: hipcc --offload-arch=gfx950 -O3 -o lds_indep lds_indep.hip
 #include <hip/hip_runtime.h>
