@@ -95,12 +95,13 @@ def build_chromosome(Lib, key, cname, model, correct, args, width, device, input
 
 
 def warm_imports():
-    """scikit-learn's isotonic module (the expected curve's fit, peakachu/utils.py:173) and the
-    device library take a few tenths of a second to import / initialise; started on a thread
+    """scipy.stats (the Poisson tables) and scikit-learn's isotonic module (the expected curve's
+    fit, peakachu/utils.py:173) take a few tenths of a second to import; started on a thread
     here, that happens while the main thread opens the model and the first chromosome is read."""
     import threading
 
     def work():
+        import scipy.stats  # noqa: F401  (the Poisson tables of get_candidate)
         try:
             import sklearn.isotonic  # noqa: F401
         except ImportError:

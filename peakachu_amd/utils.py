@@ -8,7 +8,20 @@ feed numpy / scipy / sklearn the same operands in the same order, so their
 results are bit-identical to the reference's (tests/test_host_golden.py).
 """
 import numpy as np
-from scipy import sparse, stats
+from scipy import sparse
+
+
+class _LazyStats:
+    """scipy.stats on first use: its import costs a quarter of a second, which the scoring commands
+    would otherwise pay before the first chromosome is even read (score_genome.warm_imports starts
+    it on a thread instead)."""
+
+    def __getattr__(self, name):
+        import scipy.stats
+        return getattr(scipy.stats, name)
+
+
+stats = _LazyStats()
 
 
 def tocsr(X):

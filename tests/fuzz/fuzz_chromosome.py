@@ -28,6 +28,7 @@ def main():
     _lib.require_device()
     t0 = time.time()
     npix = 0
+    n_upper = 0
     for case in range(n_cases):
         seed = seed0 + case
         rng = np.random.default_rng(seed)
@@ -56,7 +57,9 @@ def main():
             M = synth.balance(raw, weights)
         else:
             M = sparse.csr_matrix(raw * 0.37)
+        injected = False
         if rng.random() < 0.15 and mode != "raw":  # a few non-finite cells
+            injected = True
             M = M.copy()
             idx = rng.choice(M.data.size, min(5, M.data.size), replace=False)
             M.data[idx[:3]] = np.nan
@@ -79,6 +82,24 @@ def main():
                 continue
             print("case %3d seed=%d: only the device path raised %s: %s" % (case, seed, type(e).__name__, e))
             raise
+        # the same chromosome from its pixel table as a .cool stores it (Chromosome.from_upper: mirrored and
+        # balanced on the device) must be the same object: expected curve, background, candidates
+        if mode in ("raw", "weights") and not injected:
+            tri = sparse.triu(raw, 0, format="csr")
+            tri.sort_indices()
+            px = utils.UpperPixels(n, tri.indptr.astype(np.int32), tri.indices.astype(np.int32),
+                                   tri.data.astype(np.int32) if rng.random() < 0.7 else tri.data.astype(np.float64))
+            chu = scoreUtils.Chromosome.from_upper(px, model, bias=weights, weights=weights, lower=lower, upper=upper, width=w)
+            # (balanced values as cooler makes them, (w[row] * w[col]) * count: synth.balance multiplies in another order)
+            chm = ch if mode == "raw" else scoreUtils.Chromosome(px.symmetric(weights), model, raw_M=px.symmetric(),
+                                                                 weights=weights, lower=lower, upper=upper, width=w)
+            same = (np.array_equal(bits(chu.exp_arr), bits(chm.exp_arr)) and np.array_equal(bits(chu.background), bits(chm.background))
+                    and np.array_equal(chu.ridx, chm.ridx) and np.array_equal(chu.cidx, chm.cidx))
+            ru = sparse.csr_matrix(chu.score(thre)[0])
+            rm = None if chm is ch else sparse.csr_matrix(chm.score(thre)[0])   # (ch itself is scored below)
+            n_upper += 1
+        else:
+            chu, same, ru, rm = None, True, None, None
         # host restatement of the constructor
         lo = max(lower, w + 1)
         up = min(upper, n - 2 * w)
@@ -95,6 +116,11 @@ def main():
         rx, ry = utils.candidates(raw_arg, bg_ref, weights, lo, up)
         ok_c = np.array_equal(ch.ridx, rx) and np.array_equal(ch.cidx, ry)
         res, R = ch.score(thre)
+        if ru is not None:
+            rm = sparse.csr_matrix(res) if rm is None else rm
+            ru.sort_indices(), rm.sort_indices()
+            same = same and np.array_equal(ru.indptr, rm.indptr) and np.array_equal(ru.indices, rm.indices) and \
+                np.array_equal(bits(ru.data), bits(rm.data))
         ox, oy = res.nonzero()
         px, py, pp, ps = onp.score(Mf, e_ref, w, fo, thre, np.asarray(rx, np.int32), np.asarray(ry, np.int32), threads=8)
         got = sparse.csr_matrix(res)
@@ -103,11 +129,13 @@ def main():
         npix += int(px.size)
         print("case %3d seed=%d w=%2d n=%4d band=%3d lower=%2d upper=%4d %-7s thin=%d cands=%6d scored=%5d device_cands=%s: exp %s band %s cands %s score %s" % (
             case, seed, w, n, band, lower, upper, mode, thin, len(rx), px.size, ch._cands is not None,
-            "ok" if ok else "MISMATCH", "ok" if ok_band else "MISMATCH", "ok" if ok_c else "MISMATCH", "ok" if ok_s else "MISMATCH"))
+            "ok" if ok else "MISMATCH", "ok" if ok_band else "MISMATCH", "ok" if ok_c else "MISMATCH", "ok" if ok_s else "MISMATCH")
+            + ("" if chu is None else " from_upper %s" % ("ok" if same else "MISMATCH")))
         sys.stdout.flush()
-        if not (ok and ok_band and ok_c and ok_s):
+        if not (ok and ok_band and ok_c and ok_s and same):
             sys.exit(1)
-    print("all %d cases identical in %.0f s (%d scored pixels compared)" % (n_cases, time.time() - t0, npix))
+    print("all %d cases identical in %.0f s (%d scored pixels compared; %d chromosomes also built from their pixel table)"
+          % (n_cases, time.time() - t0, npix, n_upper))
 
 
 if __name__ == "__main__":
