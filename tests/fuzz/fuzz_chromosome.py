@@ -90,13 +90,15 @@ def main():
             px = utils.UpperPixels(n, tri.indptr.astype(np.int32), tri.indices.astype(np.int32),
                                    tri.data.astype(np.int32) if rng.random() < 0.7 else tri.data.astype(np.float64))
             chu = scoreUtils.Chromosome.from_upper(px, model, bias=weights, weights=weights, lower=lower, upper=upper, width=w)
-            # (balanced values as cooler makes them, (w[row] * w[col]) * count: synth.balance multiplies in another order)
-            chm = ch if mode == "raw" else scoreUtils.Chromosome(px.symmetric(weights), model, raw_M=px.symmetric(),
-                                                                 weights=weights, lower=lower, upper=upper, width=w)
+            # against the matrix constructor on the MIRROR IMAGE of that table (a thinned map is not
+            # symmetric any more; balanced values as cooler makes them, (w[row] * w[col]) * count:
+            # synth.balance multiplies in another order)
+            sym = px.symmetric()
+            chm = scoreUtils.Chromosome(sym if mode == "raw" else px.symmetric(weights), model, raw_M=sym,
+                                        weights=weights, lower=lower, upper=upper, width=w)
             same = (np.array_equal(bits(chu.exp_arr), bits(chm.exp_arr)) and np.array_equal(bits(chu.background), bits(chm.background))
                     and np.array_equal(chu.ridx, chm.ridx) and np.array_equal(chu.cidx, chm.cidx))
-            ru = sparse.csr_matrix(chu.score(thre)[0])
-            rm = None if chm is ch else sparse.csr_matrix(chm.score(thre)[0])   # (ch itself is scored below)
+            ru, rm = sparse.csr_matrix(chu.score(thre)[0]), sparse.csr_matrix(chm.score(thre)[0])
             n_upper += 1
         else:
             chu, same, ru, rm = None, True, None, None
@@ -117,7 +119,6 @@ def main():
         ok_c = np.array_equal(ch.ridx, rx) and np.array_equal(ch.cidx, ry)
         res, R = ch.score(thre)
         if ru is not None:
-            rm = sparse.csr_matrix(res) if rm is None else rm
             ru.sort_indices(), rm.sort_indices()
             same = same and np.array_equal(ru.indptr, rm.indptr) and np.array_equal(ru.indices, rm.indices) and \
                 np.array_equal(bits(ru.data), bits(rm.data))
