@@ -315,7 +315,7 @@ def _timed_runs(L, dev, cd, hm, hf, w, thre, batch, reps):
     return el / reps * 1e6, kern, int(n_out)
 
 
-def real_regime(L, dev, M, fo, w, lower, upper, thre, batch, x_all, y_all, hm, hf):
+def real_regime(L, dev, M, fo, w, lower, upper, thre, batch, x_all, y_all, hm, hf, strided=True):
     """The regime the CLI runs in (peakachu/scoreUtils.py:40-68, 95-106): the Poisson-filtered
     candidate list get_candidate makes -- a few percent of the band's non-zero pixels, scattered
     along the diagonals -- and short lists, scored by pk_score_run with the early exit
@@ -364,7 +364,7 @@ def real_regime(L, dev, M, fo, w, lower, upper, thre, batch, x_all, y_all, hm, h
                                       "the first carries this process's one-off costs"}
     leg("get_candidate (Poisson p < 0.01)", px, py, 50)
     # (ii) strided sub-lists of the all-non-zero-band-pixels list
-    for m in (1000, 10000, 100000, 1000000):
+    for m in ((1000, 10000, 100000, 1000000) if strided else ()):
         s = max(1, x_all.size // m)
         leg("every %d-th non-zero band pixel" % s, x_all[::s].copy(), y_all[::s].copy(), 200 if m <= 10000 else 50)
     out["legs"] = legs

@@ -161,9 +161,9 @@ def oracle_bedpe(man, work, model_path, wname, lower, upper, thre, out, only=Non
     return T
 
 
-def run_cli(argv, report=None):
+def run_cli(argv, report=None, **extra_env):
     """The product's command line in a FRESH process (as a user starts it); returns wall seconds."""
-    env = dict(os.environ, PK_NO_SPAWN="1")
+    env = dict(os.environ, PK_NO_SPAWN="1", **extra_env)
     if report:
         env.update(PK_STAGE_TIMES="1", PK_STAGE_REPORT=report)
     t0 = time.perf_counter()
@@ -216,6 +216,11 @@ def e2e(a):
             % (host_cores(), cpu, ", ".join("%s %.1f" % (k, v) for k, v in T.items() if k != "candidates_total")))
         say("   %d candidates, %d bedpe lines, bedpe bytes %s the oracle chain's"
             % (T["candidates_total"], sum(1 for _ in open(out)), "EQUAL" if same else "DIFFER FROM"))
+    if a.prefetch_sweep:
+        out = os.path.join(work, "sweep.bedpe")
+        for depth in (1, 2, 3, 4, 6):
+            walls = [run_cli(legs[0][1] + ["-O", out, "-u", str(a.upper)], PK_PREFETCH=str(depth)) for _ in range(2)]
+            say("PK_PREFETCH=%d: score_genome raw wall %s s" % (depth, " / ".join("%.2f" % v for v in walls)))
     if not a.keep:
         for f in os.listdir(work):
             os.remove(os.path.join(work, f))
@@ -235,4 +240,5 @@ if __name__ == "__main__":
     ap.add_argument("--repeats", type=int, default=2)
     ap.add_argument("--trans", type=int, default=0, help="trans pixels per bin")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--prefetch-sweep", action="store_true", help="also time score_genome raw for reader-thread counts 1..6")
     sys.exit(e2e(ap.parse_args()))

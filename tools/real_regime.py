@@ -21,7 +21,9 @@ Mf = utils.band_filter(M, w, upper)
 x, y = synth.all_band_pixels(Mf, max(6, w + 1), upper)
 hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, n, exp_arr, -2 * w + 1, upper + 2 * w - 1)
 hf = _lib.HipForest(fo)
-rr = bench.real_regime(L, 0, M, fo, w, 6, upper, 0.5, 100000, x, y, hm, hf)
+# PK_RR_POISSON_ONLY=1: only the list get_candidate makes (the leg whose rocprofv3 --stats summary is kept)
+rr = bench.real_regime(L, 0, M, fo, w, 6, upper, 0.5, 100000, x, y, hm, hf,
+                       strided=os.environ.get("PK_RR_POISSON_ONLY") != "1")
 for p in rr["chromosome_cold"]["passes"]:
     print("cold: construct %.2f ms, score %.2f ms, %d candidates, %d pixels"
           % (p["construct_ms"], p["score_ms"], p["candidates"], p["scored_pixels"]))
