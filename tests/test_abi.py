@@ -74,3 +74,47 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f
+
+
+def test_host_chunk_pipeline_inflates_and_unshuffles():
+    """pk_host_unfilter_chunks (include/peakachu_hip.h; what h5lite hands a ranged read's chunks to):
+    inflate + byte un-shuffle + the wanted slice of every chunk, for element sizes 1 .. 8, whole and
+    partial slices, one and several threads -- against zlib + numpy; a chunk that does not inflate to
+    its size and a slice outside the chunk are refused.  No device involved."""
+    import ctypes as C
+    import zlib
+    from peakachu_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(9)
+    for es in (8, 4, 2, 1):
+        n_el, m = 1000, 7
+        chunks = [rng.integers(0, 256, n_el * es, dtype=np.uint8).tobytes() for _ in range(m)]
+        stored = []
+        for c in chunks:  # the write pipeline: shuffle, then deflate
+            sh = np.frombuffer(c, np.uint8).reshape(n_el, es).T.tobytes() if es > 1 else c
+            stored.append(zlib.compress(sh, 1))
+        skip = np.array([0, es * 3, 0, es * 999, es * 500, 0, es * 10], np.int64)
+        take = np.array([n_el * es, es * 5, 0, es, es * 500, es * 1000, es * 17], np.int64)
+        out = [np.zeros(max(int(t), 1), np.uint8) for t in take]
+        src = (C.c_char_p * m)(*stored)
+        dst = (C.c_void_p * m)(*[o.ctypes.data for o in out])
+        lens = np.array([len(s) for s in stored], np.int64)
+        for threads in (1, 4):
+            for o in out:
+                o[:] = 0
+            rc = L.pk_host_unfilter_chunks(m, C.cast(src, C.c_void_p), lens, 1, es, n_el * es, skip, take,
+                                           C.cast(dst, C.c_void_p), threads)
+            assert rc == 0, _lib.last_error()
+            for c, o, s0, t in zip(chunks, out, skip, take):
+                assert o[:int(t)].tobytes() == c[int(s0):int(s0 + t)]
+        # a chunk that does not inflate to chunk_bytes
+        bad = (C.c_char_p * 1)(zlib.compress(b"short", 1))
+        one = np.zeros(8, np.uint8)
+        rc = L.pk_host_unfilter_chunks(1, C.cast(bad, C.c_void_p), np.array([len(bad[0])], np.int64), 1, es, n_el * es,
+                                       np.zeros(1, np.int64), np.array([es], np.int64),
+                                       C.cast((C.c_void_p * 1)(one.ctypes.data), C.c_void_p), 1)
+        assert rc == _lib.PK_E_INVALID and "does not inflate" in _lib.last_error()
+        # a slice beyond the chunk
+        rc = L.pk_host_unfilter_chunks(1, C.cast(src, C.c_void_p), lens, 1, es, n_el * es, np.array([es * 999], np.int64),
+                                       np.array([es * 2], np.int64), C.cast(dst, C.c_void_p), 1)
+        assert rc == _lib.PK_E_INVALID
