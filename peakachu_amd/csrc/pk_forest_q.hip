@@ -1127,8 +1127,10 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
 // staged group serves 128 candidates: half the L2 traffic, half the commits, half the barriers
 // per candidate for one exchange.  The tile left in LDS by a group is the one the next group
 // walks first.  No next-tile prefetch (the staging registers and the spare tile leave no room;
-// a trip is 72 groups long), no early termination (Chromosome.score's prune keeps the
-// one-tile kernel), no issue priorities (seven latency-bound waves).
+// a trip is 72 groups long), no early termination (a run that allows pruning gets every candidate's
+// full probability here: same scored pixels, and the one-tile kernel with its early exit is the slower of
+// the two -- round 5), no issue priorities (latency-bound waves; rotating them was measured in round 5 on
+// the fitted forest's 14-15-tree groups: +1.3 %, not kept).
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,

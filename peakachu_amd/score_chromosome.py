@@ -11,7 +11,7 @@ from .score_genome import build_chromosome, warm_imports
 
 def main(args):
     np.seterr(divide='ignore', invalid='ignore')
-    warm_imports()
+    warm_imports(getattr(args, "device", 0))
     if os.path.exists(args.output):
         os.remove(args.output)
     model = load_model(args.model)

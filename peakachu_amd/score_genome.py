@@ -95,13 +95,19 @@ def build_chromosome(Lib, key, cname, model, correct, args, width, device, input
                                  width=width, device=device)
 
 
-def warm_imports():
-    """scipy.stats (the Poisson tables) and scikit-learn's isotonic module (the expected curve's
-    fit, peakachu/utils.py:173) take a few tenths of a second to import; started on a thread
-    here, that happens while the main thread opens the model and the first chromosome is read."""
+def warm_imports(device=0):
+    """scipy.stats (the Poisson tables), scikit-learn's isotonic module (the expected curve's
+    fit, peakachu/utils.py:173) and the HIP runtime's first contact with the device take a few
+    tenths of a second; started on a thread here, that happens while the main thread opens the
+    model and the first chromosome is read."""
     import threading
 
     def work():
+        try:  # (the device context of this rank: ctypes releases the GIL while HIP initialises)
+            from . import _lib
+            _lib.load().pk_device_synchronize(int(device))
+        except Exception:
+            pass  # whatever is wrong with the library or the device, the first real call says it
         import scipy.stats  # noqa: F401  (the Poisson tables of get_candidate)
         try:
             import sklearn.isotonic  # noqa: F401
@@ -112,8 +118,8 @@ def warm_imports():
 
 def main(args):
     np.seterr(divide='ignore', invalid='ignore')
-    warm_imports()
     rank, local_rank, world = dist.rank_info()
+    warm_imports(local_rank)
     if rank == 0 and os.path.exists(args.output):
         os.remove(args.output)
 
