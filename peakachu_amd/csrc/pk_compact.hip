@@ -53,18 +53,21 @@ __global__ void band_build_kernel(const int32_t *__restrict__ indptr,
 // (as ordered bits of a non-negative double).  valid_raw[c] = column c holds a positive
 // finite entry; valid_bal[r] = valid_bal[c] = 1 for every finite non-zero entry
 // (peakachu/utils.py:145-155).
-__global__ void csr_info_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                                const double *__restrict__ data, int64_t nnz, int n,
-                                unsigned long long *__restrict__ info,
-                                unsigned long long *__restrict__ vmax_bits,
-                                uint8_t *__restrict__ valid_raw, uint8_t *__restrict__ valid_bal,
-                                const double *__restrict__ bias, int upper,
-                                unsigned long long *__restrict__ bad_order)
+__global__ void __launch_bounds__(256) csr_info_kernel(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                       const double *__restrict__ data, int64_t nnz, int n,
+                                                       unsigned long long *__restrict__ info,
+                                                       unsigned long long *__restrict__ vmax_bits,
+                                                       uint8_t *__restrict__ valid_raw, uint8_t *__restrict__ valid_bal,
+                                                       const double *__restrict__ bias, int upper,
+                                                       unsigned long long *__restrict__ bad_order)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned c_fin = 0, c_non = 0, c_frac = 0, c_neg = 0, c_off = 0;
+    // A fixed grid strides over the entries and every thread keeps its own counts: one atomic per
+    // WORKGROUP and counter at the end.  (Rounds 2-4 issued them per wave: 380 000 atomics on two
+    // addresses for a 12 M-entry chromosome, serialised in the L2 -- 4.2 ms for a scan that takes 0.2;
+    // profiles/r05_real_regime_kernel_stats.csv shows it as the longest kernel of a chromosome.)
+    unsigned n_fin = 0, n_non = 0, n_frac = 0, n_neg = 0, n_bad = 0;
     unsigned long long mx = 0;
-    if (e < nnz) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
         double v = data[e];
         const int col = indices[e];
         const bool inside = col >= 0 && col < n;
@@ -73,45 +76,52 @@ __global__ void csr_info_kernel(const int32_t *__restrict__ indptr, const int32_
             r = csr_row_of(indptr, n, e);
             // an upper-triangle table must be what a .cool holds: columns strictly ascending
             // inside a row, none left of the diagonal (a duplicate pixel would be written, not summed)
-            if (upper && (col < r || (e > (int64_t)indptr[r] && indices[e - 1] >= col))) atomicAdd(bad_order, 1ull);
+            if (upper && (col < r || (e > (int64_t)indptr[r] && indices[e - 1] >= col))) n_bad++;
             if (bias && inside) v = (bias[r] * bias[col]) * v;
         }
+        // (an off-diagonal entry of an upper-triangle table stands for two entries of the matrix)
+        const unsigned weight = (upper && col != r) ? 2u : 1u;
         if (upper && !inside) {
             // a pixel of another chromosome: not part of this matrix
         } else if (!(v - v == 0.0)) {
-            c_non = 1;
-            c_off = upper && col != r;
+            n_non += weight;
         } else if (v != 0.0) {
-            c_fin = 1;
-            c_off = upper && col != r;
-            if (v < 0.0) c_neg = 1;
-            if (v < 0.0 || v != __builtin_floor(v)) c_frac = 1;
+            n_fin += weight;
+            if (v < 0.0) n_neg += weight;
+            if (v < 0.0 || v != __builtin_floor(v)) n_frac += weight;
             if (r < 0 && inside) r = csr_row_of(indptr, n, e);
             if (v > 0.0) {
-                mx = (unsigned long long)__double_as_longlong(v);
-                if (inside) valid_raw[col] = 1;
-                if (upper) valid_raw[r] = 1;  // (the mirrored entry sits in column r)
+                const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+                mx = b > mx ? b : mx;
+                if (inside && !valid_raw[col]) valid_raw[col] = 1;
+                if (upper && !valid_raw[r]) valid_raw[r] = 1;  // (the mirrored entry sits in column r)
             }
             if (inside) {
-                valid_bal[col] = 1;
-                valid_bal[r] = 1;
+                if (!valid_bal[col]) valid_bal[col] = 1;
+                if (!valid_bal[r]) valid_bal[r] = 1;
             }
         }
     }
-    // wave-level reduction, one atomic per wave and counter (an off-diagonal entry of an
-    // upper-triangle table stands for two entries of the matrix)
-    const unsigned long long m_fin = __ballot(c_fin), m_non = __ballot(c_non), m_frac = __ballot(c_frac),
-                             m_neg = __ballot(c_neg), m_off = __ballot(c_off);
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(mx, o);
-        mx = other > mx ? other : mx;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (m_fin) atomicAdd(&info[0], (unsigned long long)(__popcll(m_fin) + __popcll(m_fin & m_off)));
-        if (m_non) atomicAdd(&info[1], (unsigned long long)(__popcll(m_non) + __popcll(m_non & m_off)));
-        if (m_frac) atomicAdd(&info[2], (unsigned long long)(__popcll(m_frac) + __popcll(m_frac & m_off)));
-        if (m_neg) atomicAdd(&info[3], (unsigned long long)(__popcll(m_neg) + __popcll(m_neg & m_off)));
-        if (mx) atomicMax(vmax_bits, mx);
+    __shared__ unsigned long long part[4][6];
+    unsigned long long v6[6] = {n_fin, n_non, n_frac, n_neg, n_bad, mx};
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(v6[k], o);
+            v6[k] = k == 5 ? (other > v6[k] ? other : v6[k]) : v6[k] + other;
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 6; k++) part[threadIdx.x >> 6][k] = v6[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        unsigned long long t = part[0][k];
+        for (int w = 1; w < 4; w++) t = k == 5 ? (part[w][k] > t ? part[w][k] : t) : t + part[w][k];
+        if (t) {
+            if (k < 4) atomicAdd(&info[k], t);
+            else if (k == 4) atomicAdd(bad_order, t);
+            else atomicMax(vmax_bits, t);
+        }
     }
 }
 
@@ -558,7 +568,8 @@ int pk_launch_csr_info(pk_device_ctx *ctx, const int32_t *d_indptr, const int32_
     PK_HIP(hipMemsetAsync(d_valid_raw, 0, (size_t)n, ctx->stream));
     PK_HIP(hipMemsetAsync(d_valid_bal, 0, (size_t)n, ctx->stream));
     if (nnz > 0) {
-        hipLaunchKernelGGL(csr_info_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, ctx->stream,
+        const int64_t blocks = (nnz + 255) / 256;
+        hipLaunchKernelGGL(csr_info_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, ctx->stream,
                            d_indptr, d_indices, d_data, nnz, n, d_info6, d_info6 + 4, d_valid_raw,
                            d_valid_bal, d_bias, upper, d_info6 + 5);
         PK_HIP(hipGetLastError());
