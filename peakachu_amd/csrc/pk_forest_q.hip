@@ -990,7 +990,14 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 #endif
             const bool undecided = !PRUNE || (owner && *LDS_AT(lds_i32, dec_off + 4 * (tid & (C - 1))) == 0);
             if (owner && active && undecided) {
-                for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
+                // tree order (sklearn's sequential sum).  The group's parked values are read TOGETHER and then
+                // added in order -- a slot without a tree adds +0.0, and x + 0.0 == x for the never-negative
+                // sum.  (Rounds 2-4: a loop over the group's trees, every add behind its own LDS round trip.)
+                double pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) pv[j] = *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc += (j < gt) ? pv[j] : 0.0;
                 if (PRUNE) {
                     // every remaining tree adds at most 1.0: if even that cannot lift the sum to thre*T
                     // (1e-12 covers the rounding of at most T additions) the pixel is not reported
@@ -1280,8 +1287,23 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
                 if (half == 0 && g + 1 < n_grp && pf_late) {  // the walkers' loads: in flight during the
                     Q2_PF6(Q2_PL_LOAD)                          // exchange and the second walk
                 }
-                if (active && (tid >> 6) == cur)  // tree order: sklearn's sequential float64 sum
-                    for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * 64 + (tid & 63)) * 8);
+                if (active && (tid >> 6) == cur) {  // tree order: sklearn's sequential float64 sum
+                    // Eight parked values are read at once, then added in order (a slot without a tree adds
+                    // +0.0: the sum is never negative, so x + 0.0 == x bit for bit).  Round 5: as a loop over
+                    // the group's trees every add waited for its own LDS read -- 14 round trips, ~900 cycles
+                    // per tile and group during which fifteen waves stood at the barrier
+                    // (profiles/r05_stamps_w11_fitted.log); now two.
+#pragma unroll
+                    for (int j0 = 0; j0 < 16; j0 += 8) {
+                        if (j0 < gt) {
+                            double pv[8];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) pv[j] = *LDS_AT(lds_f64, val_off + ((j0 + j) * 64 + (tid & 63)) * 8);
+#pragma unroll
+                            for (int j = 0; j < 8; j++) acc += (j0 + j < gt) ? pv[j] : 0.0;
+                        }
+                    }
+                }
                 if (half == 0) {
                     if (has_b) {  // exchange the tiles: this thread's units of the one in LDS against its spare
 #define Q2_SWAP_RD(k) v4u t##k = tb##k; if (tid + (k) * THREADS < upt) t##k = *LDS_AT(lds_u4, (tid + (k) * THREADS) << 4);
