@@ -159,6 +159,10 @@ class CoolFile:
         nothing cached -- `Chromosome.from_upper` has the device do both from one upload."""
         from .utils import UpperPixels
         lo, hi = self.extent(chrom)
+        if self._bin1_offset is None:
+            self._bin1_offset = self._g["indexes/bin1_offset"].read().astype(np.int64)
+        if int(self._bin1_offset[hi] - self._bin1_offset[lo]) >= 2 ** 31 - 1:
+            raise OverflowError("%s holds more than 2^31 pixels in its rows" % chrom)  # (32-bit row pointers on the device)
         with self._pixel_lock:
             self.pixel_reads += 1
         return UpperPixels(hi - lo, *self._read_upper(lo, hi))

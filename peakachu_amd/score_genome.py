@@ -31,8 +31,13 @@ def fetch_inputs(Lib, key, correct):
     upper triangle, no mirroring, no balancing) does so, and the device mirrors and balances
     (scoreUtils.Chromosome.from_upper); PK_UPPER=0 keeps the host matrices of the reference."""
     if hasattr(Lib, "upper") and os.environ.get("PK_UPPER", "1") != "0":
-        bias, column = Lib.bias(correct, key) if correct else (None, None)
-        return UpperInputs(Lib.upper(key), bias, column)
+        try:
+            pixels = Lib.upper(key)
+        except OverflowError:
+            pixels = None   # (more pixels than the device path's 32-bit row pointers: the host matrices below)
+        if pixels is not None:
+            bias, column = Lib.bias(correct, key) if correct else (None, None)
+            return UpperInputs(pixels, bias, column)
     if correct:
         # the built-in reader keeps the chromosome's pixels for the second fetch (cooler has
         # no such notion: nullcontext)

@@ -144,3 +144,29 @@ def test_a_pixel_table_out_of_order_is_mirrored_on_the_host(hip_lib):
     raw = px.symmetric()
     B = scoreUtils.Chromosome(raw, model, raw_M=raw, weights=None, **kw)
     assert _same_chromosome(A, B) > 10
+
+
+@pytest.mark.parametrize("n", [4, 13, 14, 40])
+def test_tiny_chromosomes_from_the_pixel_table(hip_lib, n):
+    """Chromosomes too short for a window (n <= 2w: the reference clamps `upper` below `lower` and finds
+    no candidate) and barely long enough: the pixel-table constructor takes the same way out as the
+    matrix constructor (host path where the device path does not apply)."""
+    import numpy as np
+    from peakachu_amd import scoreUtils, synth, utils
+    from peakachu_amd.forest import load_model
+    cnt = synth.band_counts(n, min(n - 1, 20), seed=n)
+    i, d = np.nonzero(cnt)
+    indptr = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(i, minlength=n), out=indptr[1:])
+    px = utils.UpperPixels(n, indptr.astype(np.int32), (i + d).astype(np.int32), cnt[i, d].astype(np.int32))
+    model = load_model(MODEL)
+    kw = dict(lower=6, upper=300, cname="chrT", res=10000, width=6)
+    raw = px.symmetric()
+    try:
+        B = scoreUtils.Chromosome(raw, model, raw_M=raw, weights=None, **kw)
+    except Exception as e:   # what the reference's arithmetic does with such a map, the other constructor does too
+        with pytest.raises(type(e)):
+            scoreUtils.Chromosome.from_upper(px, model, **kw)
+        return
+    A = scoreUtils.Chromosome.from_upper(px, model, **kw)
+    _same_chromosome(A, B)
