@@ -47,6 +47,33 @@ def own_alg_bytes(kernel, F):
     return {"extract": 12 * F + 8, "forest": 4 * F + 8}.get(kernel)
 
 
+KCLASSES = ("extract", "quant", "forest", "forest_tail", "compact")
+
+
+def kernel_times(_lib):
+    """The library's HIP-event times per kernel class: (ms, launches).  `forest` brackets the forest
+    stage of a launch; when the forest is cut in two (pk_forest_q.hip) that is the head kernel, the gap
+    and the tail kernel, and `forest_tail` is the tail kernel alone -- `forest_head` = the difference is
+    what the dominant KERNEL took (rocprofv3's forest_qr_kernel<.., 1>)."""
+    k = {c: _lib.prof_get(c) for c in KCLASSES}
+    k["forest_head"] = (k["forest"][0] - k["forest_tail"][0], k["forest"][1])
+    return k
+
+
+def cut_info(hf, steps_since_reset=1):
+    """How the last call's forest launches were cut (read-only options of the forest handle)."""
+    g = int(hf.get_option("stat_split_group"))
+    if g <= 0:
+        return None
+    return {"group": g, "of_groups": int(hf.get_option("stat_q_groups")), "trees_in_front": int(hf.get_option("stat_split_trees")),
+            "parked_slots_last_call": int(hf.get_option("stat_split_parked")),
+            "note": "the forest kernel runs in two launches: the head walks the trees in front of the cut over every "
+                    "candidate and parks those whose sum plus 1.0 per remaining tree could still exceed thre x T "
+                    "(partial sum, rank codes), the tail walks the rest over the parked ones only and continues "
+                    "their sums in tree order; decided candidates are reported at probability 0 (pk_cands_set_prune: "
+                    "the permission Chromosome.score gives); same scored pixels, bit for bit"}
+
+
 def build_workload(seed, n, band, w, lower, upper, with_matrix=False):
     """(band-filtered matrix, expected curve, candidate coordinates, clamped upper[, the
     unfiltered matrix]) of one synthetic chromosome."""
@@ -255,6 +282,7 @@ def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, step
                         device=dev)
     hf = _lib.HipForest(fo, device=dev)
     cd = _lib.HipCands(x, y, device=dev)
+    cd.set_prune(True)   # as Chromosome.score runs its lists
     try:
         cd.run(hm, hf, w, thre, batch)
         L.pk_prof_enable(1)
@@ -266,12 +294,13 @@ def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, step
         _lib.check(L.pk_device_synchronize(dev), "sync")
         el = time.perf_counter() - t0
         L.pk_prof_enable(0)
-        kern = {k: _lib.prof_get(k) for k in ("extract", "quant", "forest", "compact")}
+        kern = kernel_times(_lib)
+        cut = cut_info(hf)
     finally:
         cd.close(); hf.close(); hm.close()
     value = x.size * steps / el
     dom = max(("extract", "quant", "forest"), key=lambda k: kern[k][0])
-    dom_ms, dom_n = kern[dom]
+    dom_ms, dom_n = kern["forest_head" if dom == "forest" else dom]
     achieved = float(x.size) * steps * b_alg(F) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic = issue = lds = None
     if pmc_file and dom_n:
@@ -281,9 +310,10 @@ def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, step
                 name, n, n, band, w, fo.T, " (untrained random trees)" if (forest_spec or "").startswith("random:")
                 else " (fitted: %.0f nodes per tree)" % fst["nodes_per_tree_mean"]),
             "value": value, "unit": "candidates/s", "steps": steps, "ms_per_step": el / steps * 1e3,
-            "candidates": int(x.size), "scored_pixels": int(n_out),
+            "candidates": int(x.size), "scored_pixels": int(n_out), "early_exit_allowed": True, "forest_cut": cut,
             "kernel_ms_per_step": {k: v[0] / steps for k, v in kern.items()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": dom + (" (head of the cut forest)" if (cut and dom == "forest") else ""),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "alg_bytes_per_candidate": b_alg(F),
                          "avg_launch_ms": dom_ms / dom_n if dom_n else None, "launches": dom_n,
@@ -311,7 +341,7 @@ def _timed_runs(L, dev, cd, hm, hf, w, thre, batch, reps):
     _lib.check(L.pk_device_synchronize(dev), "sync")
     el = time.perf_counter() - t0
     L.pk_prof_enable(0)
-    kern = {k: _lib.prof_get(k)[0] / reps * 1e3 for k in ("extract", "quant", "forest", "compact")}
+    kern = {k: _lib.prof_get(k)[0] / reps * 1e3 for k in KCLASSES}
     return el / reps * 1e6, kern, int(n_out)
 
 
@@ -496,7 +526,7 @@ def main():
     cd = _lib.HipCands(x, y, device=dev)
     # what ships: Chromosome.score ALLOWS the exact early exit on its candidate list
     # (peakachu_amd/scoreUtils.py: cd.set_prune(True)) and the library applies it where it pays
-    # (thre >= 0.55 on long lists; at the default 0.5 it does not: pk_api.hip score_run_impl);
+    # (long launches: the forest cut in two at a tree-group boundary, pk_forest_q.hip q_pick_cut);
     # --full-evaluation withdraws the permission
     cd.set_prune(not a.full_evaluation)
     _lib.check(L.pk_device_synchronize(dev), "sync")
@@ -594,7 +624,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     L.pk_prof_enable(0)
-    kern = {k: _lib.prof_get(k) for k in ("extract", "quant", "forest", "compact")}
+    kern = kernel_times(_lib)
+    cut = cut_info(hf)
     run_ms, gather_ms = t_run[0] / a.steps * 1e3, t_gather[0] / a.steps * 1e3
     gpu_pixels = cd.fetch() if world == 1 else None
     # untimed: the timed region can be a fraction of a second (the driver fixes --steps), too
@@ -606,11 +637,12 @@ def main():
             cd.run(hm, hf, w, a.thre, a.batch)
             busy_steps += 1
 
-    # extra, not the headline: the same pass with the exact early exit FORCED (option early_exit = 1;
-    # the headline leaves the decision to the library, which at this threshold does not prune)
-    early = None
-    if world == 1:
-        cd.set_option("early_exit", 1)
+    # extra, not the headline: the same pass WITHOUT the permission to leave decided candidates at
+    # probability 0 -- every candidate's complete probability, one forest launch per chunk (the headline
+    # of rounds 1-4, and what pk_score_fetch_all's callers get)
+    full = None
+    if world == 1 and not a.full_evaluation:
+        cd.set_prune(False)
         step()
         sync()
         e_steps = min(a.steps, 20)
@@ -618,17 +650,21 @@ def main():
         L.pk_prof_reset()
         t0 = time.perf_counter()
         for _ in range(e_steps):
-            n_early = step()
+            n_full = step()
         sync()
         e_el = time.perf_counter() - t0
         L.pk_prof_enable(0)
         e_forest = _lib.prof_get("forest")
-        cd.set_option("early_exit", 0)
-        early = {"value": int(x.size) * e_steps / e_el, "ms_per_step": e_el / e_steps * 1e3, "steps": e_steps,
-                 "forest_avg_launch_ms": e_forest[0] / e_forest[1] if e_forest[1] else None,
-                 "scored_pixels": int(n_early), "same_pixels_as_headline": bool(n_early == n_out),
-                 "note": "the headline's pass with the exact early exit FORCED at threshold %g (the library applies "
-                         "it by itself from 0.55 on long lists: profiles/r05_prune_ab.log)" % a.thre}
+        cd.set_prune(True)
+        f_avg = e_forest[0] / e_forest[1] if e_forest[1] else None
+        full = {"value": int(x.size) * e_steps / e_el, "ms_per_step": e_el / e_steps * 1e3, "steps": e_steps,
+                "forest_avg_launch_ms": f_avg, "forest_ms_per_step": e_forest[0] / e_steps,
+                "roofline_frac_dominant_kernel": (float(x.size) * e_steps * b_alg(F) / (e_forest[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                  if e_forest[0] > 0 else None),
+                "whole_path_frac": int(x.size) * e_steps / e_el * b_alg(F) / 1e9 / HBM_PEAK_GBS,
+                "scored_pixels": int(n_full), "same_pixels_as_headline": bool(n_full == n_out),
+                "note": "the headline's pass without pk_cands_set_prune: every candidate's complete probability "
+                        "(forest_qr_kernel<.., 0>, one launch per chunk); threshold %g" % a.thre}
 
     # extra, not the headline: SURVEY.md 8d's literal metric -- the same steps through
     # pk_score with HOST coordinate / result buffers (H2D of the candidates and D2H of the
@@ -728,7 +764,7 @@ def main():
         value = n_total * a.steps / elapsed
         # dominant kernel = the class with the most device time on rank 0
         dom = max(("extract", "quant", "forest"), key=lambda k: kern[k][0])
-        dom_ms, dom_n = kern[dom]
+        dom_ms, dom_n = kern["forest_head" if dom == "forest" else dom]
         alg_bytes_total = float(n_local) * a.steps * b_alg(F)
         achieved = alg_bytes_total / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         own = own_alg_bytes(dom, F)
@@ -765,8 +801,9 @@ def main():
                                "all" if a.stride == 1 else "every %d-th of the" % a.stride,
                                max(6, w + 1), upper,
                                ("without permission to stop early (every candidate's complete probability)" if a.full_evaluation
-                                else "AS Chromosome.score runs it: the exact early exit allowed, which the library "
-                                     "applies from thresholds of 0.55 on (not at this one; forced_early_exit = forced)"),
+                                else "AS Chromosome.score runs it: decided candidates may end at probability 0 "
+                                     "(pk_cands_set_prune), which lets the library cut the forest in two -- see "
+                                     "forest_cut; full_evaluation = the same pass without the permission"),
                                "" if world == 1 else
                                ("; strong scaling: every rank holds chromosome seed 0" if strong else
                                 "; weak scaling: rank r scores its own synthetic chromosome, seed = r "
@@ -789,7 +826,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": dom,
+                "kernel": dom + (" (forest_qr_kernel<..,1>: the head of the cut forest, %d of %d tree groups over every "
+                                 "candidate; the tail -- forest_tail in kernel_ms_per_step -- is a launch of its own)"
+                                 % (cut["group"], cut["of_groups"]) if (cut and dom == "forest") else ""),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -813,6 +852,7 @@ def main():
             # SURVEY 8d's definition: candidates/s x B_alg / peak (per GPU) -- the WHOLE path, not one kernel
             "roofline_whole_path_frac": value / world * b_alg(F) / 1e9 / HBM_PEAK_GBS,
             "early_exit_allowed": not a.full_evaluation,
+            "forest_cut": cut,
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kern.items()},
             "whole_path_alg_GBs": value * b_alg(F) / 1e9,
             "upload_s": upload_s,
@@ -827,8 +867,8 @@ def main():
             out["pcie_inclusive"] = pcie
         if strong_check is not None:
             out["strong_check"] = strong_check
-        if early is not None:
-            out["forced_early_exit"] = early
+        if full is not None:
+            out["full_evaluation"] = full
         if regime is not None:
             out["real_regime"] = regime
         if world > 1:

@@ -57,8 +57,8 @@ struct prof_rec {
 };
 static std::atomic<bool> g_prof_on{false};
 static std::vector<prof_rec> g_prof_pending;
-static double g_prof_ms[PK_K_NCLASS] = {0, 0, 0, 0, 0};
-static int64_t g_prof_n[PK_K_NCLASS] = {0, 0, 0, 0, 0};
+static double g_prof_ms[PK_K_NCLASS] = {0, 0, 0, 0, 0, 0};
+static int64_t g_prof_n[PK_K_NCLASS] = {0, 0, 0, 0, 0, 0};
 
 pk_prof_scope::pk_prof_scope(pk_device_ctx *c, pk_kclass kk, hipStream_t s)
     : ctx(c), k(kk), st(s ? s : c->stream)
@@ -313,6 +313,17 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
         o.forest_q_wpt = value;
     } else if (!strcmp(name, "forest_img")) {
         o.forest_img = value != 0;
+    } else if (!strcmp(name, "forest_split")) {
+        o.forest_split = value != 0;
+    } else if (!strcmp(name, "forest_split_at")) {
+        if (value < 0) return PK_E_INVALID;
+        o.forest_split_at = value;
+    } else if (!strcmp(name, "forest_split_frac")) {
+        if (value < 0 || value > 1000) return PK_E_INVALID;
+        o.forest_split_frac = value;
+    } else if (!strcmp(name, "forest_split_min")) {
+        if (value < 1) return PK_E_INVALID;
+        o.forest_split_min = value;
     } else {
         pk_set_error("unknown option '%s'", name);
         return PK_E_INVALID;
@@ -346,6 +357,10 @@ static int64_t opt_read(const pk_options &o, const char *name)
     if (!strcmp(name, "forest_q_rsv")) return o.forest_q_rsv;
     if (!strcmp(name, "forest_dbg")) return o.forest_dbg;
     if (!strcmp(name, "forest_q_early")) return o.forest_q_early;
+    if (!strcmp(name, "forest_split")) return o.forest_split;
+    if (!strcmp(name, "forest_split_at")) return o.forest_split_at;
+    if (!strcmp(name, "forest_split_frac")) return o.forest_split_frac;
+    if (!strcmp(name, "forest_split_min")) return o.forest_split_min;
     return -1;
 }
 
@@ -378,6 +393,24 @@ extern "C" int64_t pk_forest_get_option(pk_forest *f, const char *name)
     if (!strcmp(name, "stat_q_rows")) return f->q_state == 1 ? f->q_F : -1;
     if (!strcmp(name, "stat_q_shape")) return f->q_state == 1 ? f->q_ch : -1;
     if (!strcmp(name, "stat_q_trees")) return f->q_state == 1 ? f->q_T : -1;   // trees of the image (pieces count)
+    if (!strcmp(name, "stat_q_groups")) return f->q_state == 1 ? f->q_n_grp : -1;
+    // the cut forest: the group the last launch was cut in front of (0: one launch), the trees in front
+    // of it, and how many candidates the cut launches of the last scoring call on this device parked
+    if (!strcmp(name, "stat_split_group")) return f->last_cut;
+    if (!strcmp(name, "stat_split_trees"))
+        return f->last_cut > 0 && (size_t)f->last_cut * 4 < f->q_gtab_h.size() ? f->q_gtab_h[(size_t)f->last_cut * 4] : 0;
+    if (!strcmp(name, "stat_split_parked")) {
+        PK_DEV_LOCK(f->device);
+        pk_device_ctx *ctx = pk_ctx(f->device);
+        if (!ctx || !ctx->split_cnt || ctx->split_k <= 0) return 0;
+        std::vector<unsigned> h((size_t)ctx->split_k);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+            hipMemcpy(h.data(), ctx->split_cnt, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+        int64_t n = 0;
+        for (unsigned v : h) n += v;
+        return n;
+    }
     return opt_read(f->opt, name);
 }
 
@@ -439,7 +472,7 @@ extern "C" int pk_prof_reset(void)
 extern "C" int pk_prof_get(const char *name, double *ms_total, int64_t *launches)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    static const char *names[PK_K_NCLASS] = {"extract", "forest", "compact", "band", "quant"};
+    static const char *names[PK_K_NCLASS] = {"extract", "forest", "compact", "band", "quant", "forest_tail"};
     prof_drain();
     for (int i = 0; i < PK_K_NCLASS; i++)
         if (name && !strcmp(name, names[i])) {
@@ -1336,7 +1369,7 @@ static double tr_t0 = 0;
 #define PK_UPLOAD_GROWTH 5
 #endif
 static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands *cd, int w,
-                        double prune_sum)
+                        double prune_sum, double split_sum)
 {
     const int F = (2 * w + 1) * (2 * w + 1);
     const int blk = pk_forest_plan_blk(f);
@@ -1354,6 +1387,10 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     const bool overlap = cd->opt.overlap != 0;
     int rc = pk_ctx_reserve_tiles(ctx, (overlap ? 2 : 1) * tile_floats * sizeof(float));
     if (rc) return rc;
+    ctx->split_k = 0;  // (the cut forest's counters: one per launch of this call)
+    // the cut forest parks its candidates in the chunk's float tiles once they are quantized: not while
+    // the extractor of the next chunk may be writing a tile buffer beside the forest
+    if (overlap) split_sum = -INFINITY;
     if ((((w == 5 || w == 6) && m->opt.extract_pair) || (w == 11 && m->opt.extract_row16)) && m->opt.extract_clean) {
         rc = pk_matrix_prepare_norm(ctx, m);
         if (rc) return rc;
@@ -1448,7 +1485,9 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
                                        nullptr);
                 if (!rc) rc = pk_launch_quant_q(ctx, ctx->stream, f, tiles, s0 / 128, sn);
             }
-            if (!rc) rc = pk_launch_forest_q_walk(ctx, f, cd->status, c0, cn, cd->prob, prune_sum);
+            if (!rc)
+                rc = pk_launch_forest_q_walk(ctx, f, cd->status, c0, cn, cd->prob, prune_sum, split_sum, tiles,
+                                             tile_floats * sizeof(float));
             if (rc) return rc;
             if (stream_coords && c0 + cn < cd->N) {
                 rc = upload(c0 + cn, k + 1);
@@ -1463,7 +1502,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
             PK_HIP(hipEventRecord(ctx->ev_ext[buf], st_ext));
             PK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_ext[buf], 0));
         }
-        rc = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob, prune_sum);
+        rc = pk_launch_forest(ctx, f, tiles, blk, cd->status, c0, cn, cd->prob, prune_sum, split_sum);
         if (rc) return rc;
         if (overlap) PK_HIP(hipEventRecord(ctx->ev_for[buf], ctx->stream));
         if (stream_coords && c0 + cn < cd->N) {
@@ -1536,6 +1575,10 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
     // forest's time; a list of one or two tiles per workgroup never gains.  Only meaningful for thre >= 0.
     const bool prune_on = thre >= 0.0 && (cd->opt.early_exit || (cd->prune && thre >= 0.55 && cd->N >= (int64_t)1 << 19));
     const double prune_sum = prune_on ? thre * (double)f->T : -INFINITY;
+    // The same permission, per CANDIDATE: the default forest kernel can be cut in two at a tree-group
+    // boundary -- the head over everybody, the tail over the candidates whose sum could still exceed
+    // thre * T -- which pays from the default threshold on (pk_forest_q.hip, q_pick_cut; long launches only)
+    const double split_sum = thre >= 0.0 && (cd->opt.early_exit || cd->prune) ? thre * (double)f->T : -INFINITY;
     TR("run:enter");
     // A call that fails half-way may have left the record of an out-of-contract coordinate (word 65533
     // of the diagnostic buffer, coords_sanitize_kernel) behind: it belongs to THAT call and must not
@@ -1546,7 +1589,7 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
         hipMemset(ctx->dbg_buf + 65533, 0, sizeof(long long));
         return code;
     };
-    int rc = run_pipeline(ctx, m, f, cd, w, prune_sum);
+    int rc = run_pipeline(ctx, m, f, cd, w, prune_sum, split_sum);
     if (rc) return forget_offender(rc);
     TR("run:launched");
     rc = pk_launch_compact(ctx, m, cd, thre, batch);
@@ -1645,7 +1688,6 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
     bool deferred = false;
     if (cd && ctx->score_cands_cap >= N) {
         cd->N = N;
-        cd->prune = 0;
         // the coordinates travel chunk by chunk inside run_pipeline, behind the kernels
         cd->h_x = x;
         cd->h_y = y;
@@ -1663,6 +1705,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         ctx->score_cands_cap = N;
     }
     cd->opt = m->opt;  // (a call without a candidate handle: the matrix handle's pipeline options)
+    cd->prune = 1;     // pk_score hands back the scored pixels only: what a decided candidate's probability reads is invisible
     rc = score_run_impl(m, f, cd, w, thre, batch, n_out, true);
     if (deferred) {
         cd->h_x = cd->h_y = nullptr;  // borrowed for this call only

@@ -58,7 +58,11 @@ struct pk_device_ctx {
     // what a scoring call brings back in ONE copy into pinned memory: {n_out, three status words of
     // dbg_buf} and, for pk_score, the first PK_RET_INLINE scored pixels [x | y | p | signal]
     char *d_ret = nullptr, *h_ret = nullptr;
+    // the forest cut in two (pk_forest_q.hip): one counter of parked candidates per launch of a call
+    unsigned *split_cnt = nullptr;  // device [PK_SPLIT_SLOTS], zeroed at the first cut launch of a call
+    int split_k = 0;                // counters handed out in this call
 };
+#define PK_SPLIT_SLOTS 4096
 #define PK_RET_INLINE 8192
 #define PK_RET_BYTES (32 + (size_t)PK_RET_INLINE * 24)
 pk_device_ctx *pk_ctx(int device);  // lazily created; nullptr + error on failure
@@ -114,6 +118,14 @@ struct pk_options {
                                 // store rate and hold up the walkers' reads; kept as an experiment)
     int64_t forest_img = 1;     // LDS-image forest kernel (fixed-depth walks, absolute LDS addresses)
                                 // when every tree fits; 0 = the grouped preorder kernel
+    // the forest cut in two at a group boundary with a per-candidate compaction in between (runs that allow
+    // the exact early exit only; forest_qr_kernel only): 0 never, 1 where it pays (q_pick_cut)
+    int64_t forest_split = 1;
+    int64_t forest_split_at = 0;      // > 0: cut in front of this group whatever the threshold (tests, sweeps)
+    int64_t forest_split_frac = 200;  // per mille: cut at the first boundary where a partial sum of this share of
+                                      // the trees walked is already decided (config 2's background pixels sit at
+                                      // p ~ 0.10, 99 % below 0.26)
+    int64_t forest_split_min = 524288; // candidates per launch below which two launches cost more than they save
 };
 // one recursive lock per device (pk_api.hip, "Locks"); every entry point takes the lock of its handle's device
 #define PK_MAX_DEVICES 64
@@ -127,7 +139,7 @@ extern std::atomic<int64_t> g_stat_extract_clean, g_stat_extract_general;
 // ---------------------------------------------------------------- profiling
 // Brackets a kernel launch with HIP events on the library's stream when
 // profiling is enabled (pk_prof_enable); otherwise a no-op.
-enum pk_kclass { PK_K_EXTRACT = 0, PK_K_FOREST, PK_K_COMPACT, PK_K_BAND, PK_K_QUANT, PK_K_NCLASS };
+enum pk_kclass { PK_K_EXTRACT = 0, PK_K_FOREST, PK_K_COMPACT, PK_K_BAND, PK_K_QUANT, PK_K_FOREST_TAIL, PK_K_NCLASS };
 struct pk_prof_scope {
     pk_prof_scope(pk_device_ctx *ctx, pk_kclass k, hipStream_t st = nullptr);
     ~pk_prof_scope();
@@ -222,6 +234,8 @@ struct pk_forest {
     int32_t *q_gtab = nullptr, *q_ttab = nullptr, *q_off = nullptr;  // device
     float *q_thr = nullptr, *q_par = nullptr;                        // device
     uint32_t *q_lut = nullptr;                                       // device
+    std::vector<int32_t> q_gtab_h;  // host copy of q_gtab: where a cut may go (pk_forest_q.hip, q_pick_cut)
+    int last_cut = 0;               // group the last launch of forest_qr_kernel was cut in front of (0: one launch)
 };
 // ---- LDS-image forest (pk_image.hip builds it, pk_forest_img.hip walks it) ----
 struct pk_img_layout {
@@ -320,14 +334,17 @@ int pk_q_fixed_slots(const pk_q_out &out, int slots, pk_q_layout *L);
 int pk_q_max_tree_bytes(const pk_q_out &out);  // largest tree image, a multiple of 16  // (re)group the trees of `out` for a layout
 int pk_forest_q_plan(pk_forest *f);   // PK_OK when the rank image applies (built and uploaded)
 void pk_forest_q_release(pk_forest *f);
+// split_sum: -inf, or thre * T when the run allows decided candidates to end at probability 0 and the
+// float tiles may be overwritten once they are quantized (the cut forest parks its candidates there)
 int pk_launch_forest_q(pk_device_ctx *, pk_forest *f, const float *tiles, const uint8_t *d_status,
-                       int64_t c0, int64_t cn, double *d_prob, double prune_sum);
+                       int64_t c0, int64_t cn, double *d_prob, double prune_sum, double split_sum = -INFINITY);
 // the same in three steps (run_pipeline quantizes sub-chunk by sub-chunk from a cache-resident
 // float buffer and walks the whole chunk at once)
 int pk_forest_q_reserve(pk_device_ctx *, pk_forest *f, int64_t cn);
 int pk_launch_quant_q(pk_device_ctx *, hipStream_t st, pk_forest *f, const float *tiles, int64_t t0, int64_t cn);
 int pk_launch_forest_q_walk(pk_device_ctx *, pk_forest *f, const uint8_t *d_status, int64_t c0, int64_t cn,
-                            double *d_prob, double prune_sum);
+                            double *d_prob, double prune_sum, double split_sum = -INFINITY, void *scratch = nullptr,
+                            size_t scratch_bytes = 0);
 
 // (re)build f->grp for this launch shape; returns PK_OK or an error code
 int pk_forest_groups(pk_forest *f, int tree_words, int slots);
@@ -419,7 +436,7 @@ int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
 // are dropped early (grouped LDS kernel only; their reported probability is 0)
 int pk_launch_forest(pk_device_ctx *, pk_forest *, const float *tiles, int blk,
                      const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob,
-                     double prune_sum);
+                     double prune_sum, double split_sum = -INFINITY);
 // row-major float32 features [N][F] -> tiles (for pk_predict); status[i] = 1,
 // or 2 if row i holds a NaN
 int pk_launch_tile_rows(pk_device_ctx *, const float *d_rows, int64_t N, int F, float *tiles,

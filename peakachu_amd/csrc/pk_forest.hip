@@ -447,12 +447,12 @@ int pk_launch_tile_rows(pk_device_ctx *ctx, const float *d_rows, int64_t N, int 
 
 int pk_launch_forest(pk_device_ctx *ctx, pk_forest *f, const float *tiles, int blk,
                      const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob,
-                     double prune_sum)
+                     double prune_sum, double split_sum)
 {
     if (cn <= 0) return PK_OK;
     // pk_forest_plan_blk decided how this forest is evaluated (and which tile width that needs)
     if (f->plan_kind == 2 && blk == (f->q_ch == 1 ? 128 : 128 * PK_Q_FTILE) && f->q_state == 1)
-        return pk_launch_forest_q(ctx, f, tiles, d_status, c0, cn, d_prob, prune_sum);
+        return pk_launch_forest_q(ctx, f, tiles, d_status, c0, cn, d_prob, prune_sum, split_sum);
     if (f->plan_kind == 1 && blk == 64 && f->img_state == 1)
         return pk_launch_forest_img(ctx, f, tiles, d_status, c0, cn, d_prob, prune_sum);
     pk_prof_scope prof(ctx, PK_K_FOREST);

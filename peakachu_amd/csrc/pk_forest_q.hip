@@ -683,6 +683,17 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #define PK_QR_SPREAD 1             // issue slots per pair of levels from there on (0: all at once)
 #endif
 
+// A barrier that orders LDS accesses only.  __syncthreads() also waits for every global access of the wave
+// to be acknowledged (s_waitcnt vmcnt(0) in front of s_barrier): at the top of a tile that is the previous
+// tile's probability stores, which nobody in the workgroup reads -- thousands of cycles per tile.
+#ifndef PK_QR_RAWBAR
+#define PK_QR_RAWBAR 1
+#endif
+#if PK_QR_RAWBAR
+#define QR_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define QR_LDS_BARRIER() __syncthreads()
+#endif
 #define QR_LD_U(R, ptr) asm volatile("global_load_dwordx4 " R ", %0, %1" ::"v"(voff), "s"(ptr))
 // a row behind a test of its bit (the tile's rows, once per tile): the test is inside the assembly --
 // as a C++ `if` the compiler lays every conditional load out of line (two taken branches per load)
@@ -836,14 +847,27 @@ struct qr_args {
     double prune_sum;
     int opt, dbg;
     long long *stamps;
+    // the forest cut in two at a group boundary (SPLIT, see forest_qr_kernel):
+    // 1 = head: groups [0, n_grp) of the table handed in, then every candidate that is still OPEN (its sum
+    //     plus one per remaining tree could exceed prune_sum) is parked -- partial sum, status, index and
+    //     its column of rank codes, in tile format -- behind a device-side counter;
+    // 2 = tail: the remaining groups over the parked candidates (their number is read from the device),
+    //     sums continued in tree order, probabilities written back to the candidates' own places
+    unsigned *s_cnt;            // 1: slots handed out so far; 2: candidates of this launch
+    int32_t *s_idx;             // [slot] index of the candidate in its chunk
+    double *s_acc;              // [slot] partial sum of the head's trees, tree order
+    uint8_t *s_st;              // [slot] status byte
+    unsigned short *s_tiles;    // 1: rank tiles of the parked candidates, slot order
+    double split_rem;           // 1: trees (of the image) behind the cut
 };
 
 // the persistent loop of one wave role: X0 = LDS offset of its rank tile, POS = its position among
 // the four waves of its SIMD.  opt bits: 1 PREF0 (the last group of a tile also fetches the next
 // tile's first group: a tile change then has no exposed load)
-template <int HALF1, bool PRUNE, int NR, int X0, int POS>
+template <int HALF1, bool PRUNE, int NR, int X0, int POS, int SPLIT>
 __device__ __forceinline__ void qr_body(const qr_args &A)
 {
+    static_assert(SPLIT == 0 || !PRUNE, "the cut forest decides at the cut, not inside the kernel");
     constexpr int THREADS = Q_THREADS;
     constexpr int C = 256;
     constexpr int NCH = 2;  // walks per lane of one wave
@@ -851,7 +875,10 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
     const int n_grp = A.n_grp, T = A.T, F = A.F, dec_off = A.dec_off, val_off = A.val_off, img_off = A.img_off;
     const int dbg = A.dbg;
     [[maybe_unused]] long long *const stamps = A.stamps;  // (used by builds with -DPK_QR_STAMPS)
-    const int64_t c0 = A.c0, cn = A.cn;
+    const int64_t c0 = A.c0;
+    const int64_t sc0 = SPLIT == 2 ? 0 : c0;  // (the tail's status bytes are the parked ones, in slot order)
+    // (tail of a cut forest: as many candidates as the head parked)
+    const int64_t cn = SPLIT == 2 ? (int64_t)__builtin_amdgcn_readfirstlane((int)*A.s_cnt) : A.cn;
     const uint8_t *const status = A.status;
     const int HB = F * 256;  // bytes of a rank tile [F][64][2] u16
     const int upt = HB >> 4;
@@ -861,6 +888,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
     const int64_t n_wg = (cn + C - 1) / C;
     unsigned stc_n[NCH] = {}, st_n = 0;
     bool tile_ready = false;  // (uniform) the tile of this trip and its first tree group are in LDS already
+    [[maybe_unused]] unsigned pk_at = 0, pk_end = 0;  // SPLIT 1: the next free parking slot and the end of this workgroup's block
     for (int64_t wg = blockIdx.x; wg < n_wg; wg += gridDim.x) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));  // (see forest_q_kernel: keeps per-trip addresses inside the trip)
@@ -879,6 +907,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
         if (wg != (int64_t)blockIdx.x && !tile_ready) __syncthreads();  // nobody reads the previous trip's tile any more
         if (PRUNE)
             for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
+        if (SPLIT == 1 && wg == (int64_t)blockIdx.x && tid == 0) *LDS_AT(lds_i32, dec_off + 4 * 256) = 0;  // parked in this tile
         const int64_t cbase = wg * C;
         int4 g_cur = A.gtab[0];
         int4 tt = A.ttab[min(g_cur.x + slot, T - 1)];  // this wave's tree: offset, depth, root word, units
@@ -903,7 +932,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int64_t loc = cbase + lane + 64 * (NCH * sub + c);
-            stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[c0 + loc] : 0);
+            stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[sc0 + loc] : 0);
             act[c] = stc[c] != 0 && lds_ok;
             any_nan = any_nan || stc[c] == 2;
         }
@@ -911,7 +940,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
         const bool owner = tid < C;
         const int64_t local = cbase + tid;
         const bool valid = owner && local < cn;
-        const unsigned st = tile_ready ? st_n : (valid ? status[c0 + local] : 0);
+        const unsigned st = tile_ready ? st_n : (valid ? status[sc0 + local] : 0);
         const bool active = st != 0 && lds_ok;
         const int64_t wg_next = wg + gridDim.x;
         bool fetched = false;
@@ -930,6 +959,8 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 #define QR_STAMP(slot_) do {} while (0)
 #endif
         double acc = 0.0;
+        if constexpr (SPLIT == 2)
+            if (valid) acc = A.s_acc[local];  // the head's trees, already added in order
         for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
             const int t0 = g_cur.x, gt = g_cur.y;
             const int4 g_nxt = A.gtab[g + 1];
@@ -948,9 +979,9 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     const int64_t loc = cb + lane + 64 * (NCH * sub + c);
-                    stc_n[c] = loc < cn ? status[c0 + loc] : 0;
+                    stc_n[c] = loc < cn ? status[sc0 + loc] : 0;
                 }
-                st_n = (owner && cb + tid < cn) ? status[c0 + cb + tid] : 0;
+                st_n = (owner && cb + tid < cn) ? status[sc0 + cb + tid] : 0;
                 fetched = true;
                 qr_issue_tile((rows | (cb + 128 < cn ? rows << 3 : 0u)) << 8, tb0, tb0 + HB, voff);
             }
@@ -1040,7 +1071,82 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 #define QR_TSTAMP(k_) do {} while (0)
 #endif
         QR_TSTAMP(0);
-        if (valid) A.prob[c0 + local] = active ? acc / (double)A.t_div : 0.0;
+        if constexpr (SPLIT == 1) {
+            // The cut.  A candidate whose sum cannot reach prune_sum even if every tree behind the cut adds
+            // 1.0 is decided (the rule of the PRUNE instantiations; its reported probability is 0); the others
+            // are parked for the tail: partial sum, status, index and their column of rank codes, in tile
+            // format.  Slot order changes no bit of the result: every candidate is scored on its own.
+            //  * The tile's open candidates are listed in LDS (the early-exit flags' place: this instantiation
+            //    has no in-kernel exit); behind a barrier ALL sixteen waves copy the codes -- lanes = parked
+            //    candidates (different columns of the tile: different banks), a wave takes every sixteenth
+            //    row.  (First version: the four owner waves, lanes = rows.  A column of the [row][64][2] tile
+            //    lies in ONE bank: 64-way conflicts, 1 us per parked candidate.)
+            //  * Slots come in blocks of 256 that the workgroup reserves with one atomic (an atomic per tile
+            //    and wave -- 87 000 on one address per launch -- costs 1-2 us under its own contention); what
+            //    a tile parks beyond the end of the block goes to the front of the next one, and what is left
+            //    of the last block at the end of the kernel gets status 0 (nobody).
+            //  * The barriers order LDS only: __syncthreads() would also wait for the acknowledgement of this
+            //    tile's global stores (4 000 cycles per tile, measured), which nobody in the workgroup reads.
+            const unsigned pk_list = (unsigned)dec_off, pk_cnt = pk_list + 4u * 256u, pk_new = pk_cnt + 4u;
+            bool decided = false, open = false;
+            unsigned my_i = 0;
+#ifndef PK_CUT_ABLATE
+#define PK_CUT_ABLATE 0   // timing ablations (WRONG results): 1 nobody is parked (body compiled out), 2 ... at run time
+#endif
+            if (owner && PK_CUT_ABLATE != 1 && !(PK_CUT_ABLATE == 2 && !(dbg & 64))) {  // (waves 0-3, whole waves)
+                open = valid && active && !((acc + A.split_rem) * (1.0 + 1e-12) < A.prune_sum);
+                decided = valid && !open;
+                const unsigned long long m = __ballot(open);
+                if (m != 0ull) {
+                    unsigned pos = 0;
+                    if (lane == 0) pos = __hip_atomic_fetch_add(LDS_AT(lds_i32, pk_cnt), (int)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+                    my_i = pos + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (open) *LDS_AT(lds_i32, pk_list + 4u * my_i) = tid;  // its place in the 256-candidate tile
+                }
+            }
+            QR_LDS_BARRIER();  // list and count are published
+            const unsigned P = PK_CUT_ABLATE == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_cnt));
+            if (P != 0u) {  // (uniform)
+                const unsigned room = pk_end - pk_at;
+                unsigned new_base = 0;
+                if (P > room) {  // (uniform) a new block; the workgroup waits for ONE atomic, every ~25 tiles
+                    if (tid == 0) *LDS_AT(lds_i32, pk_new) = (int)atomicAdd(A.s_cnt, 256u);
+                    QR_LDS_BARRIER();
+                    new_base = (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_new));
+                }
+                if (open) {
+                    const unsigned s = my_i < room ? pk_at + my_i : new_base + (my_i - room);
+                    A.s_idx[s] = (int32_t)local;
+                    A.s_acc[s] = acc;
+                    A.s_st[s] = (uint8_t)st;
+                }
+                for (unsigned i0 = 0; i0 < P; i0 += 64u) {
+                    const unsigned i = i0 + (unsigned)lane;
+                    if (i < P) {
+                        const int cand = *LDS_AT(const lds_i32, pk_list + 4u * i);
+                        const unsigned s = i < room ? pk_at + i : new_base + (i - room);
+                        const unsigned src = (cand >= 128 ? (unsigned)HALF1 : 0u) + ((unsigned)(cand & 63) << 2) +
+                                             ((unsigned)((cand >> 6) & 1) << 1);
+                        unsigned short *dst = A.s_tiles + (size_t)(s >> 7) * (size_t)F * 128u + ((s & 63u) << 1) + ((s >> 6) & 1u);
+                        for (int r = wave; r < F; r += 16) dst[(size_t)r * 128u] = *LDS_AT(const lds_u16, src + (unsigned)r * 256u);
+                    }
+                }
+                if (P > room) {
+                    pk_at = new_base + (P - room);
+                    pk_end = new_base + 256u;
+                } else {
+                    pk_at += P;
+                }
+            }
+            QR_LDS_BARRIER();  // the codes are read: the next tile may be stored over this one
+            if (tid == 0) *LDS_AT(lds_i32, pk_cnt) = 0;  // (everybody has read it; the next tile adds to it many barriers later)
+            if (decided) A.prob[c0 + local] = 0.0;
+        } else if constexpr (SPLIT == 2) {
+            if (valid && active) A.prob[c0 + A.s_idx[local]] = acc / (double)A.t_div;  // (status 0: a slot nobody took)
+        } else {
+            if (valid) A.prob[c0 + local] = active ? acc / (double)A.t_div : 0.0;
+        }
         // the next tile and (PREF0) its first group: every walk of this tile is behind barrier 1 of
         // the last group and the sums are done, so its rank tiles and trees can go
         const bool grp0_here = fetched && pref0;
@@ -1064,16 +1170,26 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
         }
         QR_TSTAMP(3);
     }
+    if constexpr (SPLIT == 1)  // what is left of the last block: nobody
+        for (unsigned i = pk_at + threadIdx.x; i < pk_end; i += THREADS) A.s_st[i] = 0;
 #undef QR_TSTAMP
 #undef QR_STAMP
 }
 
-template <int HALF1, bool PRUNE, int NR>
+struct qr_split_args {
+    unsigned *cnt;
+    int32_t *idx;
+    double *acc;
+    uint8_t *st;
+    unsigned short *tiles;
+    double rem;
+};
+template <int HALF1, bool PRUNE, int NR, int SPLIT>
 __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGPRS))) void forest_qr_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
     int t_div, int F, int dec_off, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
     const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob, double prune_sum,
-    int opt, int dbg, long long *__restrict__ stamps)
+    int opt, int dbg, long long *__restrict__ stamps, qr_split_args sp)
 {
     // v72..v127 belong to the inline assembly (the register count of the kernel covers them)
     asm volatile("" ::: "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83",
@@ -1104,17 +1220,23 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
     A.opt = lds_at_zero ? (opt & 0x7fffffff) : -1;
     A.dbg = dbg;
     A.stamps = stamps;
+    A.s_cnt = sp.cnt;
+    A.s_idx = sp.idx;
+    A.s_acc = sp.acc;
+    A.s_st = sp.st;
+    A.s_tiles = sp.tiles;
+    A.split_rem = sp.rem;
     // the role of this wave, once: rank tile = wave & 1, position among the waves of its SIMD = wave >> 2
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (((wave >> 2) << 1) | (wave & 1)) {
-    case 0: qr_body<HALF1, PRUNE, NR, 0, 0>(A); break;
-    case 1: qr_body<HALF1, PRUNE, NR, HALF1, 0>(A); break;
-    case 2: qr_body<HALF1, PRUNE, NR, 0, 1>(A); break;
-    case 3: qr_body<HALF1, PRUNE, NR, HALF1, 1>(A); break;
-    case 4: qr_body<HALF1, PRUNE, NR, 0, 2>(A); break;
-    case 5: qr_body<HALF1, PRUNE, NR, HALF1, 2>(A); break;
-    case 6: qr_body<HALF1, PRUNE, NR, 0, 3>(A); break;
-    default: qr_body<HALF1, PRUNE, NR, HALF1, 3>(A); break;
+    case 0: qr_body<HALF1, PRUNE, NR, 0, 0, SPLIT>(A); break;
+    case 1: qr_body<HALF1, PRUNE, NR, HALF1, 0, SPLIT>(A); break;
+    case 2: qr_body<HALF1, PRUNE, NR, 0, 1, SPLIT>(A); break;
+    case 3: qr_body<HALF1, PRUNE, NR, HALF1, 1, SPLIT>(A); break;
+    case 4: qr_body<HALF1, PRUNE, NR, 0, 2, SPLIT>(A); break;
+    case 5: qr_body<HALF1, PRUNE, NR, HALF1, 2, SPLIT>(A); break;
+    case 6: qr_body<HALF1, PRUNE, NR, 0, 3, SPLIT>(A); break;
+    default: qr_body<HALF1, PRUNE, NR, HALF1, 3, SPLIT>(A); break;
     }
 }
 
@@ -1373,6 +1495,7 @@ void q_free(pk_forest *f)
     f->q_lut = nullptr;
     delete f->q_layout;
     f->q_layout = nullptr;
+    f->q_gtab_h.clear();
 }
 
 template <typename V>
@@ -1507,6 +1630,7 @@ static int q_plan_build(pk_forest *f)
     rc = q_upload((void **)&f->q_img, best.pairs);
     if (!rc) rc = q_upload((void **)&f->q_src, best.qsrc);
     if (!rc) rc = q_upload((void **)&f->q_gtab, best.gtab);
+    f->q_gtab_h = best.gtab;
     if (!rc) rc = q_upload((void **)&f->q_ttab, best.ttab);
     if (!rc) rc = q_upload((void **)&f->q_off, best.qoff);
     if (!rc) rc = q_upload((void **)&f->q_thr, best.qthr);
@@ -1626,18 +1750,45 @@ int pk_launch_quant_q(pk_device_ctx *ctx, hipStream_t st, pk_forest *f, const fl
 }
 
 int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, const uint8_t *d_status,
-                       int64_t c0, int64_t cn, double *d_prob, double prune_sum)
+                       int64_t c0, int64_t cn, double *d_prob, double prune_sum, double split_sum)
 {
     if (cn <= 0) return PK_OK;
     int rc = pk_forest_q_reserve(ctx, f, cn);
     if (!rc) rc = pk_launch_quant_q(ctx, ctx->stream, f, tiles, 0, cn);
-    if (!rc) rc = pk_launch_forest_q_walk(ctx, f, d_status, c0, cn, d_prob, prune_sum);
+    // (behind the quantizer the float tiles of these candidates are dead: the cut forest's scratch)
+    const int64_t blk = f->q_ch == 1 ? 128 : 128 * PK_Q_FTILE;
+    if (!rc)
+        rc = pk_launch_forest_q_walk(ctx, f, d_status, c0, cn, d_prob, prune_sum, split_sum, const_cast<float *>(tiles),
+                                     (size_t)((cn + blk - 1) / blk * blk) * (size_t)f->F * sizeof(float));
     return rc;
 }
 
 // the walk over the rank tiles of candidates [c0, c0 + cn) (tile 0 = candidate c0)
+// The forest cut in two (round 5).  Measured potential on config 2 (tools/cut_potential.py, the oracle's
+// per-tree values of 153 546 candidates): at the default threshold 0.5 a candidate's fate is sealed after
+// ~60 of the 100 trees on average (its partial sum plus 1.0 per remaining tree can no longer exceed
+// thre * T), but a 256-candidate TILE -- the unit the in-kernel early exit works on -- only after ~80,
+// and leaving a tile early costs an exposed tile load: the in-kernel exit gains nothing below 0.55.  A
+// cut at a group boundary with a compaction behind it works per CANDIDATE: the head walks the first
+// `cut` groups over everybody, every candidate still open is parked (3.9 % of config 2's at 64 trees),
+// the tail walks the remaining groups over the parked ones only and continues their sums in tree order.
+// Returns the group to cut in front of (0: no cut): the first boundary behind which a candidate whose
+// partial sum is at most `forest_split_frac` per mille of the trees walked is decided.
+static int q_pick_cut(const pk_forest *f, double split_sum)
+{
+    if ((int)f->q_gtab_h.size() < 4 * (f->q_n_grp + 1)) return 0;
+    if (f->opt.forest_split_at > 0) return f->opt.forest_split_at < f->q_n_grp ? (int)f->opt.forest_split_at : 0;
+    const double frac = (double)f->opt.forest_split_frac * 1e-3;
+    for (int g = 1; g < f->q_n_grp; g++) {
+        const double done = (double)f->q_gtab_h[4 * (size_t)g];  // trees in front of group g
+        const double lim = split_sum - ((double)f->q_T - done);  // a sum up to here is decided
+        if (lim >= frac * done && lim > 0.0) return g;
+    }
+    return 0;
+}
+
 int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_status, int64_t c0, int64_t cn,
-                            double *d_prob, double prune_sum)
+                            double *d_prob, double prune_sum, double split_sum, void *scratch, size_t scratch_bytes)
 {
     if (cn <= 0) return PK_OK;
     if (f->q_state != 1 || !f->q_layout) {
@@ -1661,34 +1812,100 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     for (int i = 0; i < 16; i++) slots_at.off[i] = L.slot_off[i];
     // rows of 16 KiB of the largest group: forest_qr_kernel loads that many without looking
     const int rows = (f->q_max_group_bytes + 16383) / 16384;
+    f->last_cut = 0;
     if (L.ch == 4 && wpt2 && !early && (f->opt.forest_q_rsv & 1) && !(f->opt.forest_dbg & (8 | 32)) &&
         (L.half1 == 32768 || L.half1 == 49152) && rows <= 5) {
+        // the cut: allowed by the caller (split_sum = thre * T: the run may leave decided candidates at
+        // probability 0), worth two launches (forest_split_min candidates), room for the parked candidates
+        // (worst case: all of them) in the scratch the caller lends -- the chunk's dead float tiles
+        int cut = 0;
+        qr_split_args sp{};
+        unsigned grid_tail = 1;
+        if (split_sum > -1e300 && f->opt.forest_split && scratch && cn >= f->opt.forest_split_min &&
+            ctx->split_k < PK_SPLIT_SLOTS)
+            cut = q_pick_cut(f, split_sum);
+        if (cut > 0) {
+            auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            // (slots are handed out in blocks of 256 per workgroup: at most one unfinished block each)
+            const size_t cap = (size_t)cn + 256u * (size_t)grid + 256u;
+            const size_t tiles_b = up((cap + 127) / 128 * f->q_F * 128 * sizeof(unsigned short) + PK_Q_PAD_BYTES);
+            const size_t acc_b = up(cap * 8), idx_b = up(cap * 4), st_b = up(cap);
+            if (tiles_b + acc_b + idx_b + st_b > scratch_bytes) {
+                cut = 0;
+            } else {
+                if (!ctx->split_cnt) {
+                    PK_HIP(hipMalloc((void **)&ctx->split_cnt, PK_SPLIT_SLOTS * sizeof(unsigned)));
+                    ctx->split_k = 0;
+                }
+                if (ctx->split_k == 0)
+                    PK_HIP(hipMemsetAsync(ctx->split_cnt, 0, PK_SPLIT_SLOTS * sizeof(unsigned), ctx->stream));
+                char *b = static_cast<char *>(scratch);
+                sp.tiles = reinterpret_cast<unsigned short *>(b);
+                sp.acc = reinterpret_cast<double *>(b + tiles_b);
+                sp.idx = reinterpret_cast<int32_t *>(b + tiles_b + acc_b);
+                sp.st = reinterpret_cast<uint8_t *>(b + tiles_b + acc_b + idx_b);
+                sp.cnt = ctx->split_cnt + ctx->split_k++;
+                sp.rem = (double)f->q_T - (double)f->q_gtab_h[4 * (size_t)cut];
+                grid_tail = grid;
+            }
+        }
         // the default shape: staging registers outside the compiler's reach, loads from inside the walk
 #define QR_LAUNCH(HALF1, PRUNE, NR)                                                                        \
     do {                                                                                                   \
-        int rc__ = q_set_max_lds(forest_qr_kernel<HALF1, PRUNE, NR>, 163840);                              \
+        int rc__ = q_set_max_lds(forest_qr_kernel<HALF1, PRUNE, NR, 0>, 163840);                           \
         if (rc__) return rc__;                                                                             \
-        hipLaunchKernelGGL((forest_qr_kernel<HALF1, PRUNE, NR>), dim3(grid), dim3(Q_THREADS), 163840, ctx->stream, \
+        hipLaunchKernelGGL((forest_qr_kernel<HALF1, PRUNE, NR, 0>), dim3(grid), dim3(Q_THREADS), 163840, ctx->stream, \
                            reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab), \
                            f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.dec_off,   \
                            L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob, prune_sum,        \
-                           (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg, ctx->dbg_buf);          \
+                           (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg, ctx->dbg_buf, qr_split_args{}); \
     } while (0)
 #define QR_LAUNCH_NR(HALF1, PRUNE)                                  \
     do {                                                            \
         if (rows <= 4) QR_LAUNCH(HALF1, PRUNE, 4);                  \
         else QR_LAUNCH(HALF1, PRUNE, 5);                            \
     } while (0)
+        // the forest cut in two (see q_pick_cut): head over every candidate, tail over the parked ones
+#define QR_LAUNCH_CUT(HALF1, NR)                                                                           \
+    do {                                                                                                   \
+        int rc__ = q_set_max_lds(forest_qr_kernel<HALF1, false, NR, 1>, 163840);                           \
+        if (!rc__) rc__ = q_set_max_lds(forest_qr_kernel<HALF1, false, NR, 2>, 163840);                    \
+        if (rc__) return rc__;                                                                             \
+        hipLaunchKernelGGL((forest_qr_kernel<HALF1, false, NR, 1>), dim3(grid), dim3(Q_THREADS), 163840, ctx->stream, \
+                           reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab), \
+                           cut, reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.dec_off,  \
+                           L.val_off, L.img_off, ctx->q_tiles, d_status, c0, cn, d_prob, split_sum,        \
+                           (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg, ctx->dbg_buf, sp);      \
+        PK_HIP(hipGetLastError());                                                                         \
+        {                                                                                                  \
+            pk_prof_scope prof_tail(ctx, PK_K_FOREST_TAIL);                                                \
+            hipLaunchKernelGGL((forest_qr_kernel<HALF1, false, NR, 2>), dim3(grid_tail), dim3(Q_THREADS), 163840, ctx->stream, \
+                               reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab) + cut, \
+                               f->q_n_grp - cut, reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.dec_off, \
+                               L.val_off, L.img_off, sp.tiles, sp.st, c0, (int64_t)0, d_prob, split_sum,    \
+                               (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg, ctx->dbg_buf, sp);  \
+        }                                                                                                  \
+    } while (0)
         // forest_q_rsv bits: 1 on, 2 PREF0 (the next tile's first group prefetched with the tile)
         const bool prune = prune_sum > -1e300;
         f->last_family = 1;
-        if (L.half1 == 32768) {
+        f->last_cut = cut;
+        if (cut > 0) {
+            if (L.half1 == 32768) {
+                if (rows <= 4) QR_LAUNCH_CUT(32768, 4);
+                else QR_LAUNCH_CUT(32768, 5);
+            } else {
+                if (rows <= 4) QR_LAUNCH_CUT(49152, 4);
+                else QR_LAUNCH_CUT(49152, 5);
+            }
+        } else if (L.half1 == 32768) {
             if (prune) QR_LAUNCH_NR(32768, true);
             else QR_LAUNCH_NR(32768, false);
         } else {
             if (prune) QR_LAUNCH_NR(49152, true);
             else QR_LAUNCH_NR(49152, false);
         }
+#undef QR_LAUNCH_CUT
 #undef QR_LAUNCH_NR
 #undef QR_LAUNCH
     } else if (L.ch == 4 && L.half1 == 32768) {

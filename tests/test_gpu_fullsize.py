@@ -287,12 +287,13 @@ def test_early_exit_same_pixels(config2, thre):
         assert np.all(same) or thre > 0.0
 
 
-@pytest.mark.parametrize("thre,n,prunes", [(0.5, 1_500_000, False), (0.9, 1_500_000, True), (0.9, 300_000, False),
-                                           (0.6, 1_500_000, True)])
+@pytest.mark.parametrize("thre,n,prunes", [(0.5, 1_500_000, True), (0.9, 1_500_000, True), (0.9, 300_000, False),
+                                           (0.6, 1_500_000, True), (0.2, 1_500_000, False)])
 def test_permission_to_stop_early_is_used_where_it_pays(config2, thre, n, prunes):
     """pk_cands_set_prune ALLOWS the early exit (what Chromosome.score sets); the library applies it
-    from thresholds of 0.55 on lists of at least 2^19 candidates (profiles/r05_prune_ab.log: below
-    that it costs more than it saves).  The scored pixels never depend on it."""
+    where it pays: launches of at least 2^19 candidates are cut in two at a tree-group boundary (from
+    the default threshold 0.5 on: tools/cut_ab.py), shorter ones run whole (profiles/r05_prune_ab.log).
+    The scored pixels never depend on it."""
     c = config2
     w = c["w"]
     x, y = c["x"][:n], c["y"][:n]
@@ -309,6 +310,63 @@ def test_permission_to_stop_early_is_used_where_it_pays(config2, thre, n, prunes
     same = gio.bits(pr2) == gio.bits(pr)
     assert np.all(same | (pr2 == 0.0)) and np.all(pr[~same] <= thre)
     assert bool((~same).any()) == prunes
+
+
+@pytest.mark.parametrize("w,nan_diag", [(5, None), (5, 150), (6, None)])
+def test_cut_forest_scores_the_same_pixels(config2, w, nan_diag):
+    """The forest cut in two (pk_forest_q.hip: head over every candidate, the still-open ones parked with
+    their partial sums and rank codes, tail over the parked ones): whatever group it is cut in front of,
+    however many launches a call takes and whether candidates carry NaN features (status 2: the walk
+    with missing_go_to_left), the scored pixels are the one-launch kernel's bit for bit, a candidate's
+    probability is either that kernel's or -- decided at the cut -- 0, and only losers are decided."""
+    c = config2
+    M = c["Mf"]
+    e = c["e"] if w == 5 else utils.calculate_expected(M, 200 + 2 * w, raw=True)
+    if nan_diag is not None:   # a NaN expected value poisons every window that touches its diagonal
+        e = e.copy()
+        e[nan_diag] = np.nan
+    fo = c["fo"] if w == 5 else FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w%d_t100.npz" % w))
+    hm = _lib.HipMatrix(M.indptr, M.indices, M.data, M.shape[0], e, -2 * w + 1, 200 + 2 * w - 1)
+    hf = _lib.HipForest(fo)
+    n = 1_300_003
+    x, y = c["x"][-n:], c["y"][-n:]          # (the far diagonals: the poisoned one is among them)
+    thre = 0.5
+    cd = _lib.HipCands(x, y, options={"chunk": 500_000})
+    n1 = cd.run(hm, hf, w, thre)
+    base = digest(*cd.fetch())
+    st, pr = cd.fetch_all()
+    assert hf.get_option("stat_family") == 1 and hf.get_option("stat_split_group") == 0
+    if nan_diag is not None:
+        assert (st == 2).sum() > 10_000
+    n_grp = hf.get_option("stat_q_groups")
+    assert n_grp >= 8
+    hf.set_option("forest_split_min", 1)
+    parked = {}
+    late = n_grp * 3 // 4          # (three quarters of the trees walked: most candidates are decided at 0.5)
+    for at in (0, 1, late, n_grp - 1):
+        hf.set_option("forest_split_at", at)
+        cd2 = _lib.HipCands(x, y, options={"chunk": 500_000})
+        cd2.set_prune(True)
+        assert cd2.run(hm, hf, w, thre) == n1
+        assert digest(*cd2.fetch()) == base
+        st2, pr2 = cd2.fetch_all()
+        assert np.array_equal(st2, st)
+        same = gio.bits(pr2) == gio.bits(pr)
+        assert np.all(same | (pr2 == 0.0)) and np.all(pr[~same] <= thre)
+        g = hf.get_option("stat_split_group")
+        assert g == at if at else 0 < g < n_grp
+        parked[at] = hf.get_option("stat_split_parked")
+        # every candidate that kept its probability and could still win was parked (+ the unfinished blocks)
+        assert parked[at] >= int((pr > thre).sum())
+        assert hf.get_option("stat_split_trees") in range(1, 100)
+        cd2.close()
+    assert parked[1] > parked[late] >= parked[n_grp - 1]   # the later the cut, the fewer are open
+    assert parked[1] >= int((st != 0).sum())                       # (after 8 of 100 trees nobody is decided at 0.5)
+    # the permission withdrawn: one launch, every probability
+    hf.set_option("forest_split_at", 0)
+    cd3 = _lib.HipCands(x, y, options={"chunk": 500_000})
+    assert cd3.run(hm, hf, w, thre) == n1 and hf.get_option("stat_split_group") == 0
+    assert np.array_equal(gio.bits(cd3.fetch_all()[1]), gio.bits(pr))
 
 
 def test_extract_and_predict_across_chunks(config2):

@@ -40,8 +40,13 @@ def source_sha():
 def kclass(name):
     n = name.replace(" ", "")
     if "forest_qr_kernel" in n:
-        # forest_qr_kernel<HALF1, PRUNE, NR>: the full evaluation is PRUNE = false
-        return "forest" if re.search(r"forest_qr_kernel<\d+,false,\d+>", n) else None
+        # forest_qr_kernel<HALF1, PRUNE, NR, SPLIT>: PRUNE = true is the in-kernel early exit (not counted);
+        # SPLIT 1 = the head of the cut forest (what the headline runs: the dominant kernel), 2 = its tail,
+        # 0 = the one-launch kernel of the full-evaluation leg (class "forest" only when nothing was cut)
+        m = re.search(r"forest_qr_kernel<\d+,(true|false),\d+,(\d)>", n)
+        if not m or m.group(1) == "true":
+            return None
+        return {"0": "forest_full", "1": "forest", "2": "forest_tail"}[m.group(2)]
     if "forest_q2_kernel" in n:
         return "forest"
     if "forest_q_kernel" in n:
@@ -70,8 +75,10 @@ def main():
                     acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
                     ids[k][r["Counter_Name"]].add(r["Dispatch_Id"])
                     names[k].add(r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0])
+    if "forest" not in acc and "forest_full" in acc:   # nothing was cut: the one-launch kernel is THE forest kernel
+        acc["forest"], ids["forest"], names["forest"] = acc.pop("forest_full"), ids.pop("forest_full"), names.pop("forest_full")
     out = {"source_sha": source_sha(), "candidates": n_cand}
-    for k in ("extract", "quant", "forest"):
+    for k in ("extract", "quant", "forest", "forest_tail", "forest_full"):
         if k not in acc:
             continue
         per = {c: acc[k][c] / max(1, len(ids[k][c])) for c in acc[k]}
