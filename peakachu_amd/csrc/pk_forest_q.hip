@@ -1764,8 +1764,8 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
 }
 
 // the walk over the rank tiles of candidates [c0, c0 + cn) (tile 0 = candidate c0)
-// The forest cut in two (round 5).  Measured potential on config 2 (tools/cut_potential.py, the oracle's
-// per-tree values of 153 546 candidates): at the default threshold 0.5 a candidate's fate is sealed after
+// The forest cut in two (round 5).  Measured potential on config 2 (tests/fuzz/cut_potential.py: per-tree
+// leaf values of 153 546 candidates, computed on the host): at the default threshold 0.5 a candidate's fate is sealed after
 // ~60 of the 100 trees on average (its partial sum plus 1.0 per remaining tree can no longer exceed
 // thre * T), but a 256-candidate TILE -- the unit the in-kernel early exit works on -- only after ~80,
 // and leaving a tile early costs an exposed tile load: the in-kernel exit gains nothing below 0.55.  A
