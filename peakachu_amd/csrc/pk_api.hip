@@ -399,6 +399,7 @@ extern "C" int64_t pk_forest_get_option(pk_forest *f, const char *name)
     if (!strcmp(name, "stat_split_group")) return f->last_cut;
     if (!strcmp(name, "stat_split_trees"))
         return f->last_cut > 0 && (size_t)f->last_cut * 4 < f->q_gtab_h.size() ? f->q_gtab_h[(size_t)f->last_cut * 4] : 0;
+    if (!strcmp(name, "stat_split_shift")) return f->cut_off ? -1 : f->cut_shift;  // what the cut has learnt (-1: given up)
     if (!strcmp(name, "stat_split_parked")) {
         PK_DEV_LOCK(f->device);
         pk_device_ctx *ctx = pk_ctx(f->device);
@@ -1388,6 +1389,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     int rc = pk_ctx_reserve_tiles(ctx, (overlap ? 2 : 1) * tile_floats * sizeof(float));
     if (rc) return rc;
     ctx->split_k = 0;  // (the cut forest's counters: one per launch of this call)
+    ctx->split_n = 0;
     // the cut forest parks its candidates in the chunk's float tiles once they are quantized: not while
     // the extractor of the next chunk may be writing a tile buffer beside the forest
     if (overlap) split_sum = -INFINITY;
@@ -1517,13 +1519,20 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
 __global__ void __launch_bounds__(256) ret_pack_kernel(const int64_t *__restrict__ n_out, const long long *__restrict__ dbg3,
                                                        const int32_t *__restrict__ ox, const int32_t *__restrict__ oy,
                                                        const double *__restrict__ op, const double *__restrict__ os,
-                                                       char *__restrict__ ret, int with_records)
+                                                       char *__restrict__ ret, int with_records,
+                                                       const unsigned *__restrict__ split_cnt, int split_k)
 {
     const int64_t n = *n_out;
     if (blockIdx.x == 0 && threadIdx.x < 4)
         reinterpret_cast<long long *>(ret)[threadIdx.x] = threadIdx.x == 0 ? (long long)n : dbg3[threadIdx.x - 1];
+    if (blockIdx.x == 0 && threadIdx.x == 4 && split_k > 0) {
+        // what the cut forest's launches of this call parked (fifth word of the header)
+        long long parked = 0;
+        for (int i = 0; i < split_k; i++) parked += split_cnt[i];
+        reinterpret_cast<long long *>(ret)[4] = parked;
+    }
     if (!with_records || n > PK_RET_INLINE) return;
-    int32_t *rx = reinterpret_cast<int32_t *>(ret + 32), *ry = rx + PK_RET_INLINE;
+    int32_t *rx = reinterpret_cast<int32_t *>(ret + PK_RET_HEAD), *ry = rx + PK_RET_INLINE;
     double *rp = reinterpret_cast<double *>(ry + PK_RET_INLINE), *rs = rp + PK_RET_INLINE;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         rx[i] = ox[i];
@@ -1601,15 +1610,21 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
     // 1-4: two pageable copies here and four more in pk_score_fetch, 25 us each).
     cd->ret_inline = false;
     hipLaunchKernelGGL(ret_pack_kernel, dim3(with_records ? 32 : 1), dim3(256), 0, ctx->stream, cd->n_out_dev,
-                       ctx->dbg_buf + 65533, cd->ox, cd->oy, cd->op, cd->osig, ctx->d_ret, with_records ? 1 : 0);
+                       ctx->dbg_buf + 65533, cd->ox, cd->oy, cd->op, cd->osig, ctx->d_ret, with_records ? 1 : 0,
+                       ctx->split_cnt, ctx->split_cnt ? ctx->split_k : 0);
     PK_HIP(hipGetLastError());
-    PK_HIP(hipMemcpyAsync(ctx->h_ret, ctx->d_ret, with_records ? PK_RET_BYTES : 32, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(hipMemcpyAsync(ctx->h_ret, ctx->d_ret, with_records ? PK_RET_BYTES : PK_RET_HEAD, hipMemcpyDeviceToHost, ctx->stream));
     TR("run:enq");
     PK_HIP(hipStreamSynchronize(ctx->stream));
     TR("run:synced");
     long long dbg3[3];
     memcpy(&cd->n_out, ctx->h_ret, 8);
     memcpy(dbg3, ctx->h_ret + 8, 24);
+    if (ctx->split_k > 0) {
+        long long parked = 0;
+        memcpy(&parked, ctx->h_ret + 32, 8);
+        pk_forest_cut_feedback(f, ctx->split_n, parked, ctx->split_k);
+    }
     cd->ret_inline = with_records && cd->n_out <= PK_RET_INLINE;
     const long long err = dbg3[2];
     if (dbg3[0]) {
@@ -1716,7 +1731,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
     }
     if (!rc && cd->ret_inline) {  // the pixels came back with the count
         const size_t k = (size_t)cd->n_out;
-        const char *r = ctx->h_ret + 32;
+        const char *r = ctx->h_ret + PK_RET_HEAD;
         if (ox) memcpy(ox, r, k * 4);
         if (oy) memcpy(oy, r + (size_t)PK_RET_INLINE * 4, k * 4);
         if (op) memcpy(op, r + (size_t)PK_RET_INLINE * 8, k * 8);

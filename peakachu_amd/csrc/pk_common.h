@@ -61,10 +61,12 @@ struct pk_device_ctx {
     // the forest cut in two (pk_forest_q.hip): one counter of parked candidates per launch of a call
     unsigned *split_cnt = nullptr;  // device [PK_SPLIT_SLOTS], zeroed at the first cut launch of a call
     int split_k = 0;                // counters handed out in this call
+    int64_t split_n = 0;            // candidates of this call's cut launches
 };
 #define PK_SPLIT_SLOTS 4096
 #define PK_RET_INLINE 8192
-#define PK_RET_BYTES (32 + (size_t)PK_RET_INLINE * 24)
+#define PK_RET_HEAD 64  // {n_out, three status words, candidates the cut forest parked, -, -, -}
+#define PK_RET_BYTES (PK_RET_HEAD + (size_t)PK_RET_INLINE * 24)
 pk_device_ctx *pk_ctx(int device);  // lazily created; nullptr + error on failure
 int pk_ctx_reserve_tiles(pk_device_ctx *, size_t bytes);
 int pk_ctx_reserve_scan(pk_device_ctx *, size_t bytes);
@@ -236,6 +238,10 @@ struct pk_forest {
     uint32_t *q_lut = nullptr;                                       // device
     std::vector<int32_t> q_gtab_h;  // host copy of q_gtab: where a cut may go (pk_forest_q.hip, q_pick_cut)
     int last_cut = 0;               // group the last launch of forest_qr_kernel was cut in front of (0: one launch)
+    // what the cut has learnt for one threshold (q_pick_cut, pk_forest_cut_feedback)
+    double cut_sum = -1.0;          // thre * T it belongs to
+    int cut_shift = 0;              // groups later than the first plausible boundary
+    bool cut_off = false;           // no cut pays at this threshold
 };
 // ---- LDS-image forest (pk_image.hip builds it, pk_forest_img.hip walks it) ----
 struct pk_img_layout {
@@ -333,6 +339,7 @@ int pk_q_group(pk_q_out *out, const pk_q_layout &L);
 int pk_q_fixed_slots(const pk_q_out &out, int slots, pk_q_layout *L);
 int pk_q_max_tree_bytes(const pk_q_out &out);  // largest tree image, a multiple of 16  // (re)group the trees of `out` for a layout
 int pk_forest_q_plan(pk_forest *f);   // PK_OK when the rank image applies (built and uploaded)
+void pk_forest_cut_feedback(pk_forest *f, int64_t candidates, int64_t parked, int launches);  // after a call whose launches were cut
 void pk_forest_q_release(pk_forest *f);
 // split_sum: -inf, or thre * T when the run allows decided candidates to end at probability 0 and the
 // float tiles may be overwritten once they are quantized (the cut forest parks its candidates there)

@@ -1261,13 +1261,20 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
 // the two -- round 5), no issue priorities (latency-bound waves; rotating them was measured in round 5 on
 // the fitted forest's 14-15-tree groups: +1.3 %, not kept).
 // ------------------------------------------------------------------------
+// SPLIT (the forest cut in two, see forest_qr_kernel / q_pick_cut): 1 = head -- after its groups every
+// candidate that is still open is parked (partial sum, status, index, its column of the rank tile as a
+// column of a 64-candidate tile in slot order) --, 2 = tail over the parked candidates.
+template <int SPLIT>
 __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
     int t_div, int F, int val_off, int img_off, const unsigned short *__restrict__ qtiles,
-    const uint8_t *__restrict__ status, int64_t c0, int64_t cn, double *__restrict__ prob,
-    long long *__restrict__ stamps, int dbg, int late_below)
+    const uint8_t *__restrict__ status, int64_t c0, int64_t cn_arg, double *__restrict__ prob,
+    long long *__restrict__ stamps, int dbg, int late_below, qr_split_args sp, double prune_sum)
 {
     constexpr int THREADS = Q_THREADS;
+    const int64_t cn = SPLIT == 2 ? (int64_t)__builtin_amdgcn_readfirstlane((int)*sp.cnt) : cn_arg;
+    const int64_t sc0 = SPLIT == 2 ? 0 : c0;  // (the tail's status bytes are the parked ones, in slot order)
+    [[maybe_unused]] unsigned pk_at = 0, pk_end = 0;  // SPLIT 1: the next free parking slot, the end of this workgroup's block
     // six staging registers (groups of <= 96 KiB) and five for the spare tile (<= 5 x 1024 units of
     // 16 B: F <= 639) per thread.  Every thread stages its share of the next group, but the waves
     // that walk (slot < late_below: no group has more trees) issue their loads BEHIND the first
@@ -1319,14 +1326,14 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         }
         // lane's candidate in either tile; thread tid < 128 owns candidate cbase + tid (ordered sum)
         const int64_t la = cbase + lane, lb = cbase + 64 + lane;
-        const unsigned st_a = la < cn ? status[c0 + la] : 0, st_b = lb < cn ? status[c0 + lb] : 0;
+        const unsigned st_a = la < cn ? status[sc0 + la] : 0, st_b = lb < cn ? status[sc0 + lb] : 0;
         const bool act_a = lds_at_zero && st_a != 0;
         const bool act_b = lds_at_zero && st_b != 0;
         // (uniform) a wave with a NaN feature among its candidates walks with the NaN rule
         const bool nan_a = __any(st_a == 2), nan_b = __any(st_b == 2);
         const bool owner = tid < 128;
         const bool valid = owner && cbase + tid < cn;
-        const bool active = valid && lds_at_zero && status[c0 + cbase + tid] != 0;
+        const bool active = valid && lds_at_zero && status[sc0 + cbase + tid] != 0;
 #define Q2_PF_DECL(q) v4u pf##q = {0u, 0u, 0u, 0u}, pl##q = {0u, 0u, 0u, 0u};
         Q2_PF6(Q2_PF_DECL)
         // Thread tid moves units tid, tid + 1024, ... of the group.  The loads in front of the walk
@@ -1361,6 +1368,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
         const bool pf_late = has_b && slot < late_below;  // (uniform) this wave loads behind the first walk
         __syncthreads();  // tile A and the first group are in LDS
         double acc = 0.0;
+        if constexpr (SPLIT == 2)
+            if (valid) acc = sp.acc[cbase + tid];  // the head's trees, already added in order
         int cur = 0;  // (uniform) the tile that sits in LDS: 0 = A, 1 = B
 #ifdef PK_QR_STAMPS
 #define Q2_STAMP(k_)                                                                    \
@@ -1461,8 +1470,76 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
             g_cur = g_nxt;
             tt = tt_nxt;
         }
-        if (valid) prob[c0 + cbase + tid] = active ? acc / (double)t_div : 0.0;
+        if constexpr (SPLIT == 1) {
+            // The cut (see forest_qr_kernel): the open candidates of this trip's two tiles are listed in LDS
+            // (the parked values' place: every sum is behind the last barrier), the spare tile joins the other
+            // one in LDS (over the tree images: every walk is done), then all sixteen waves copy the columns --
+            // lanes = parked candidates, a wave takes every sixteenth row.  Slots: blocks of 128 (a trip's two tiles) per workgroup.
+            const unsigned pk_list = (unsigned)val_off, pk_cnt = pk_list + 4u * 128u, pk_new = pk_cnt + 4u;
+            if (tid == 0) *LDS_AT(lds_i32, pk_cnt) = 0;
+            if (has_b) {
+#define Q2_SPARE_ST(k) if (tid + (k) * THREADS < upt) *LDS_AT(lds_u4, img_off + ((tid + (k) * THREADS) << 4)) = tb##k;
+                Q2_TB5(Q2_SPARE_ST)
+#undef Q2_SPARE_ST
+            }
+            QR_LDS_BARRIER();
+            bool open = false;
+            unsigned my_i = 0;
+            if (owner) {  // (waves 0 and 1: tile A, tile B)
+                open = active && !((acc + sp.rem) * (1.0 + 1e-12) < prune_sum);
+                const unsigned long long m = __ballot(open);
+                if (m != 0ull) {
+                    unsigned pos = 0;
+                    if (lane == 0) pos = __hip_atomic_fetch_add(LDS_AT(lds_i32, pk_cnt), (int)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+                    my_i = pos + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                    if (open) *LDS_AT(lds_i32, pk_list + 4u * my_i) = tid;  // tile << 6 | lane
+                }
+            }
+            QR_LDS_BARRIER();  // list and count are published
+            const unsigned P = (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_cnt));
+            if (P != 0u) {  // (uniform)
+                const unsigned room = pk_end - pk_at;
+                unsigned new_base = 0;
+                if (P > room) {  // (uniform) a new block of slots: one atomic per ~128 parked candidates
+                    if (tid == 0) *LDS_AT(lds_i32, pk_new) = (int)atomicAdd(sp.cnt, 128u);
+                    QR_LDS_BARRIER();
+                    new_base = (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_new));
+                }
+                if (open) {
+                    const unsigned s_ = my_i < room ? pk_at + my_i : new_base + (my_i - room);
+                    sp.idx[s_] = (int32_t)(cbase + tid);
+                    sp.acc[s_] = acc;
+                    sp.st[s_] = (uint8_t)(tid < 64 ? st_a : st_b);
+                }
+                for (unsigned i0 = 0; i0 < P; i0 += 64u) {
+                    const unsigned i = i0 + (unsigned)lane;
+                    if (i < P) {
+                        const int cand = *LDS_AT(const lds_i32, pk_list + 4u * i);
+                        const unsigned s_ = i < room ? pk_at + i : new_base + (i - room);
+                        // (the tile that sat in LDS at the end is at 0, the other one over the tree images)
+                        const unsigned src = ((cand >> 6) == cur ? 0u : (unsigned)img_off) + ((unsigned)(cand & 63) << 1);
+                        unsigned short *dst = sp.tiles + (size_t)(s_ >> 6) * (size_t)F * 64u + (s_ & 63u);
+                        for (int r = slot; r < F; r += 16) dst[(size_t)r * 64u] = *LDS_AT(const lds_u16, src + (unsigned)r * 128u);
+                    }
+                }
+                if (P > room) {
+                    pk_at = new_base + (P - room);
+                    pk_end = new_base + 128u;
+                } else {
+                    pk_at += P;
+                }
+            }
+            if (valid && !open) prob[c0 + cbase + tid] = 0.0;
+            // (the barrier at the top of the next trip stands between these reads and the next tile's stores)
+        } else if constexpr (SPLIT == 2) {
+            if (valid && active) prob[c0 + sp.idx[cbase + tid]] = acc / (double)t_div;  // (status 0: a slot nobody took)
+        } else {
+            if (valid) prob[c0 + cbase + tid] = active ? acc / (double)t_div : 0.0;
+        }
     }
+    if constexpr (SPLIT == 1)  // what is left of the last block: nobody
+        for (unsigned i = pk_at + threadIdx.x; i < pk_end; i += THREADS) sp.st[i] = 0;
     if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-up loads alive
 #undef Q2_STAMP
 #undef Q2_TB5
@@ -1774,17 +1851,45 @@ int pk_launch_forest_q(pk_device_ctx *ctx, pk_forest *f, const float *tiles, con
 // the tail walks the remaining groups over the parked ones only and continues their sums in tree order.
 // Returns the group to cut in front of (0: no cut): the first boundary behind which a candidate whose
 // partial sum is at most `forest_split_frac` per mille of the trees walked is decided.
-static int q_pick_cut(const pk_forest *f, double split_sum)
+// What the runs themselves teach (pk_forest_cut_feedback, called with the number of candidates a call's cut
+// launches parked): a cut that leaves more than 15 % open moves a group later for the next call (two when
+// more than half stayed open), one that has nothing worth-while left behind it is given up for this
+// threshold -- a forest of untrained random trees (p ~ 0.5 everywhere) parks everybody wherever it is cut.
+static int q_pick_cut(pk_forest *f, double split_sum)
 {
     if ((int)f->q_gtab_h.size() < 4 * (f->q_n_grp + 1)) return 0;
     if (f->opt.forest_split_at > 0) return f->opt.forest_split_at < f->q_n_grp ? (int)f->opt.forest_split_at : 0;
+    if (f->cut_sum != split_sum) {  // another threshold: what was learnt does not apply
+        f->cut_sum = split_sum;
+        f->cut_shift = 0;
+        f->cut_off = false;
+    }
+    if (f->cut_off) return 0;
     const double frac = (double)f->opt.forest_split_frac * 1e-3;
     for (int g = 1; g < f->q_n_grp; g++) {
         const double done = (double)f->q_gtab_h[4 * (size_t)g];  // trees in front of group g
         const double lim = split_sum - ((double)f->q_T - done);  // a sum up to here is decided
-        if (lim >= frac * done && lim > 0.0) return g;
+        if (lim >= frac * done && lim > 0.0) {
+            g += f->cut_shift;
+            // (a tail of less than a seventh of the forest does not pay for the head's parking and a launch)
+            if (g * 7 > f->q_n_grp * 6) {
+                f->cut_off = true;
+                return 0;
+            }
+            return g;
+        }
     }
     return 0;
+}
+
+void pk_forest_cut_feedback(pk_forest *f, int64_t candidates, int64_t parked, int launches)
+{
+    if (!f || candidates <= 0 || f->last_cut <= 0 || f->opt.forest_split_at > 0) return;
+    // (`parked` counts slots: up to one unfinished block of 256 per workgroup and launch is nobody)
+    parked -= (int64_t)launches * 65536;
+    const double open = parked > 0 ? (double)parked / (double)candidates : 0.0;
+    if (open > 0.5) f->cut_shift += 2;
+    else if (open > 0.15) f->cut_shift += 1;
 }
 
 int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_status, int64_t c0, int64_t cn,
@@ -1845,6 +1950,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
                 sp.idx = reinterpret_cast<int32_t *>(b + tiles_b + acc_b);
                 sp.st = reinterpret_cast<uint8_t *>(b + tiles_b + acc_b + idx_b);
                 sp.cnt = ctx->split_cnt + ctx->split_k++;
+                ctx->split_n += cn;
                 sp.rem = (double)f->q_T - (double)f->q_gtab_h[4 * (size_t)cut];
                 grid_tail = grid;
             }
@@ -1929,14 +2035,58 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
         // one-tile kernel with its early exit is the slower of the two on these forests (round 5)
         f->last_family = 3;
         const int late_below = f->opt.forest_q_help ? f->q_slots : 0;
-        int rc2 = q_set_max_lds(forest_q2_kernel, 163840);
-        if (rc2) return rc2;
         unsigned grid2 = (unsigned)((cn + 127) / 128);
         if (f->opt.forest_q_persist != 0 && grid2 > want) grid2 = want;
-        hipLaunchKernelGGL(forest_q2_kernel, dim3(grid2), dim3(Q_THREADS), 163840, ctx->stream,
-                           reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab),
-                           f->q_n_grp, reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.val_off, L.img_off,
-                           ctx->q_tiles, d_status, c0, cn, d_prob, ctx->dbg_buf, (int)f->opt.forest_dbg, late_below);
+        // the cut (see the default shape above): the spare tile must fit over the tree images
+        int cut = 0;
+        qr_split_args sp{};
+        if (split_sum > -1e300 && f->opt.forest_split && scratch && cn >= f->opt.forest_split_min &&
+            ctx->split_k < PK_SPLIT_SLOTS && L.HB <= L.cap && L.slots * 64 * 8 >= 4 * 130)
+            cut = q_pick_cut(f, split_sum);
+        if (cut > 0) {
+            auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t cap = (size_t)cn + 128u * (size_t)grid2 + 256u;
+            const size_t tiles_b = up((cap + 63) / 64 * f->q_F * 64 * sizeof(unsigned short) + PK_Q_PAD_BYTES);
+            const size_t acc_b = up(cap * 8), idx_b = up(cap * 4), st_b = up(cap);
+            if (tiles_b + acc_b + idx_b + st_b > scratch_bytes) {
+                cut = 0;
+            } else {
+                if (!ctx->split_cnt) {
+                    PK_HIP(hipMalloc((void **)&ctx->split_cnt, PK_SPLIT_SLOTS * sizeof(unsigned)));
+                    ctx->split_k = 0;
+                }
+                if (ctx->split_k == 0)
+                    PK_HIP(hipMemsetAsync(ctx->split_cnt, 0, PK_SPLIT_SLOTS * sizeof(unsigned), ctx->stream));
+                char *b = static_cast<char *>(scratch);
+                sp.tiles = reinterpret_cast<unsigned short *>(b);
+                sp.acc = reinterpret_cast<double *>(b + tiles_b);
+                sp.idx = reinterpret_cast<int32_t *>(b + tiles_b + acc_b);
+                sp.st = reinterpret_cast<uint8_t *>(b + tiles_b + acc_b + idx_b);
+                sp.cnt = ctx->split_cnt + ctx->split_k++;
+                ctx->split_n += cn;
+                sp.rem = (double)f->q_T - (double)f->q_gtab_h[4 * (size_t)cut];
+            }
+        }
+        f->last_cut = cut;
+#define Q2_LAUNCH(SPLIT_, GRID_, GTAB_, NGRP_, TILES_, STATUS_, CN_)                                              \
+    do {                                                                                                           \
+        int rc2 = q_set_max_lds(forest_q2_kernel<SPLIT_>, 163840);                                                 \
+        if (rc2) return rc2;                                                                                       \
+        hipLaunchKernelGGL(forest_q2_kernel<SPLIT_>, dim3(GRID_), dim3(Q_THREADS), 163840, ctx->stream,            \
+                           reinterpret_cast<const v4u *>(f->q_img), GTAB_, NGRP_,                                  \
+                           reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.val_off, L.img_off,  \
+                           TILES_, STATUS_, c0, CN_, d_prob, ctx->dbg_buf, (int)f->opt.forest_dbg, late_below, sp,  \
+                           split_sum);                                                                             \
+    } while (0)
+        if (cut > 0) {
+            Q2_LAUNCH(1, grid2, reinterpret_cast<const int4 *>(f->q_gtab), cut, ctx->q_tiles, d_status, cn);
+            PK_HIP(hipGetLastError());
+            pk_prof_scope prof_tail(ctx, PK_K_FOREST_TAIL);
+            Q2_LAUNCH(2, grid2, reinterpret_cast<const int4 *>(f->q_gtab) + cut, f->q_n_grp - cut, sp.tiles, sp.st, (int64_t)0);
+        } else {
+            Q2_LAUNCH(0, grid2, reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp, ctx->q_tiles, d_status, cn);
+        }
+#undef Q2_LAUNCH
     } else if (L.ch == 1) {
         f->last_family = 2;
         Q_LAUNCH(1, 1, 32768, false);

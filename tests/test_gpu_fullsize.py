@@ -369,6 +369,33 @@ def test_cut_forest_scores_the_same_pixels(config2, w, nan_diag):
     assert np.array_equal(gio.bits(cd3.fetch_all()[1]), gio.bits(pr))
 
 
+def test_cut_forest_gives_up_where_nobody_is_decided(config2):
+    """A forest of untrained random trees (p ~ 0.5 everywhere) parks every candidate wherever it is cut:
+    the library learns that from the calls themselves (pk_forest_cut_feedback) -- the cut moves later,
+    then is given up for this threshold -- and the scored pixels never change."""
+    c = config2
+    w = c["w"]
+    import bench
+    fo = bench.load_forest("random:100:14", w, 121)
+    hf = _lib.HipForest(fo, options={"forest_split_min": 1})
+    x, y = c["x"][:700_000], c["y"][:700_000]
+    cd0 = _lib.HipCands(x, y)
+    n0 = cd0.run(c["hm"], hf, w, 0.5)
+    base = digest(*cd0.fetch())
+    if hf.get_option("stat_family") != 1:
+        pytest.skip("the random forest did not take the default rank kernel")
+    cd = _lib.HipCands(x, y)
+    cd.set_prune(True)
+    cuts = []
+    for _ in range(8):
+        assert cd.run(c["hm"], hf, w, 0.5) == n0 and digest(*cd.fetch()) == base
+        cuts.append(hf.get_option("stat_split_group"))
+    assert cuts[0] > 0 and cuts[-1] == 0 and hf.get_option("stat_split_shift") == -1
+    assert all(b >= a or b == 0 for a, b in zip(cuts, cuts[1:]))   # later and later, then not at all
+    # another threshold starts afresh
+    assert cd.run(c["hm"], hf, w, 0.9) >= 0 and hf.get_option("stat_split_group") > 0
+
+
 def test_extract_and_predict_across_chunks(config2):
     """pk_extract (65 536-candidate staging chunks) and pk_predict (512 k chunks)
     on inputs larger than one chunk: survivor order and sampled values vs the oracle."""
