@@ -1088,12 +1088,19 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
             //  * The barriers order LDS only: __syncthreads() would also wait for the acknowledgement of this
             //    tile's global stores (4 000 cycles per tile, measured), which nobody in the workgroup reads.
             const unsigned pk_list = (unsigned)dec_off, pk_cnt = pk_list + 4u * 256u, pk_new = pk_cnt + 4u;
+#ifdef PK_QR_STAMPS   // (row 30 of the stamp matrix: the phases of the parking, tools/stamps.py)
+#define QR_PSTAMP(k_)                                                                    \
+    do {                                                                                 \
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && fetched)             \
+            stamps[((tid >> 6) * 32 + 30) * 5 + (k_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define QR_PSTAMP(k_) do {} while (0)
+#endif
+            QR_PSTAMP(0);
             bool decided = false, open = false;
             unsigned my_i = 0;
-#ifndef PK_CUT_ABLATE
-#define PK_CUT_ABLATE 0   // timing ablations (WRONG results): 1 nobody is parked (body compiled out), 2 ... at run time
-#endif
-            if (owner && PK_CUT_ABLATE != 1 && !(PK_CUT_ABLATE == 2 && !(dbg & 64))) {  // (waves 0-3, whole waves)
+            if (owner) {  // (waves 0-3, whole waves)
                 open = valid && active && !((acc + A.split_rem) * (1.0 + 1e-12) < A.prune_sum);
                 decided = valid && !open;
                 const unsigned long long m = __ballot(open);
@@ -1105,8 +1112,10 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
                     if (open) *LDS_AT(lds_i32, pk_list + 4u * my_i) = tid;  // its place in the 256-candidate tile
                 }
             }
+            QR_PSTAMP(1);
             QR_LDS_BARRIER();  // list and count are published
-            const unsigned P = PK_CUT_ABLATE == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_cnt));
+            QR_PSTAMP(2);
+            const unsigned P = (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_cnt));
             if (P != 0u) {  // (uniform)
                 const unsigned room = pk_end - pk_at;
                 unsigned new_base = 0;
@@ -1121,15 +1130,27 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
                     A.s_acc[s] = acc;
                     A.s_st[s] = (uint8_t)st;
                 }
+                // A store INSTRUCTION costs the CU's address unit the same 16+ cycles whether ten of its lanes
+                // are live or sixty-four (stamps, round 5: 128 of them per tile -- sixteen waves x eight rows,
+                // ten parked candidates each -- took 4 000 cycles).  So the lanes are filled: the candidates of
+                // a pass in the low bits of the lane number (different columns: different banks), as many ROWS
+                // beside them as fit (the same column in several rows: that many lanes in one bank).
                 for (unsigned i0 = 0; i0 < P; i0 += 64u) {
-                    const unsigned i = i0 + (unsigned)lane;
-                    if (i < P) {
+                    const unsigned pc = P - i0 < 64u ? P - i0 : 64u;          // candidates of this pass
+                    const unsigned sh = pc <= 1u ? 0u : 32u - (unsigned)__builtin_clz(pc - 1u);  // lanes per row: 1 << sh
+                    const unsigned ci = (unsigned)lane & ((1u << sh) - 1u), rsub = (unsigned)lane >> sh;
+                    const int rows = 64 >> sh;                                 // rows per instruction
+                    if (ci < pc) {
+                        const unsigned i = i0 + ci;
                         const int cand = *LDS_AT(const lds_i32, pk_list + 4u * i);
                         const unsigned s = i < room ? pk_at + i : new_base + (i - room);
                         const unsigned src = (cand >= 128 ? (unsigned)HALF1 : 0u) + ((unsigned)(cand & 63) << 2) +
                                              ((unsigned)((cand >> 6) & 1) << 1);
                         unsigned short *dst = A.s_tiles + (size_t)(s >> 7) * (size_t)F * 128u + ((s & 63u) << 1) + ((s >> 6) & 1u);
-                        for (int r = wave; r < F; r += 16) dst[(size_t)r * 128u] = *LDS_AT(const lds_u16, src + (unsigned)r * 256u);
+                        for (int r0 = wave * rows; r0 < F; r0 += 16 * rows) {
+                            const int r = r0 + (int)rsub;
+                            if (r < F) dst[(size_t)r * 128u] = *LDS_AT(const lds_u16, src + (unsigned)r * 256u);
+                        }
                     }
                 }
                 if (P > room) {
@@ -1139,7 +1160,9 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
                     pk_at += P;
                 }
             }
+            QR_PSTAMP(3);
             QR_LDS_BARRIER();  // the codes are read: the next tile may be stored over this one
+            QR_PSTAMP(4);
             if (tid == 0) *LDS_AT(lds_i32, pk_cnt) = 0;  // (everybody has read it; the next tile adds to it many barriers later)
             if (decided) A.prob[c0 + local] = 0.0;
         } else if constexpr (SPLIT == 2) {
@@ -1512,15 +1535,25 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
                     sp.acc[s_] = acc;
                     sp.st[s_] = (uint8_t)(tid < 64 ? st_a : st_b);
                 }
+                // (the lanes of a store instruction are filled -- candidates in the low bits of the lane number,
+                // rows beside them -- as in forest_qr_kernel: an instruction costs the address unit the same
+                // whether two of its lanes are live or sixty-four)
                 for (unsigned i0 = 0; i0 < P; i0 += 64u) {
-                    const unsigned i = i0 + (unsigned)lane;
-                    if (i < P) {
+                    const unsigned pc = P - i0 < 64u ? P - i0 : 64u;
+                    const unsigned sh = pc <= 1u ? 0u : 32u - (unsigned)__builtin_clz(pc - 1u);
+                    const unsigned ci = (unsigned)lane & ((1u << sh) - 1u), rsub = (unsigned)lane >> sh;
+                    const int rows = 64 >> sh;
+                    if (ci < pc) {
+                        const unsigned i = i0 + ci;
                         const int cand = *LDS_AT(const lds_i32, pk_list + 4u * i);
                         const unsigned s_ = i < room ? pk_at + i : new_base + (i - room);
                         // (the tile that sat in LDS at the end is at 0, the other one over the tree images)
                         const unsigned src = ((cand >> 6) == cur ? 0u : (unsigned)img_off) + ((unsigned)(cand & 63) << 1);
                         unsigned short *dst = sp.tiles + (size_t)(s_ >> 6) * (size_t)F * 64u + (s_ & 63u);
-                        for (int r = slot; r < F; r += 16) dst[(size_t)r * 64u] = *LDS_AT(const lds_u16, src + (unsigned)r * 128u);
+                        for (int r0 = slot * rows; r0 < F; r0 += 16 * rows) {
+                            const int r = r0 + (int)rsub;
+                            if (r < F) dst[(size_t)r * 64u] = *LDS_AT(const lds_u16, src + (unsigned)r * 128u);
+                        }
                     }
                 }
                 if (P > room) {
@@ -1989,7 +2022,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
                                reinterpret_cast<const v4u *>(f->q_img), reinterpret_cast<const int4 *>(f->q_gtab) + cut, \
                                f->q_n_grp - cut, reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.dec_off, \
                                L.val_off, L.img_off, sp.tiles, sp.st, c0, (int64_t)0, d_prob, split_sum,    \
-                               (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg, ctx->dbg_buf, sp);  \
+                               (int)(f->opt.forest_q_rsv >> 1), (int)f->opt.forest_dbg & ~16, ctx->dbg_buf, sp); /* (stamps: the head's) */ \
         }                                                                                                  \
     } while (0)
         // forest_q_rsv bits: 1 on, 2 PREF0 (the next tile's first group prefetched with the tile)

@@ -25,6 +25,10 @@ for kv in filter(None, os.environ.get("PK_OPTS", "").split(",")):
 hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -2 * w + 1, upper + 2 * w - 1)
 hf = _lib.HipForest(fo)
 cd = _lib.HipCands(x, y)
+if os.environ.get("PK_STAMP_CUT"):   # the head of the cut forest (PK_STAMP_CUT = group to cut in front of; 0 = the library's choice)
+    cd.set_prune(True)
+    hf.set_option("forest_split_min", 1)
+    hf.set_option("forest_split_at", int(os.environ["PK_STAMP_CUT"]))
 cd.run(hm, hf, w, 0.5)
 hf.set_option("forest_dbg", 16 | dbg_extra)   # (in-kernel stamps: builds with -DPK_QR_STAMPS, tools/build_variant.sh)
 cd.run(hm, hf, w, 0.5)
@@ -70,6 +74,11 @@ print("  commit+accumulate   %8.0f" % commit.mean())
 print("  wait at barrier 2   %8.0f" % bar2.mean())
 print("  total per group     %8.0f ; whole workgroup %.0f cycles" % ((st[:, :, 4] - st[:, :, 0]).mean(), tot.mean()))
 print("per-wave walk means:", np.round(walk.mean(1)).astype(int).tolist())
+park = buf.reshape(16, 32, 5)[:, 30, :].astype(np.float64)   # the head of the cut forest: phases of the parking
+if os.environ.get("PK_STAMP_CUT") and park[:, 0].all() and park[:, 4].all():
+    d = np.diff(park, axis=1)
+    print("parking (head of the cut forest), cycles per wave: owners' list %s | wait at barrier 1 %s | copy %s | wait at barrier 2 %s"
+          % tuple(np.round(d[:, k]).astype(int).tolist() for k in range(4)))
 if tile[:, 0].all() and tile[:, 3].all():
     # (stamp 4 is taken at the START of a trip: the one stored last belongs to the trip whose end
     # stamps 0-3 describe only when that trip was not the workgroup's last one)
