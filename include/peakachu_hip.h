@@ -148,11 +148,21 @@ pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t
 void pk_cands_destroy(pk_cands *);
 /* ALLOW exact early termination for the runs of THIS candidate list (what Chromosome.score
  * needs: only the pixels with p > thre, peakachu/scoreUtils.py:110-113): a candidate may stop
- * walking the forest once its sum can no longer exceed thre * T.  The scored pixels are
- * identical; pk_score_fetch_all reports 0 for a candidate that was stopped.  The library uses the
- * permission where it pays (thre >= 0.55 on lists of >= 2^19 candidates: at the default 0.5 no
- * candidate can stop before half the forest and the test costs more than it saves); option
- * "early_exit" = 1 on the list forces it.  Off by default (every candidate gets its full probability). */
+ * walking the forest once its sum can no longer exceed thre * T (every remaining tree adds at most
+ * 1.0).  The scored pixels are identical; pk_score_fetch_all reports 0 for a candidate that was
+ * stopped.  The library uses the permission where it pays:
+ *   - launches of at least 2^19 candidates on the default rank kernels (forest_qr_kernel,
+ *     forest_q2_kernel) are CUT IN TWO at a tree-group boundary -- the head walks the groups in front
+ *     of the cut over every candidate and parks the ones still open (partial sum, rank codes), the
+ *     tail walks the rest over the parked ones only, sums continued in tree order.  From the default
+ *     threshold 0.5 on (config 2: the forest's time x 0.75 at 0.5, x 0.32 at 0.9); the cut moves
+ *     later, or is given up, when the calls show that too many candidates stay open (forest options
+ *     forest_split, forest_split_at, forest_split_frac, forest_split_min; read-only
+ *     stat_split_group / _trees / _parked / _shift);
+ *   - elsewhere the in-kernel exit (a whole 256-candidate tile stops) for thre >= 0.55 on lists of
+ *     >= 2^19 candidates; option "early_exit" = 1 on the list forces it.
+ * pk_score (host buffers, scored pixels only) always gives the permission.
+ * Off by default on a pk_cands (every candidate gets its full probability). */
 int pk_cands_set_prune(pk_cands *, int on);
 /* extract -> predict -> (p > thre) -> compact, with the reference's batch
  * rule (a batch of `batch` candidates with fewer than two surviving windows

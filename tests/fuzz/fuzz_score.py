@@ -93,6 +93,9 @@ def main():
             opts["extract_row16"] = 0
         if rng.random() < 0.15:
             opts["early_exit"] = 1
+        if rng.random() < 0.4:     # the forest cut in two (pk_score always allows it): any length, any cut
+            opts["forest_split_min"] = 1
+            opts["forest_split_at"] = int(rng.choice([0, 0, 1, 2, 3, 5]))
         hm = hip_matrix(Mf, e, w, upper, options=opts)   # (options are the handles' own)
         hf = _lib.HipForest(flat(fo), options=opts)
         ox, oy, op, osig = hm.score(hf, w, thre, x, y, batch=batch)
@@ -101,12 +104,18 @@ def main():
               and np.array_equal(op.view(np.uint64), rp.view(np.uint64))
               and np.array_equal(np.asarray(osig).view(np.uint64), np.asarray(rs).view(np.uint64)))
         stats[kind] = stats.get(kind, 0) + 1
-        print("case %3d seed=%d w=%2d n=%3d band=%3d upper=%3d kind=%d cands=%6d thre=%.1f batch=%6d %s: %d pixels %s" % (
-            case, seed, w, n, band, upper, kind, x.size, thre, batch, opts, ox.size, "ok" if ok else "MISMATCH"))
+        cut = hf.get_option("stat_split_group")
+        stats["cut"] = stats.get("cut", 0) + (1 if cut > 0 else 0)
+        print("case %3d seed=%d w=%2d n=%3d band=%3d upper=%3d kind=%d cands=%6d thre=%.1f batch=%6d %s: %d pixels%s %s" % (
+            case, seed, w, n, band, upper, kind, x.size, thre, batch, opts, ox.size,
+            " (forest cut in front of group %d, family %d)" % (cut, hf.get_option("stat_family")) if cut > 0 else "",
+            "ok" if ok else "MISMATCH"))
         sys.stdout.flush()
         if not ok:
             sys.exit(1)
-    print("all %d cases bit-exact in %.0f s; matrix kinds: %s" % (n_cases, time.time() - t0, dict(sorted(stats.items()))))
+    cuts = stats.pop("cut", 0)
+    print("all %d cases bit-exact in %.0f s; matrix kinds: %s; %d with the forest cut in two" % (
+        n_cases, time.time() - t0, dict(sorted(stats.items())), cuts))
 
 
 if __name__ == "__main__":
