@@ -313,6 +313,8 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
         o.forest_q_wpt = value;
     } else if (!strcmp(name, "forest_img")) {
         o.forest_img = value != 0;
+    } else if (!strcmp(name, "compact_small")) {
+        o.compact_small = value != 0;
     } else if (!strcmp(name, "forest_split")) {
         o.forest_split = value != 0;
     } else if (!strcmp(name, "forest_split_at")) {
@@ -357,6 +359,7 @@ static int64_t opt_read(const pk_options &o, const char *name)
     if (!strcmp(name, "forest_q_rsv")) return o.forest_q_rsv;
     if (!strcmp(name, "forest_dbg")) return o.forest_dbg;
     if (!strcmp(name, "forest_q_early")) return o.forest_q_early;
+    if (!strcmp(name, "compact_small")) return o.compact_small;
     if (!strcmp(name, "forest_split")) return o.forest_split;
     if (!strcmp(name, "forest_split_at")) return o.forest_split_at;
     if (!strcmp(name, "forest_split_frac")) return o.forest_split_frac;
@@ -1601,7 +1604,8 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
     int rc = run_pipeline(ctx, m, f, cd, w, prune_sum, split_sum);
     if (rc) return forget_offender(rc);
     TR("run:launched");
-    rc = pk_launch_compact(ctx, m, cd, thre, batch);
+    bool reply_packed = false;
+    rc = pk_launch_compact(ctx, m, cd, thre, batch, with_records ? 1 : 0, &reply_packed);
     if (rc) return forget_offender(rc);
     // One copy into pinned memory brings back the count, words 65533 (first coordinate outside
     // pk_score's contract, see coords_sanitize_kernel), 65534 (a sink that keeps the kernels' warm-up
@@ -1609,10 +1613,12 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
     // pk_score -- the scored pixels themselves when there are at most PK_RET_INLINE of them (rounds
     // 1-4: two pageable copies here and four more in pk_score_fetch, 25 us each).
     cd->ret_inline = false;
-    hipLaunchKernelGGL(ret_pack_kernel, dim3(with_records ? 32 : 1), dim3(256), 0, ctx->stream, cd->n_out_dev,
-                       ctx->dbg_buf + 65533, cd->ox, cd->oy, cd->op, cd->osig, ctx->d_ret, with_records ? 1 : 0,
-                       ctx->split_cnt, ctx->split_cnt ? ctx->split_k : 0);
-    PK_HIP(hipGetLastError());
+    if (!reply_packed) {  // (a short list's compaction has packed the reply itself)
+        hipLaunchKernelGGL(ret_pack_kernel, dim3(with_records ? 32 : 1), dim3(256), 0, ctx->stream, cd->n_out_dev,
+                           ctx->dbg_buf + 65533, cd->ox, cd->oy, cd->op, cd->osig, ctx->d_ret, with_records ? 1 : 0,
+                           ctx->split_cnt, ctx->split_cnt ? ctx->split_k : 0);
+        PK_HIP(hipGetLastError());
+    }
     PK_HIP(hipMemcpyAsync(ctx->h_ret, ctx->d_ret, with_records ? PK_RET_BYTES : PK_RET_HEAD, hipMemcpyDeviceToHost, ctx->stream));
     TR("run:enq");
     PK_HIP(hipStreamSynchronize(ctx->stream));

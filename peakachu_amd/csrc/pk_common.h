@@ -128,6 +128,8 @@ struct pk_options {
                                       // the trees walked is already decided (config 2's background pixels sit at
                                       // p ~ 0.10, 99 % below 0.26)
     int64_t forest_split_min = 524288; // candidates per launch below which two launches cost more than they save
+    int64_t compact_small = 1;  // lists of up to 2^14 candidates: batch rule, p > thre, ordered compaction and the
+                                // reply in ONE single-workgroup launch (0: the four kernels of long lists)
 };
 // one recursive lock per device (pk_api.hip, "Locks"); every entry point takes the lock of its handle's device
 #define PK_MAX_DEVICES 64
@@ -450,8 +452,10 @@ int pk_launch_tile_rows(pk_device_ctx *, const float *d_rows, int64_t N, int F, 
                         int blk, uint8_t *d_status);
 int pk_forest_tile_width(int F, const pk_options &o);  // candidates per feature tile for F features
 
+// with_records / reply_packed: a short list's compaction also packs the call's reply (ctx->d_ret: header
+// and, with_records, the inline pixels) and says so; nullptr = the caller packs it itself
 int pk_launch_compact(pk_device_ctx *, const pk_matrix *, pk_cands *, double thre,
-                      int64_t batch);
+                      int64_t batch, int with_records = 0, bool *reply_packed = nullptr);
 int pk_launch_expected_means(pk_device_ctx *, const pk_matrix *m, int first, int top,
                              const uint8_t *d_valid, double *d_scratch, double *d_means);
 int pk_launch_candidates(pk_device_ctx *, const pk_matrix *raw, int lower, int upper,

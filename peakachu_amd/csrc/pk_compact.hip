@@ -631,15 +631,188 @@ int pk_launch_band_build(pk_device_ctx *ctx, pk_matrix *m, const int32_t *d_indp
     return PK_OK;
 }
 
+// ---- short lists: everything behind the forest in ONE launch ------------------------------------
+// The regime the CLI runs in -- 10^3 .. 10^5 candidates per chromosome -- pays for launches, not for
+// work: behind the forest kernel stood a memset, four kernels (batch counts, survivors per block, scan,
+// scatter) and the packing of the reply, each a few microseconds of device time behind ~5 us of
+// dependent-launch latency (round 5: 20 us of kernels + ~25 us of gaps in a 123-us call on 1 001
+// candidates).  One workgroup does all of it for lists of up to 2^14 candidates (measured: 1 001
+// candidates 20 -> 8 us of kernels and four launches fewer, 123 -> 100 us per call; one workgroup has nobody
+// to hide its loads' latency behind -- on 10^5 candidates it took 170 us where the four kernels take 24,
+// so longer lists keep those):
+//   1. groups of 64 candidates, wave by wave (coalesced): the survivors' mask of a group (ballot) parked
+//      in LDS, the batch counts by one LDS add per group and batch it touches (scoreUtils.py:104-108);
+//   2. the keep mask of every group: survivor, batch with more than one survivor, p > thre (:108-110);
+//   3. an exclusive scan of the groups' counts (thread t owns four groups; wave shuffles);
+//   4. the kept candidates written in candidate order (x, y, p, M[x, y]: :118-121) -- and, when they fit,
+//      into the reply's inline records as well -- with the reply's header words.
+constexpr int CS_MAX_N = 1 << 14;
+constexpr int CS_GROUPS = CS_MAX_N / 64;   // 256
+constexpr int CS_MAX_BATCHES = 1024;
+constexpr size_t CS_LDS = (size_t)CS_GROUPS * (8 + 8 + 4) + (size_t)CS_MAX_BATCHES * 4 + 16 * 8 + 64;
+__global__ void __launch_bounds__(1024) compact_small_kernel(
+    const uint8_t *__restrict__ status, const double *__restrict__ prob, int64_t batch, double thre, int N,
+    const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, const double *__restrict__ band, int64_t ld,
+    int dlo, int dhi, int32_t *__restrict__ ox, int32_t *__restrict__ oy, double *__restrict__ op,
+    double *__restrict__ osig, int64_t *__restrict__ n_out, int32_t *__restrict__ batch_cnt_out,
+    const long long *__restrict__ dbg3, char *__restrict__ ret, int with_records,
+    const unsigned *__restrict__ split_cnt, int split_k)
+{
+    extern __shared__ __attribute__((aligned(16))) char cs_lds[];
+    unsigned long long *stmask = reinterpret_cast<unsigned long long *>(cs_lds);
+    unsigned long long *kmask = stmask + CS_GROUPS;
+    int *koff = reinterpret_cast<int *>(kmask + CS_GROUPS);
+    int *bcnt = koff + CS_GROUPS;
+    long long *wsum = reinterpret_cast<long long *>(bcnt + CS_MAX_BATCHES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = (N + 63) >> 6;
+    const unsigned ubatch = batch > 0x40000000 ? 0x40000000u : (unsigned)batch;   // (N < 2^14: 32-bit divisions)
+    const int nb = (int)(((unsigned)N + ubatch - 1u) / ubatch);
+    for (int b = tid; b < nb; b += 1024) bcnt[b] = 0;
+    __syncthreads();
+    // 1. survivors.  (Eight groups of a wave per trip, their loads in flight together: one workgroup has
+    // nobody else to hide a load's latency behind -- one group per trip took 180 us on 10^5 candidates.)
+    constexpr int U = 8;
+    for (int g0 = wave; g0 < G; g0 += 16 * U) {
+        uint8_t stv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int c = ((g0 + 16 * u) << 6) + lane;
+            stv[u] = c < N ? status[c] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int g = g0 + 16 * u;
+            const unsigned long long m = __ballot(stv[u] != 0);
+            if (lane == 0 && g < G) {
+                stmask[g] = m;
+                if (m) {
+                    const unsigned c0 = (unsigned)g << 6;
+                    const int b0 = (int)(c0 / ubatch);
+                    // (batch >= 64: a group touches two batches at most)
+                    const int64_t edge = (int64_t)(b0 + 1) * ubatch - c0;   // candidates of the group in batch b0
+                    const unsigned long long lo = edge >= 64 ? m : (m & ((1ull << edge) - 1ull));
+                    if (lo) atomicAdd(&bcnt[b0], __popcll(lo));
+                    if (m ^ lo) atomicAdd(&bcnt[b0 + 1], __popcll(m ^ lo));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += 1024) batch_cnt_out[b] = bcnt[b];
+    // 2. keep masks
+    for (int g0 = wave; g0 < G; g0 += 16 * U) {
+        double pv[U];
+        bool stb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int g = g0 + 16 * u;
+            const int c = (g << 6) + lane;
+            stb[u] = g < G && ((stmask[g < G ? g : 0] >> lane) & 1ull);
+            pv[u] = stb[u] ? prob[c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int g = g0 + 16 * u;
+            const int c = (g << 6) + lane;
+            const bool keep = stb[u] && bcnt[(unsigned)c / ubatch] > 1 && pv[u] > thre;
+            const unsigned long long km = __ballot(keep);
+            if (lane == 0 && g < G) {
+                kmask[g] = km;
+                koff[g] = __popcll(km);
+            }
+        }
+    }
+    __syncthreads();
+    // 3. exclusive scan of koff[0 .. G): thread t owns groups 4t .. 4t + 3
+    int own[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        own[j] = 4 * tid + j < G ? koff[4 * tid + j] : 0;
+        s += own[j];
+    }
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int v = (int)wsum[i];
+        if (i < wave) woff += v;
+        total += v;
+    }
+    int run = woff + incl - s;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (4 * tid + j < G) koff[4 * tid + j] = run;
+        run += own[j];
+    }
+    __syncthreads();
+    // 4. the kept candidates, in candidate order; the reply
+    const bool inl = with_records && total <= PK_RET_INLINE;
+    int32_t *rx = reinterpret_cast<int32_t *>(ret + PK_RET_HEAD), *ry = rx + PK_RET_INLINE;
+    double *rp = reinterpret_cast<double *>(ry + PK_RET_INLINE), *rs = rp + PK_RET_INLINE;
+    for (int g = wave; g < G; g += 16) {
+        const unsigned long long km = kmask[g];
+        if (km == 0ull) continue;   // (uniform)
+        if ((km >> lane) & 1ull) {
+            const int c = (g << 6) + lane;
+            const int pos = koff[g] + __popcll(km & ((1ull << lane) - 1ull));
+            const int x = xs[c], y = ys[c];
+            const double p = prob[c];
+            const int d = y - x;
+            // signal = M[row, col] (scoreUtils.py:120)
+            const double sg = (d >= dlo && d <= dhi) ? band[(int64_t)(d - dlo) * ld + x] : 0.0;
+            ox[pos] = x;
+            oy[pos] = y;
+            op[pos] = p;
+            osig[pos] = sg;
+            if (inl) {
+                rx[pos] = x;
+                ry[pos] = y;
+                rp[pos] = p;
+                rs[pos] = sg;
+            }
+        }
+    }
+    if (tid == 0) {
+        *n_out = total;
+        reinterpret_cast<long long *>(ret)[0] = total;
+    }
+    if (tid >= 1 && tid < 4) reinterpret_cast<long long *>(ret)[tid] = dbg3[tid - 1];
+    if (tid == 4 && split_k > 0) {
+        long long parked = 0;
+        for (int i = 0; i < split_k; i++) parked += split_cnt[i];
+        reinterpret_cast<long long *>(ret)[4] = parked;
+    }
+}
+
 int pk_launch_compact(pk_device_ctx *ctx, const pk_matrix *m, pk_cands *cd, double thre,
-                      int64_t batch)
+                      int64_t batch, int with_records, bool *reply_packed)
 {
     const int64_t N = cd->N;
+    if (reply_packed) *reply_packed = false;
     if (N == 0) {
         PK_HIP(hipMemsetAsync(cd->n_out_dev, 0, sizeof(int64_t), ctx->stream));
         return PK_OK;
     }
     pk_prof_scope prof(ctx, PK_K_COMPACT);
+    if (reply_packed && N <= CS_MAX_N && batch >= 64 && (N + batch - 1) / batch <= CS_MAX_BATCHES && cd->opt.compact_small) {
+        PK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(compact_small_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)CS_LDS));
+        hipLaunchKernelGGL(compact_small_kernel, dim3(1), dim3(1024), CS_LDS, ctx->stream, cd->status, cd->prob, batch,
+                           thre, (int)N, cd->x, cd->y, m->band, m->ld, m->dlo, m->dhi, cd->ox, cd->oy, cd->op, cd->osig,
+                           cd->n_out_dev, cd->batch_cnt, ctx->dbg_buf + 65533, ctx->d_ret, with_records,
+                           ctx->split_cnt, ctx->split_cnt ? ctx->split_k : 0);
+        PK_HIP(hipGetLastError());
+        *reply_packed = true;
+        return PK_OK;
+    }
     const int64_t nb = (N + batch - 1) / batch;
     PK_HIP(hipMemsetAsync(cd->batch_cnt, 0, sizeof(int32_t) * (size_t)nb, ctx->stream));
     hipLaunchKernelGGL(batch_count_kernel,

@@ -396,6 +396,34 @@ def test_cut_forest_gives_up_where_nobody_is_decided(config2):
     assert cd.run(c["hm"], hf, w, 0.9) >= 0 and hf.get_option("stat_split_group") > 0
 
 
+def test_short_lists_take_one_launch_behind_the_forest(config2):
+    """Lists of up to 2^14 candidates: batch rule, p > thre, ordered compaction and the reply of the call
+    in ONE single-workgroup launch (compact_small_kernel) -- the same pixels as the four kernels of long
+    lists, for lengths around a 64-candidate group and the 2^14 limit, batches that cut groups in two and
+    thresholds that keep everything or almost nothing; through pk_score_run and through pk_score (whose
+    pixels come back inside the reply)."""
+    c = config2
+    w = c["w"]
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 63, 64, 65, 1000, 4097, 16383, 16384, 16385):
+        sel = np.sort(rng.choice(c["x"].size, n, replace=False))
+        x, y = c["x"][sel], c["y"][sel]
+        for batch in (64, 97, 5000, 100000):
+            for thre in (0.0, 0.02, 0.5):
+                got = {}
+                for small in (1, 0):
+                    cd = _lib.HipCands(x, y, options={"compact_small": small})
+                    k = cd.run(c["hm"], c["hf"], w, thre, batch)
+                    got[small] = (k, digest(*cd.fetch()))
+                    cd.close()
+                assert got[1] == got[0], (n, batch, thre)
+                with handle_options({"compact_small": 1}, c["hm"]):
+                    a = digest(*c["hm"].score(c["hf"], w, thre, x, y, batch=batch))
+                with handle_options({"compact_small": 0}, c["hm"]):
+                    b = digest(*c["hm"].score(c["hf"], w, thre, x, y, batch=batch))
+                assert a == b == got[0][1], (n, batch, thre)
+
+
 def test_extract_and_predict_across_chunks(config2):
     """pk_extract (65 536-candidate staging chunks) and pk_predict (512 k chunks)
     on inputs larger than one chunk: survivor order and sampled values vs the oracle."""

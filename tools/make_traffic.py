@@ -47,8 +47,9 @@ def kclass(name):
         if not m or m.group(1) == "true":
             return None
         return {"0": "forest_full", "1": "forest", "2": "forest_tail"}[m.group(2)]
-    if "forest_q2_kernel" in n:
-        return "forest"
+    if "forest_q2_kernel" in n:   # forest_q2_kernel<SPLIT>
+        m = re.search(r"forest_q2_kernel<(\d)>", n)
+        return {"0": "forest_full", "1": "forest", "2": "forest_tail"}[m.group(1)] if m else "forest"
     if "forest_q_kernel" in n:
         # forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>: the full evaluation is PRUNE = false AND
         # EARLY = false (`<..., true, false>` -- the early-exit extra pass -- also ends in "false>")
