@@ -287,11 +287,11 @@ def test_early_exit_same_pixels(config2, thre):
         assert np.all(same) or thre > 0.0
 
 
-@pytest.mark.parametrize("thre,n,prunes", [(0.5, 1_500_000, True), (0.9, 1_500_000, True), (0.9, 300_000, False),
+@pytest.mark.parametrize("thre,n,prunes", [(0.5, 1_500_000, True), (0.9, 1_500_000, True), (0.9, 200_000, False),
                                            (0.6, 1_500_000, True), (0.2, 1_500_000, False)])
 def test_permission_to_stop_early_is_used_where_it_pays(config2, thre, n, prunes):
     """pk_cands_set_prune ALLOWS the early exit (what Chromosome.score sets); the library applies it
-    where it pays: launches of at least 2^19 candidates are cut in two at a tree-group boundary (from
+    where it pays: launches of at least 2^18 candidates are cut in two at a tree-group boundary (from
     the default threshold 0.5 on: tools/cut_ab.py), shorter ones run whole (profiles/r05_prune_ab.log).
     The scored pixels never depend on it."""
     c = config2

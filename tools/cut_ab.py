@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--band", type=int, default=200)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--forest", default=None)
+    ap.add_argument("--min", type=int, default=0, help="forest_split_min (0: the library's default)")
     a = ap.parse_args()
     w = a.w
     L = _lib.require_device()
@@ -59,7 +60,7 @@ def main():
         x, y = x[:a.n], y[:a.n]
     fo = bench.load_forest(a.forest, w, (2 * w + 1) ** 2)
     hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, Mf.shape[0], e, -2 * w + 1, upper + 2 * w - 1)
-    hf = _lib.HipForest(fo)
+    hf = _lib.HipForest(fo, options={"forest_split_min": a.min} if a.min else None)
     print("w=%d  %d candidates, %d trees" % (w, x.size, fo.tree_off.size - 1), flush=True)
     for thre in [float(t) for t in a.thre.split(",")]:
         # the reference: no permission, every candidate's probability
