@@ -362,6 +362,15 @@ def test_cut_forest_scores_the_same_pixels(config2, w, nan_diag):
         cd2.close()
     assert parked[1] > parked[late] >= parked[n_grp - 1]   # the later the cut, the fewer are open
     assert parked[1] >= int((st != 0).sum())                       # (after 8 of 100 trees nobody is decided at 0.5)
+    # the float tiles made piece by piece (sub_chunk), or two tile buffers with the extractor of the next chunk
+    # beside the forest (overlap: no cut then -- the parked candidates live in the chunk's dead float tiles)
+    hf.set_option("forest_split_at", 0)
+    for extra, cut_expected in (({"sub_chunk": 131072}, True), ({"overlap": 1}, False)):
+        cd4 = _lib.HipCands(x, y, options=dict({"chunk": 500_000}, **extra))
+        cd4.set_prune(True)
+        assert cd4.run(hm, hf, w, thre) == n1 and digest(*cd4.fetch()) == base
+        assert (hf.get_option("stat_split_group") > 0) == cut_expected, extra
+        cd4.close()
     # the permission withdrawn: one launch, every probability
     hf.set_option("forest_split_at", 0)
     cd3 = _lib.HipCands(x, y, options={"chunk": 500_000})
