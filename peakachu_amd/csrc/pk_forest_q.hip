@@ -347,16 +347,115 @@ constexpr int Q_THREADS = 1024;
 struct q_slot_table {
     int off[16];  // EARLY: LDS offset (relative to img_off) of the tree slot of each wave pair
 };
-template <int CH, int WPT, int HALF1, bool PRUNE, bool EARLY>
+struct qr_split_args {
+    unsigned *cnt;
+    int32_t *idx;
+    double *acc;
+    uint8_t *st;
+    unsigned short *tiles;
+    double rem;
+};
+
+// The parking of a cut forest's head (see forest_qr_kernel, where the same steps are written out between
+// its stamps) for the generic shapes: C = 64 * CH candidates per workgroup, rank tiles of 128 candidates
+// (CH = 2, 4) or 64 (CH = 1).  Called by every thread behind the barrier that follows the last group's
+// sums; `list` = C + 2 ints of LDS nobody else uses (the early-exit flags' place); leaves behind a
+// barrier after which the tile may be overwritten.
+template <int CH, int HALF1>
+__device__ __forceinline__ void q_park_tile(const int tid, const int lane, const int wave, const bool owner,
+                                            const bool valid, const bool active, const double acc, const unsigned st,
+                                            const int64_t local, const int64_t c0, const int F, const unsigned list,
+                                            const qr_split_args &sp, const double prune_sum, double *__restrict__ prob,
+                                            unsigned &pk_at, unsigned &pk_end)
+{
+    constexpr int C = 64 * CH;
+    const unsigned pk_cnt = list + 4u * C, pk_new = pk_cnt + 4u;
+    bool open = false;
+    unsigned my_i = 0;
+    if (owner) {  // (whole waves: C is a multiple of 64)
+        open = valid && active && !((acc + sp.rem) * (1.0 + 1e-12) < prune_sum);
+        const unsigned long long m = __ballot(open);
+        if (m != 0ull) {
+            unsigned pos = 0;
+            if (lane == 0) pos = __hip_atomic_fetch_add(LDS_AT(lds_i32, pk_cnt), (int)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pos = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+            my_i = pos + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (open) *LDS_AT(lds_i32, list + 4u * my_i) = tid;  // its place in the workgroup's tile(s)
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS only: see forest_qr_kernel)
+    const unsigned P = (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_cnt));
+    if (P != 0u) {  // (uniform)
+        const unsigned room = pk_end - pk_at;
+        unsigned new_base = 0;
+        if (P > room) {  // (uniform) a new block of 256 slots
+            if (tid == 0) *LDS_AT(lds_i32, pk_new) = (int)atomicAdd(sp.cnt, 256u);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            new_base = (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_new));
+        }
+        if (open) {
+            const unsigned s = my_i < room ? pk_at + my_i : new_base + (my_i - room);
+            sp.idx[s] = (int32_t)local;
+            sp.acc[s] = acc;
+            sp.st[s] = (uint8_t)st;
+        }
+        for (unsigned i0 = 0; i0 < P; i0 += 64u) {
+            const unsigned pc = P - i0 < 64u ? P - i0 : 64u;
+            const unsigned sh = pc <= 1u ? 0u : 32u - (unsigned)__builtin_clz(pc - 1u);
+            const unsigned ci = (unsigned)lane & ((1u << sh) - 1u), rsub = (unsigned)lane >> sh;
+            const int rows = 64 >> sh;
+            if (ci < pc) {
+                const unsigned i = i0 + ci;
+                const int cand = *LDS_AT(const lds_i32, list + 4u * i);
+                const unsigned s = i < room ? pk_at + i : new_base + (i - room);
+                unsigned src, rstride;
+                unsigned short *dst;
+                size_t dstride;
+                if (CH == 1) {  // [F][64] u16
+                    src = (unsigned)(cand & 63) << 1;
+                    rstride = 128u;
+                    dst = sp.tiles + (size_t)(s >> 6) * (size_t)F * 64u + (s & 63u);
+                    dstride = 64u;
+                } else {        // [F][64][2] u16, the second 128 candidates at HALF1
+                    src = (cand >= 128 ? (unsigned)HALF1 : 0u) + ((unsigned)(cand & 63) << 2) + ((unsigned)((cand >> 6) & 1) << 1);
+                    rstride = 256u;
+                    dst = sp.tiles + (size_t)(s >> 7) * (size_t)F * 128u + ((s & 63u) << 1) + ((s >> 6) & 1u);
+                    dstride = 128u;
+                }
+                for (int r0 = wave * rows; r0 < F; r0 += 16 * rows) {
+                    const int r = r0 + (int)rsub;
+                    if (r < F) dst[(size_t)r * dstride] = *LDS_AT(const lds_u16, src + (unsigned)r * rstride);
+                }
+            }
+        }
+        if (P > room) {
+            pk_at = new_base + (P - room);
+            pk_end = new_base + 256u;
+        } else {
+            pk_at += P;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the codes are read
+    if (tid == 0) *LDS_AT(lds_i32, pk_cnt) = 0;
+    if (valid && !open) prob[c0 + local] = 0.0;
+}
+
+template <int CH, int WPT, int HALF1, bool PRUNE, bool EARLY, int SPLIT = 0>
 __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp,
     const int4 *__restrict__ ttab, int T, int t_div, int F, int dec_off, int val_off, int img_off,
     const q_slot_table slots_at,
     const unsigned short *__restrict__ qtiles, const uint8_t *__restrict__ status, int64_t c0,
-    int64_t cn, double *__restrict__ prob, double prune_sum, int warm_ahead, int dbg,
-    long long *__restrict__ stamps)
+    int64_t cn_arg, double *__restrict__ prob, double prune_sum, int warm_ahead, int dbg,
+    long long *__restrict__ stamps, qr_split_args sp)
 {
+    static_assert(SPLIT == 0 || (!PRUNE && !EARLY), "the cut forest decides at the cut, not inside the kernel");
     constexpr int THREADS = Q_THREADS;
+    // (SPLIT, the forest cut in two -- see forest_qr_kernel: 1 = head, parks the open candidates behind its
+    // last group; 2 = tail over the parked ones)
+    const int64_t cn = SPLIT == 2 ? (int64_t)__builtin_amdgcn_readfirstlane((int)*sp.cnt) : cn_arg;
+    const int64_t sc0 = SPLIT == 2 ? 0 : c0;
+    [[maybe_unused]] unsigned pk_at = 0, pk_end = 0;
     constexpr int C = 64 * CH;
     constexpr int PFN = 8;  // staging registers: 8 x 1024 x 16 B = 128 KiB per group (pk_q_stage_regs)
     constexpr int NCH = CH / WPT;  // walks per lane of one wave
@@ -392,6 +491,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         if (PRUNE)
             for (int i = tid; i < C + 3; i += THREADS) *LDS_AT(lds_i32, dec_off + 4 * i) = 0;
         if (EARLY && tid < 8) *LDS_AT(lds_i32, done_off + 4 * tid) = 0;
+        if (SPLIT == 1 && wg == (int64_t)blockIdx.x && tid == 0) *LDS_AT(lds_i32, dec_off + 4 * C) = 0;  // parked in this tile
         const int64_t cbase = wg * C;  // first candidate of this workgroup (relative to c0)
         if (!tile_ready) {
             // rank tiles of 128 candidates each, consecutive in memory; the second one exists
@@ -411,7 +511,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int64_t loc = cbase + lane + 64 * (NCH * sub + c);
-            stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[c0 + loc] : 0);
+            stc[c] = tile_ready ? stc_n[c] : (loc < cn ? status[sc0 + loc] : 0);
             act[c] = stc[c] != 0 && lds_at_zero;
             any_nan = any_nan || stc[c] == 2;
         }
@@ -420,7 +520,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
         const bool owner = tid < C;
         const int64_t local = cbase + tid;
         const bool valid = owner && local < cn;
-        const unsigned st = tile_ready ? st_n : (valid ? status[c0 + local] : 0);
+        const unsigned st = tile_ready ? st_n : (valid ? status[sc0 + local] : 0);
         const bool active = st != 0 && lds_at_zero;
         const int64_t wg_next = wg + gridDim.x;
         bool fetched = false;  // (uniform) tile_u / stc_n / st_n hold the next tile
@@ -458,6 +558,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             stamps[((tid >> 6) * 32 + g) * 5 + (slot_)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
         double acc = 0.0;
+        if constexpr (SPLIT == 2)
+            if (valid) acc = sp.acc[local];  // the head's trees, already added in order
         unsigned warm_sink = 0;
         for (int g = 0; g < n_grp; g++) {  // uniform: every thread takes the same trips
             const int t0 = g_cur.x, gt = g_cur.y;
@@ -499,9 +601,9 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     const int64_t loc = cb + lane + 64 * (NCH * sub + c);
-                    stc_n[c] = loc < cn ? status[c0 + loc] : 0;
+                    stc_n[c] = loc < cn ? status[sc0 + loc] : 0;
                 }
-                st_n = (owner && cb + tid < cn) ? status[c0 + cb + tid] : 0;
+                st_n = (owner && cb + tid < cn) ? status[sc0 + cb + tid] : 0;
                 fetched = true;
             } else if (warm_ahead > 0 && gridDim.x >= n_wg) {
                 // last group: pull the tiles of the workgroup that follows this one on this XCD
@@ -617,7 +719,14 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             tt = tt_nxt;
             if (all_done) break;
         }
-        if (valid) prob[c0 + local] = active ? acc / (double)t_div : 0.0;  // (t_div: the model's trees; T: the image's pieces)
+        if constexpr (SPLIT == 1) {
+            q_park_tile<CH, HALF1>(tid, lane, wave, owner, valid, active, acc, st, local, c0, F, (unsigned)dec_off, sp,
+                                   prune_sum, prob, pk_at, pk_end);
+        } else if constexpr (SPLIT == 2) {
+            if (valid && active) prob[c0 + sp.idx[local]] = acc / (double)t_div;  // (status 0: a slot nobody took)
+        } else {
+            if (valid) prob[c0 + local] = active ? acc / (double)t_div : 0.0;  // (t_div: the model's trees; T: the image's pieces)
+        }
         if (warm_sink == 0x9e3779b9u && stamps) stamps[65534] = 1;  // keeps the warm-ahead loads alive
         tile_ready = fetched;
         if (fetched) {  // every walk of this tile is behind the last barrier: its rank tiles can go
@@ -637,6 +746,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #undef Q_TILE_STORE
         }
     }
+    if constexpr (SPLIT == 1)  // what is left of the last block: nobody
+        for (unsigned i = pk_at + threadIdx.x; i < pk_end; i += THREADS) sp.st[i] = 0;
 #undef Q_STAMP
 }
 
@@ -1094,8 +1205,14 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
         if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && fetched)             \
             stamps[((tid >> 6) * 32 + 30) * 5 + (k_)] = (long long)__builtin_amdgcn_s_memtime(); \
     } while (0)
+#define QR_PSTAMP2(k_)                                                                   \
+    do {                                                                                 \
+        if ((dbg & 16) && stamps && blockIdx.x == 0 && lane == 0 && fetched)             \
+            stamps[((tid >> 6) * 32 + 29) * 5 + (k_)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
 #else
 #define QR_PSTAMP(k_) do {} while (0)
+#define QR_PSTAMP2(k_) do {} while (0)
 #endif
             QR_PSTAMP(0);
             bool decided = false, open = false;
@@ -1124,12 +1241,14 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
                     QR_LDS_BARRIER();
                     new_base = (unsigned)__builtin_amdgcn_readfirstlane(*LDS_AT(const lds_i32, pk_new));
                 }
+                QR_PSTAMP2(0);   // (P read, block reserved)
                 if (open) {
                     const unsigned s = my_i < room ? pk_at + my_i : new_base + (my_i - room);
                     A.s_idx[s] = (int32_t)local;
                     A.s_acc[s] = acc;
                     A.s_st[s] = (uint8_t)st;
                 }
+                QR_PSTAMP2(1);   // (owners' stores issued)
                 // A store INSTRUCTION costs the CU's address unit the same 16+ cycles whether ten of its lanes
                 // are live or sixty-four (stamps, round 5: 128 of them per tile -- sixteen waves x eight rows,
                 // ten parked candidates each -- took 4 000 cycles).  So the lanes are filled: the candidates of
@@ -1153,6 +1272,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
                         }
                     }
                 }
+                QR_PSTAMP2(2);   // (codes copied)
                 if (P > room) {
                     pk_at = new_base + (P - room);
                     pk_end = new_base + 256u;
@@ -1199,14 +1319,6 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 #undef QR_STAMP
 }
 
-struct qr_split_args {
-    unsigned *cnt;
-    int32_t *idx;
-    double *acc;
-    uint8_t *st;
-    unsigned short *tiles;
-    double rem;
-};
 template <int HALF1, bool PRUNE, int NR, int SPLIT>
 __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGPRS))) void forest_qr_kernel(
     const v4u *__restrict__ img, const int4 *__restrict__ gtab, int n_grp, const int4 *__restrict__ ttab, int T,
@@ -1788,24 +1900,37 @@ int pk_forest_q_plan(pk_forest *f)
     return f->q_state == 1 ? PK_OK : PK_E_UNSUPPORTED;
 }
 
-#define Q_LAUNCH_P(CH, WPT, HALF1, PRUNE, EARLY)                                               \
+#define Q_LAUNCH_PS(CH, WPT, HALF1, PRUNE, EARLY, SPLIT_, GTAB_, NGRP_, TILES_, STATUS_, CN_, PSUM_)  \
     do {                                                                                       \
-        int rc__ = q_set_max_lds(forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>, 163840);       \
+        int rc__ = q_set_max_lds(forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY, SPLIT_>, 163840); \
         if (rc__) return rc__;                                                                 \
-        hipLaunchKernelGGL((forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY>), dim3(grid), dim3(Q_THREADS), \
+        hipLaunchKernelGGL((forest_q_kernel<CH, WPT, HALF1, PRUNE, EARLY, SPLIT_>), dim3(grid), dim3(Q_THREADS), \
                            163840, ctx->stream, reinterpret_cast<const v4u *>(f->q_img),       \
-                           reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp,              \
+                           GTAB_, NGRP_,                                                       \
                            reinterpret_cast<const int4 *>(f->q_ttab), f->q_T, f->T, f->q_F, L.dec_off,   \
-                           L.val_off, L.img_off, slots_at, ctx->q_tiles, d_status, c0,         \
-                           cn, d_prob,                                                         \
-                           prune_sum,                                                          \
+                           L.val_off, L.img_off, slots_at, TILES_, STATUS_, c0,                \
+                           CN_, d_prob,                                                        \
+                           PSUM_,                                                              \
                            persist ? (int)grid : f->opt.forest_warm == 1 ? ctx->cu_count : (int)f->opt.forest_warm, \
-                           (int)f->opt.forest_dbg | (f->opt.forest_q_prio ? 0 : 32), ctx->dbg_buf);  \
+                           (int)f->opt.forest_dbg | (f->opt.forest_q_prio ? 0 : 32), ctx->dbg_buf, gsp);  \
     } while (0)
+#define Q_LAUNCH_P(CH, WPT, HALF1, PRUNE, EARLY)                                               \
+    Q_LAUNCH_PS(CH, WPT, HALF1, PRUNE, EARLY, 0, reinterpret_cast<const int4 *>(f->q_gtab), f->q_n_grp, ctx->q_tiles, \
+                d_status, cn, prune_sum)
 #define Q_LAUNCH(CH, WPT, HALF1, EARLY)                                                        \
     do {                                                                                       \
         if (prune_sum > -1e300) Q_LAUNCH_P(CH, WPT, HALF1, true, EARLY);                       \
         else Q_LAUNCH_P(CH, WPT, HALF1, false, EARLY);                                         \
+    } while (0)
+// the generic shapes cut in two (never with early staging): head, then the tail over the parked candidates
+#define Q_LAUNCH_CUT(CH, WPT, HALF1)                                                           \
+    do {                                                                                       \
+        Q_LAUNCH_PS(CH, WPT, HALF1, false, false, 1, reinterpret_cast<const int4 *>(f->q_gtab), gcut, ctx->q_tiles, \
+                    d_status, cn, split_sum);                                                  \
+        PK_HIP(hipGetLastError());                                                             \
+        pk_prof_scope prof_tail(ctx, PK_K_FOREST_TAIL);                                        \
+        Q_LAUNCH_PS(CH, WPT, HALF1, false, false, 2, reinterpret_cast<const int4 *>(f->q_gtab) + gcut, f->q_n_grp - gcut, \
+                    gsp.tiles, gsp.st, (int64_t)0, split_sum);                                 \
     } while (0)
 
 // Room for the rank tiles of `cn` candidates (scratch of the context; grows only).
@@ -1951,6 +2076,41 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     // rows of 16 KiB of the largest group: forest_qr_kernel loads that many without looking
     const int rows = (f->q_max_group_bytes + 16383) / 16384;
     f->last_cut = 0;
+    // the cut for the generic kernel (forest_q_kernel; decided here, used only if that kernel is launched)
+    int gcut = 0;
+    qr_split_args gsp{};
+    const bool qr_shape = L.ch == 4 && wpt2 && !early && (f->opt.forest_q_rsv & 1) && !(f->opt.forest_dbg & (8 | 32)) &&
+                          (L.half1 == 32768 || L.half1 == 49152) && rows <= 5;
+    const bool q2_shape = L.ch == 1 && f->opt.forest_q_two && cn > 64 && f->q_F <= 639 && f->q_max_group_bytes <= 6 * 16384;
+    if (!qr_shape && !q2_shape && !early && split_sum > -1e300 && f->opt.forest_split && scratch &&
+        cn >= f->opt.forest_split_min && ctx->split_k < PK_SPLIT_SLOTS && (L.ch == 1 || L.ch == 2 || L.ch == 4))
+        gcut = q_pick_cut(f, split_sum);
+    if (gcut > 0) {
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t per_tile = L.ch == 1 ? 64 : 128;
+        const size_t cap = (size_t)cn + 256u * (size_t)grid + 256u;
+        const size_t tiles_b = up((cap + per_tile - 1) / per_tile * f->q_F * per_tile * sizeof(unsigned short) + PK_Q_PAD_BYTES);
+        const size_t acc_b = up(cap * 8), idx_b = up(cap * 4), st_b = up(cap);
+        if (tiles_b + acc_b + idx_b + st_b > scratch_bytes) {
+            gcut = 0;
+        } else {
+            if (!ctx->split_cnt) {
+                PK_HIP(hipMalloc((void **)&ctx->split_cnt, PK_SPLIT_SLOTS * sizeof(unsigned)));
+                ctx->split_k = 0;
+            }
+            if (ctx->split_k == 0)
+                PK_HIP(hipMemsetAsync(ctx->split_cnt, 0, PK_SPLIT_SLOTS * sizeof(unsigned), ctx->stream));
+            char *b = static_cast<char *>(scratch);
+            gsp.tiles = reinterpret_cast<unsigned short *>(b);
+            gsp.acc = reinterpret_cast<double *>(b + tiles_b);
+            gsp.idx = reinterpret_cast<int32_t *>(b + tiles_b + acc_b);
+            gsp.st = reinterpret_cast<uint8_t *>(b + tiles_b + acc_b + idx_b);
+            gsp.cnt = ctx->split_cnt + ctx->split_k++;
+            ctx->split_n += cn;
+            gsp.rem = (double)f->q_T - (double)f->q_gtab_h[4 * (size_t)gcut];
+            f->last_cut = gcut;
+        }
+    }
     if (L.ch == 4 && wpt2 && !early && (f->opt.forest_q_rsv & 1) && !(f->opt.forest_dbg & (8 | 32)) &&
         (L.half1 == 32768 || L.half1 == 49152) && rows <= 5) {
         // the cut: allowed by the caller (split_sum = thre * T: the run may leave decided candidates at
@@ -2050,16 +2210,21 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
     } else if (L.ch == 4 && L.half1 == 32768) {
         f->last_family = 2;
         if (early) Q_LAUNCH(4, 2, 32768, true);
+        else if (gcut > 0 && wpt2) Q_LAUNCH_CUT(4, 2, 32768);
+        else if (gcut > 0) Q_LAUNCH_CUT(4, 1, 32768);
         else if (wpt2) Q_LAUNCH(4, 2, 32768, false);
         else Q_LAUNCH(4, 1, 32768, false);
     } else if (L.ch == 4 && L.half1 == 49152) {
         f->last_family = 2;
         if (early) Q_LAUNCH(4, 2, 49152, true);
+        else if (gcut > 0 && wpt2) Q_LAUNCH_CUT(4, 2, 49152);
+        else if (gcut > 0) Q_LAUNCH_CUT(4, 1, 49152);
         else if (wpt2) Q_LAUNCH(4, 2, 49152, false);
         else Q_LAUNCH(4, 1, 49152, false);
     } else if (L.ch == 2) {
         f->last_family = 2;
-        Q_LAUNCH(2, 1, 32768, false);
+        if (gcut > 0) Q_LAUNCH_CUT(2, 1, 32768);
+        else Q_LAUNCH(2, 1, 32768, false);
     } else if (L.ch == 1 && f->opt.forest_q_two && cn > 64 && f->q_F <= 639 && f->q_max_group_bytes <= 6 * 16384) {
         // two rank tiles per trip (see forest_q2_kernel); the waves that walk load their share of
         // the next group behind the first walk (option forest_q_help, on).  The kernel has no early
@@ -2122,7 +2287,8 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
 #undef Q2_LAUNCH
     } else if (L.ch == 1) {
         f->last_family = 2;
-        Q_LAUNCH(1, 1, 32768, false);
+        if (gcut > 0) Q_LAUNCH_CUT(1, 1, 32768);
+        else Q_LAUNCH(1, 1, 32768, false);
     } else {
         pk_set_error("forest rank kernel: layout not instantiated");
         return PK_E_INVALID;

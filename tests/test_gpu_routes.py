@@ -66,5 +66,62 @@ def test_model_reaches_its_kernel_family(hip_lib, what, make, family, word):
     hf.close()
 
 
+CUT_ROUTES = [r for r in ROUTES if r[2] in (QR, Q, Q2)]
+
+
+@pytest.mark.parametrize("what,make,family,word", CUT_ROUTES, ids=[r[0][:40] for r in CUT_ROUTES])
+def test_rank_kernel_families_cut_in_two(hip_lib, what, make, family, word):
+    """The forest cut in two (head over every candidate, the open ones parked, tail over those) on every
+    shape of the rank kernels -- forest_qr_kernel, the generic forest_q_kernel with 256 / 128 / 64
+    candidates per workgroup, the two-tile forest_q2_kernel: scoring a band's candidates with the cut
+    forced in front of groups 1 and 2 (and wherever the library puts it) gives the one-launch run's pixels
+    bit for bit (Chromosome.score's body, peakachu/scoreUtils.py:95-125)."""
+    import hashlib
+    from peakachu_amd import synth, utils
+    flat = make()
+    w = int(round((flat.F ** 0.5 - 1) / 2))
+    assert (2 * w + 1) ** 2 == flat.F
+    n, band, upper = 2500, 120, 100
+    M, _ = synth.synth_band(n, band, seed=3)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    hm = _lib.HipMatrix(Mf.indptr, Mf.indices, Mf.data, n, e, -2 * w + 1, upper + 2 * w - 1)
+    hf = _lib.HipForest(flat, options={"forest_split_min": 1})
+
+    def dig(cd):
+        h = hashlib.sha256()
+        for a in cd.fetch():
+            h.update(np.ascontiguousarray(a).tobytes())
+        return h.hexdigest()
+
+    thre = 0.5
+    cd = _lib.HipCands(x, y)
+    n0 = cd.run(hm, hf, w, thre)
+    base = dig(cd)
+    st0, pr0 = cd.fetch_all()
+    assert FAMILY[hf.get_option("stat_family")] == FAMILY[family], what
+    assert hf.get_option("stat_split_group") == 0
+    n_grp = hf.get_option("stat_q_groups")
+    for at in (1, 2, 0):
+        if at >= n_grp:
+            continue
+        hf.set_option("forest_split_at", at)
+        cd2 = _lib.HipCands(x, y)
+        cd2.set_prune(True)
+        assert cd2.run(hm, hf, w, thre) == n0 and dig(cd2) == base, (what, at)
+        if at:
+            # (the parked candidates live in the chunk's dead float tiles, 4 F bytes per candidate: a rank tile
+            # of two rows per feature -- 20 000-node trees -- does not fit there and the launch stays whole)
+            fits = hf.get_option("stat_q_rows") * 2 + 16 < flat.F * 4
+            assert hf.get_option("stat_split_group") == (at if fits else 0), (what, at)
+        st, pr = cd2.fetch_all()
+        same = pr.view(np.uint64) == pr0.view(np.uint64)
+        assert np.array_equal(st, st0) and np.all(same | (pr == 0.0)) and np.all(pr0[~same] <= thre), (what, at)
+        cd2.close()
+    hf.close()
+    hm.close()
+
+
 def test_every_family_is_reached():
     assert {r[2] for r in ROUTES} == set(FAMILY) - {0}

@@ -79,6 +79,11 @@ if os.environ.get("PK_STAMP_CUT") and park[:, 0].all() and park[:, 4].all():
     d = np.diff(park, axis=1)
     print("parking (head of the cut forest), cycles per wave: owners' list %s | wait at barrier 1 %s | copy %s | wait at barrier 2 %s"
           % tuple(np.round(d[:, k]).astype(int).tolist() for k in range(4)))
+    p2 = buf.reshape(16, 32, 5)[:, 29, :].astype(np.float64)
+    if p2[:, 0].all() and p2[:, 2].all():
+        print("   inside `copy`: count read + block %s | owners' records %s | codes %s | rest %s" % (
+            np.round(p2[:, 0] - park[:, 2]).astype(int).tolist(), np.round(p2[:, 1] - p2[:, 0]).astype(int).tolist(),
+            np.round(p2[:, 2] - p2[:, 1]).astype(int).tolist(), np.round(park[:, 3] - p2[:, 2]).astype(int).tolist()))
 if tile[:, 0].all() and tile[:, 3].all():
     # (stamp 4 is taken at the START of a trip: the one stored last belongs to the trip whose end
     # stamps 0-3 describe only when that trip was not the workgroup's last one)
