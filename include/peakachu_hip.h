@@ -151,7 +151,7 @@ void pk_cands_destroy(pk_cands *);
  * walking the forest once its sum can no longer exceed thre * T (every remaining tree adds at most
  * 1.0).  The scored pixels are identical; pk_score_fetch_all reports 0 for a candidate that was
  * stopped.  The library uses the permission where it pays:
- *   - launches of at least 2^18 candidates on the default rank kernels (forest_qr_kernel,
+ *   - launches of at least 2^18 candidates on the rank kernels (forest_qr_kernel, forest_q_kernel,
  *     forest_q2_kernel) are CUT IN TWO at a tree-group boundary -- the head walks the groups in front
  *     of the cut over every candidate and parks the ones still open (partial sum, rank codes), the
  *     tail walks the rest over the parked ones only, sums continued in tree order.  From the default
