@@ -73,8 +73,11 @@ int pk_ctx_reserve_scan(pk_device_ctx *, size_t bytes);
 
 // ------------------------------------------------------------------ options
 struct pk_options {
-    int64_t chunk = 2097152;    // candidates per extract/forest launch pair (1 GB of tiles at w=5; measured
-                                // 524 288: 8.82 ms, 1 M: 8.66 ms, 2 M: 8.58 ms per step of config 2)
+    int64_t chunk = 3145728;    // candidates per extract / quantize / forest launch (1.5 GB of float tiles at w = 5).
+                                // Measured, ms per step of config 2: round 2 -- 524 288: 8.82, 1 M: 8.66, 2 M: 8.58;
+                                // round 5 (cut forest) -- 2 M: 4.27, 2.8 M: 4.21, 3 M: 4.18, 4 M: 4.20 (w = 6: 7.36,
+                                // -, 7.29, 10.3: beyond 3.17 M candidates a launch's float tiles pass the 2 GiB of
+                                // the clean extractor's 32-bit offsets)
     int64_t forest_ilp = 4;     // L2 kernel: trees walked concurrently per lane
     int64_t forest_slots = 0;   // LDS kernel: tree slots (wave pairs) per workgroup; 0 = as many as
                                 // average trees fit beside the tile (8 at w=5, 7 at w=6)
