@@ -794,9 +794,12 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #define PK_QR_SPREAD 1             // issue slots per pair of levels from there on (0: all at once)
 #endif
 
-// A barrier that orders LDS accesses only.  __syncthreads() also waits for every global access of the wave
-// to be acknowledged (s_waitcnt vmcnt(0) in front of s_barrier): at the top of a tile that is the previous
-// tile's probability stores, which nobody in the workgroup reads -- thousands of cycles per tile.
+// A barrier that orders LDS accesses only (the parking of the cut forest's head).  __syncthreads() also
+// waits for every global access of the wave to be acknowledged (s_waitcnt vmcnt(0) in front of s_barrier):
+// in the parking that is the tile's probability and record stores, which nobody in the workgroup reads --
+// 4 000 cycles per tile.  (At the TOP of a tile the same exchange changed nothing: there the stores have had
+// the tile's LDS commits to be acknowledged behind -- same-box A/B, 2.811 vs 2.809 ms -- and __syncthreads()
+// stays.)
 #ifndef PK_QR_RAWBAR
 #define PK_QR_RAWBAR 1
 #endif
