@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
     ("fuzz_score", 300, 50502),        # Chromosome.score's body: w = 1..15, dirty matrices, batch sizes, options
     ("fuzz_chromosome", 150, 50503),   # Chromosome.__init__ + score: raw / balanced / hic-style, device-side preparation
     ("fuzz_getwindow", 500, 50504),    # getwindow at arbitrary coordinates
+    ("fuzz_cut", 40, 50505),           # the forest cut in two: every rank kernel, forced and learnt cuts, NaN features
 ])
 def test_fuzz_slice(hip_lib, monkeypatch, script, cases, seed):
     monkeypatch.syspath_prepend(FUZZ)
