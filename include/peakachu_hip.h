@@ -330,6 +330,14 @@ int pk_debug_forest_qimage(int T, int F, const int32_t *tree_off, const int32_t 
                            int64_t *n_pairs, int64_t cap_groups, int32_t *gtab,
                            int32_t *n_groups, int32_t *ttab, int32_t cap_rows, int32_t *qsrc);
 
+/* diagnostic, needs no device: where the library would cut a forest in two (pk_cands_set_prune above) and
+ * what it learns from its calls.  trees_in_front[g] = trees in front of tree group g (n_groups + 1 entries,
+ * the last one = trees of the image); split_sum = thre * T; frac_permille = option forest_split_frac.
+ * Simulates n_calls scoring calls of 1e6 candidates each: call i is cut in front of group cuts[i] (0: not
+ * cut) and leaves open_frac[i] of its candidates open, which the next call's cut takes into account. */
+int pk_debug_cut_policy(const int32_t *trees_in_front, int n_groups, double split_sum, int frac_permille,
+                        const double *open_frac, int n_calls, int32_t *cuts);
+
 #ifdef __cplusplus
 }
 #endif

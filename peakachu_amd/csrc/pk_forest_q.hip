@@ -2053,6 +2053,33 @@ void pk_forest_cut_feedback(pk_forest *f, int64_t candidates, int64_t parked, in
     else if (open > 0.15) f->cut_shift += 1;
 }
 
+// (include/peakachu_hip.h: the cut's policy without a device, for the CPU tests)
+extern "C" int pk_debug_cut_policy(const int32_t *trees_in_front, int n_groups, double split_sum, int frac_permille,
+                                   const double *open_frac, int n_calls, int32_t *cuts)
+{
+    if (!trees_in_front || n_groups < 1 || !cuts || n_calls < 0 || (n_calls > 0 && !open_frac)) {
+        pk_set_error("pk_debug_cut_policy: bad arguments");
+        return PK_E_INVALID;
+    }
+    pk_forest f{};
+    f.opt = pk_default_options();
+    f.opt.forest_split_at = 0;
+    f.opt.forest_split_frac = frac_permille;
+    f.q_n_grp = n_groups;
+    f.q_T = trees_in_front[n_groups];
+    f.q_gtab_h.assign((size_t)4 * (n_groups + 1), 0);
+    for (int g = 0; g <= n_groups; g++) f.q_gtab_h[(size_t)4 * g] = trees_in_front[g];
+    const int64_t candidates = 1000000;
+    for (int i = 0; i < n_calls; i++) {
+        const int cut = q_pick_cut(&f, split_sum);
+        cuts[i] = cut;
+        f.last_cut = cut;
+        // (one launch; the slots of the unfinished blocks the feedback takes off are put on top)
+        pk_forest_cut_feedback(&f, candidates, (int64_t)(open_frac[i] * (double)candidates) + 65536, 1);
+    }
+    return PK_OK;
+}
+
 int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_status, int64_t c0, int64_t cn,
                             double *d_prob, double prune_sum, double split_sum, void *scratch, size_t scratch_bytes)
 {
