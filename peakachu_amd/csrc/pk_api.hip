@@ -283,6 +283,9 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
         o.extract_pair = value != 0;
     } else if (!strcmp(name, "extract_row16")) {
         o.extract_row16 = value != 0;
+    } else if (!strcmp(name, "extract_diag")) {
+        if (value < 0 || value > 2) return PK_E_INVALID;
+        o.extract_diag = value;
     } else if (!strcmp(name, "forest_slots")) {
         if (value < 0 || value == 1 || value > 16) return PK_E_INVALID;
         o.forest_slots = value;
@@ -342,6 +345,7 @@ static int64_t opt_read(const pk_options &o, const char *name)
     if (!strcmp(name, "forest_slots")) return o.forest_slots;
     if (!strcmp(name, "extract_pair")) return o.extract_pair;
     if (!strcmp(name, "extract_row16")) return o.extract_row16;
+    if (!strcmp(name, "extract_diag")) return o.extract_diag;
     if (!strcmp(name, "extract_clean")) return o.extract_clean;
     if (!strcmp(name, "forest_warm")) return o.forest_warm;
     if (!strcmp(name, "overlap")) return o.overlap;
@@ -1099,6 +1103,21 @@ extern "C" void pk_matrix_destroy(pk_matrix *m)
 }
 
 // --------------------------------------------------------------- candidates
+// Are consecutive candidates of a host list rarely neighbours on a diagonal?  (get_candidate's lists hold one
+// band pixel in ~50; "every non-zero pixel of the band" lists are runs of neighbours.)  Looks at up to 8 192
+// pairs spread over the list.  Decides in which order the extractor's lanes issue their loads -- never a result.
+static int coords_scattered(int64_t N, const int32_t *x, const int32_t *y)
+{
+    if (N < 64 || !x || !y) return 0;
+    const int64_t step = N / 8192 > 0 ? N / 8192 : 1;
+    int64_t pairs = 0, next = 0;
+    for (int64_t i = 0; i + 1 < N; i += step) {
+        pairs++;
+        next += (x[i + 1] == x[i] + 1 && y[i + 1] == y[i] + 1) ? 1 : 0;
+    }
+    return next * 4 < pairs ? 1 : 0;
+}
+
 extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y)
 {
     PK_DEV_LOCK(device);
@@ -1132,6 +1151,7 @@ extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, co
         pk_cands_destroy(c);
         return nullptr;
     }
+    c->scattered = coords_scattered(N, x, y);
     return c;
 }
 
@@ -1258,6 +1278,7 @@ extern "C" pk_cands *pk_candidates_create(pk_matrix *raw, int lower, int upper,
              hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (ok) {
         out = cands_alloc(raw->device, h[0]);
+        if (out) out->scattered = 1;  // (the Poisson-filtered pixels of a band: one in tens)
         ok = out != nullptr;
     }
     if (ok && h[0] > 0)
@@ -1487,7 +1508,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
             for (int64_t s0 = 0; !rc && s0 < cn; s0 += sub) {
                 const int64_t sn = cn - s0 < sub ? cn - s0 : sub;
                 rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0 + s0, sn, tiles, blk, cd->status,
-                                       nullptr);
+                                       nullptr, false, cd->scattered > 0);
                 if (!rc) rc = pk_launch_quant_q(ctx, ctx->stream, f, tiles, s0 / 128, sn);
             }
             if (!rc)
@@ -1501,7 +1522,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
             continue;
         }
         rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0, cn, tiles, blk, cd->status,
-                               nullptr);
+                               nullptr, false, cd->scattered > 0);
         if (rc) return rc;
         if (overlap) {
             PK_HIP(hipEventRecord(ctx->ev_ext[buf], st_ext));
@@ -1726,6 +1747,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
         ctx->score_cands_cap = N;
     }
     cd->opt = m->opt;  // (a call without a candidate handle: the matrix handle's pipeline options)
+    cd->scattered = coords_scattered(N, x, y);
     cd->prune = 1;     // pk_score hands back the scored pixels only: what a decided candidate's probability reads is invisible
     rc = score_run_impl(m, f, cd, w, thre, batch, n_out, true);
     if (deferred) {

@@ -94,6 +94,8 @@ struct pk_options {
                                 // (measured: no gain -- kernels that share the chip slow each other down)
     int64_t extract_clean = 1;  // use the pre-divided band + shortcuts when the matrix qualifies
     int64_t extract_pair = 1;   // two lanes per candidate (w = 5, 6); 0 = one lane per candidate
+    int64_t extract_diag = 1;   // scattered candidate lists (w = 5, 6, clean matrices): a lane's loads in the order of its
+                                // window's diagonals (neighbours on a diagonal share a line of the band)
     int64_t extract_row16 = 1;  // w = 11 on clean matrices: four register-blocked windows per wave
     int64_t forest_warm = 1;    // last tree group: pull the tile of workgroup id + N into this XCD's L2
                                 // (0 = off, 1 = N = number of CUs: the workgroup that follows on this XCD)
@@ -421,6 +423,7 @@ struct pk_cands {
     int32_t *batch_cnt;    // device [n_batches] survivors per reference batch
     int64_t n_batches_cap;
     int prune;             // pk_cands_set_prune: exact early termination for this list's runs
+    int scattered;         // 1: consecutive candidates are rarely neighbours on a diagonal (get_candidate's lists)
     // pk_score (host buffers): coordinates still on the host; run_pipeline uploads chunk k + 1 on the
     // second stream while chunk k is being scored (nullptr: everything is on the device already)
     const int32_t *h_x = nullptr, *h_y = nullptr;
@@ -442,7 +445,8 @@ int pk_matrix_prepare_norm(pk_device_ctx *, pk_matrix *);
 int pk_extract_upload_taps(const double *taps5);  // into the current device's constant memory
 int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
-                      int blk, uint8_t *d_status, double *fea64_rows, bool any_coords = false);
+                      int blk, uint8_t *d_status, double *fea64_rows, bool any_coords = false,
+                      bool scattered = false);  // scattered: consecutive candidates are rarely neighbours
 
 // walk the forest over feature tiles of candidates [c0, c0+cn)
 // prune_sum: -inf (full evaluation) or thre*T: candidates whose sum provably cannot reach it

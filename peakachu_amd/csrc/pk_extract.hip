@@ -467,7 +467,14 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 // general one and with the CPU restatement of the reference.
 // ------------------------------------------------------------------------
 // (the body of the kernel, for wave `vblock` of `vgrid`)
-template <int W, bool FEA64>
+// DIAG (round 5, scattered candidate lists -- the list get_candidate makes holds one band pixel in ~50): a
+// lane's loads are issued DIAGONAL BY DIAGONAL of its window instead of column by column.  Neighbouring
+// cells of a window diagonal are neighbouring doubles of the diagonal-major band, i.e. the same 64-byte
+// line: requested back to back they hit the line the first of them fetched, twelve instructions apart
+// (column order, 64 lanes x 12 other lines in between) the CU's vector cache has long dropped it.  With
+// consecutive candidates in a wave (the benchmark lists) the lanes share their lines anyway and the column
+// order -- the order the column blur consumes -- stays.
+template <int W, bool FEA64, bool DIAG = false>
 __device__ __forceinline__ void extract_pair_clean_body(
     const unsigned vblock, const unsigned vgrid, const unsigned lane_id,
     const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
@@ -553,6 +560,32 @@ __device__ __forceinline__ void extract_pair_clean_body(
         // window -> wait at w = 6: two full latencies with nothing to do.)
         double tl[W][W];
         const bool want_tl = normalise && role == 0;
+        if constexpr (DIAG) {
+            // every load of a diagonal behind its neighbour on that diagonal (same line of the band)
+            if (want_tl) {
+#pragma unroll
+                for (int t = -(W - 1); t <= W - 1; t++) {
+#pragma unroll
+                    for (int i = 0; i < W; i++)
+                        if (i + t >= 0 && i + t < W) tl[i][i + t] = PK_CELL(raw0, i, i + t);
+                }
+            }
+            if (normalise)
+                centre = *reinterpret_cast<const double *>(bbase + (unsigned)(((int64_t)(d - dlo) * ld + xc) * 8));
+#pragma unroll
+            for (int t = -(S - 1); t <= H - 1; t++) {
+#pragma unroll
+                for (int i = 0; i < S; i++)
+                    if (i + t >= 0 && i + t < H) win[i][i + t] = PK_CELL(row0, i, i + t);
+            }
+            if (want_tl) {
+#pragma unroll
+                for (int i = 0; i < W; i++) {
+#pragma unroll
+                    for (int q = 0; q < W; q++) acc += tl[i][q];
+                }
+            }
+        } else {
         if (want_tl) {
 #pragma unroll
             for (int i = 0; i < W; i++) {
@@ -579,6 +612,7 @@ __device__ __forceinline__ void extract_pair_clean_body(
         for (int q = H1; q < H; q++) {
 #pragma unroll
             for (int i = 0; i < S; i++) win[i][q] = PK_CELL(row0, i, q);
+        }
         }
     } else {
         if (normalise) raw_block();
@@ -713,15 +747,15 @@ __device__ __forceinline__ void extract_pair_clean_body(
 }
 
 
-template <int W, bool FEA64>
+template <int W, bool FEA64, bool DIAG = false>
 __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) void extract_pair_clean_kernel(
     const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
     const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
     float *__restrict__ tiles, int blk, uint8_t *__restrict__ status,
     double *__restrict__ fea64_rows)
 {
-    extract_pair_clean_body<W, FEA64>(blockIdx.x, gridDim.x, threadIdx.x, band, norm_off, ld, dlo, dhi, n,
-                                      exp_len, xs, ys, c0, cn, tiles, blk, status, fea64_rows);
+    extract_pair_clean_body<W, FEA64, DIAG>(blockIdx.x, gridDim.x, threadIdx.x, band, norm_off, ld, dlo, dhi, n,
+                                            exp_len, xs, ys, c0, cn, tiles, blk, status, fea64_rows);
 }
 
 // ------------------------------------------------------------------------
@@ -1215,7 +1249,7 @@ int pk_extract_upload_taps(const double *taps5)
 
 int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
-                      int blk, uint8_t *d_status, double *fea64_rows, bool any_coords)
+                      int blk, uint8_t *d_status, double *fea64_rows, bool any_coords, bool scattered)
 {
     if (cn <= 0) return PK_OK;
     pk_prof_scope prof(ctx, PK_K_EXTRACT, st);
@@ -1245,13 +1279,22 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
     hipLaunchKernelGGL((extract_pair_clean_kernel<WW, FF>), dim3((grid + 7u) & ~7u), dim3(64), 0, st, m->band, \
                        norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,   \
                        tiles, blk, d_status, fea64_rows)
+            // scattered lists: every lane's loads in the order of its window's diagonals (see extract_pair_clean_body)
+#define PK_CLEAN_D(WW)                                                                           \
+    hipLaunchKernelGGL((extract_pair_clean_kernel<WW, false, true>), dim3((grid + 7u) & ~7u), dim3(64), 0, st, m->band, \
+                       norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,   \
+                       tiles, blk, d_status, fea64_rows)
+            const bool diag = (scattered || m->opt.extract_diag == 2) && !fea64_rows && m->opt.extract_diag != 0;  // (2: always)
             if (w == 5) {
-                if (fea64_rows) PK_CLEAN(5, true);
+                if (diag) PK_CLEAN_D(5);
+                else if (fea64_rows) PK_CLEAN(5, true);
                 else PK_CLEAN(5, false);
             } else {
-                if (fea64_rows) PK_CLEAN(6, true);
+                if (diag) PK_CLEAN_D(6);
+                else if (fea64_rows) PK_CLEAN(6, true);
                 else PK_CLEAN(6, false);
             }
+#undef PK_CLEAN_D
 #undef PK_CLEAN
         } else if (w == 5) {
             hipLaunchKernelGGL(extract_pair_kernel<5>, dim3(grid), dim3(64), 0, st, m->band,

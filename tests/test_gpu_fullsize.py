@@ -433,6 +433,36 @@ def test_short_lists_take_one_launch_behind_the_forest(config2):
                 assert a == b == got[0][1], (n, batch, thre)
 
 
+@pytest.mark.parametrize("w", [5, 6])
+def test_scattered_lists_load_their_windows_diagonal_by_diagonal(config2, w):
+    """A list whose consecutive candidates are not neighbours (get_candidate's lists: one band pixel in tens)
+    is extracted with every lane's loads in the order of its window's diagonals (option extract_diag;
+    neighbours on a diagonal share a line of the band) -- the order of LOADS only: status, probability of
+    every candidate and the scored pixels are those of the column order, bit for bit, and the oracle's."""
+    c = config2
+    M = c["Mf"]
+    e = c["e"] if w == 5 else utils.calculate_expected(M, 200 + 2 * w, raw=True)
+    fo = c["fo"] if w == 5 else FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w%d_t100.npz" % w))
+    hf = _lib.HipForest(fo)
+    x, y = c["x"][3::41].copy(), c["y"][3::41].copy()          # ~135 000 scattered candidates
+    got = {}
+    for diag in (0, 1, 2):
+        hm = _lib.HipMatrix(M.indptr, M.indices, M.data, M.shape[0], e, -2 * w + 1, 200 + 2 * w - 1,
+                            options={"extract_diag": diag})
+        cd = _lib.HipCands(x, y)
+        cd.run(hm, hf, w, 0.3)
+        got[diag] = digest(*cd.fetch(), *cd.fetch_all())
+        if diag == 1:
+            ox, oy, op, osig = cd.fetch()
+        cd.close()
+        hm.close()
+    assert got[0] == got[1] == got[2]
+    fod = {k: getattr(fo, k) for k in FlatForest.FIELDS}
+    rx, ry, rp, rs = onp.score(M, e, w, fod, 0.3, x, y, threads=0)
+    assert np.array_equal(ox, rx) and np.array_equal(oy, ry)
+    assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
+
+
 def test_extract_and_predict_across_chunks(config2):
     """pk_extract (65 536-candidate staging chunks) and pk_predict (512 k chunks)
     on inputs larger than one chunk: survivor order and sampled values vs the oracle."""
