@@ -9,14 +9,20 @@ size 100 000.  One step = one pass of the hot path (extract -> forest ->
 threshold/compact [-> RCCL gather of the scored pixels when N > 1]) over the
 candidate list, with matrix, forest and candidates already resident in HBM.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank scores
-its own synthetic chromosome (weak scaling, the default; chromosomes shard
-embarrassingly, peakachu/score_genome.py:46-84) or, with --scaling strong, its
-batch-aligned block of ONE chromosome's candidate list (matrix and forest
-replicated); rank 0 collects the scored pixels with one RCCL gather.
-torch.distributed (gloo) is used only for the rendezvous, the barriers and the
-max-over-ranks of the timings.  If the RCCL communicator cannot be built the
-run fails (exit code 3) unless --allow-gloo-gather is given.
+N > 1 (one rank per GPU; RANK / LOCAL_RANK / WORLD_SIZE from the launcher --
+torch.distributed.run is the LAUNCHER only, a parent that never touches HIP): every
+rank scores its own synthetic chromosome (weak scaling, the default; chromosomes
+shard embarrassingly, peakachu/score_genome.py:46-84) or, with --scaling strong,
+its batch-aligned block of ONE chromosome's candidate list (matrix and forest
+replicated); rank 0 collects the scored pixels with one RCCL gather.  The ranks
+themselves import no deep-learning framework: the unique-id broadcast, the
+barriers and the max-over-ranks of the timings go through the product's own host
+rendezvous (peakachu_amd.rendezvous, standard library), so that every point of a
+scaling curve runs on the ROCm that `ldd libpeakachu_hip.so` names (a framework
+imported first would bind its bundled librccl / libamdhip64 under the same
+sonames instead).  The line says which runtime ran (`hip_runtime_version`,
+`rccl_version`, `rocm_libs`); a run on any other copy ends with exit code 3, and
+so does one whose RCCL communicator cannot be built.
 
 Prints ONE JSON line (rank 0).
 """
@@ -460,9 +466,9 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = every rank its own chromosome (default); strong = one chromosome, "
                          "the candidate list cut into batch-aligned blocks")
-    ap.add_argument("--allow-gloo-gather", action="store_true",
-                    help="N > 1: fall back to a gloo gather when the RCCL communicator cannot be built "
-                         "(otherwise the run fails)")
+    ap.add_argument("--allow-host-gather", "--allow-gloo-gather", dest="allow_host_gather", action="store_true",
+                    help="N > 1: fall back to a gather over the host rendezvous (TCP) when the RCCL communicator "
+                         "cannot be built (otherwise the run fails)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive extra leg")
     ap.add_argument("--full-evaluation", action="store_true",
                     help="headline on the kernels without the exact early exit (every candidate's complete "
@@ -493,13 +499,27 @@ def main():
             sys.exit(self_launch(a.gpus, sys.argv[1:]))
         a.gpus = world
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="gloo")
-
     from peakachu_amd import _lib
     from peakachu_amd.forest import FlatForest
+    # which ROCm this process bound -- stamped into the line; anything but the copy `ldd` names is refused
+    # (checked before the first device call: the answer does not need a GPU)
+    rt = _lib.runtime_info()
+    rdzv = None
+    if world > 1:
+        from peakachu_amd.rendezvous import Rendezvous
+        rdzv = Rendezvous(rank, world)
+    bad_rt = rt["product_runtime"] is False and not os.environ.get("PK_BENCH_ANY_RUNTIME")
+    if rdzv:
+        bad_rt = any(rdzv.all_gather_obj(bool(bad_rt)))
+    if bad_rt:
+        sys.stderr.write("bench.py: rank %d runs on %s, not on the ROCm `ldd` resolves for the library (%s): "
+                         "refusing to measure another runtime\n" % (rank, rt["rocm_libs"], rt["rocm_dir_ldd"]))
+        if rank == 0 and os.environ.get("PK_BENCH_EXIT_FILE"):
+            open(os.environ["PK_BENCH_EXIT_FILE"], "w").write("3")
+        if rdzv:
+            rdzv.barrier()
+            rdzv.close()
+        sys.exit(3)
     L = _lib.require_device()
     dev = 0 if a.rehearse_shared_gpu else local_rank
     for kv in a.opt:
@@ -536,37 +556,32 @@ def main():
     upload_s = time.perf_counter() - t0
 
     # the gather of the scored pixels: RCCL (pk_comm_*); if the communicator cannot be
-    # built on every rank, all ranks agree to send the (small) result through the gloo
-    # group instead -- reported as "gather" in the JSON line
+    # built on every rank, all ranks agree to send the (small) result through the host
+    # rendezvous instead -- reported as "gather" in the JSON line, and only on request
     comm = None
     gather_mode = "none" if world == 1 else "rccl"
     if world > 1:
-        import torch
         if not a.rehearse_shared_gpu:
-            ids = [None]
+            buf = np.zeros(128, np.uint8)
             if rank == 0:
-                buf = np.zeros(128, np.uint8)
                 _lib.check(L.pk_comm_unique_id(buf), "pk_comm_unique_id")
-                ids = [buf.tobytes()]
-            dist.broadcast_object_list(ids, src=0)
-            comm = L.pk_comm_create(dev, world, rank, np.frombuffer(ids[0], np.uint8).copy())
+            uid = rdzv.broadcast(buf.tobytes())
+            comm = L.pk_comm_create(dev, world, rank, np.frombuffer(uid, np.uint8).copy())
             if not comm:
                 sys.stderr.write("rank %d: pk_comm_create failed: %s\n" % (rank, _lib.last_error()))
-        flag = torch.tensor([1 if comm else 0], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
+        if not all(rdzv.all_gather_obj(bool(comm))):
             if comm:
                 L.pk_comm_destroy(comm)
             comm = None
-            gather_mode = "gloo"
-            if not (a.allow_gloo_gather or a.rehearse_shared_gpu):
+            gather_mode = "host-tcp"
+            if not (a.allow_host_gather or a.rehearse_shared_gpu):
                 if rank == 0:
                     sys.stderr.write("bench.py: the RCCL communicator could not be built on every rank; "
-                                     "refusing to measure a gloo gather (pass --allow-gloo-gather to do so)\n")
+                                     "refusing to measure a host gather (pass --allow-host-gather to do so)\n")
                     if os.environ.get("PK_BENCH_EXIT_FILE"):
                         open(os.environ["PK_BENCH_EXIT_FILE"], "w").write("3")
-                dist.barrier()
-                dist.destroy_process_group()
+                rdzv.barrier()
+                rdzv.close()
                 sys.exit(3)
     rccl_ranks = L.pk_comm_ranks(comm) if comm else 0   # what RCCL itself counts (ncclCommCount)
     cap = int(x_all.size) * (1 if strong else world)
@@ -597,13 +612,15 @@ def main():
             else:
                 _lib.check(L.pk_comm_gather_scored(comm, cd.h, counts, 0, None, None, None,
                                                    None), "gather")
-        elif gather_mode == "gloo":
+        elif gather_mode == "host-tcp":
             mine = cd.fetch()
-            parts = [None] * world if rank == 0 else None
-            dist.gather_object(mine, parts, dst=0)
+            blobs = rdzv.gather(b"".join(np.ascontiguousarray(v).tobytes() for v in mine))
             if rank == 0:
                 o = 0
-                for r, (px, py, pp, ps) in enumerate(parts):
+                for r, blob in enumerate(blobs):
+                    k = len(blob) // 24   # int32 x, int32 y, float64 prob, float64 signal per pixel
+                    px = np.frombuffer(blob, np.int32, k, 0); py = np.frombuffer(blob, np.int32, k, 4 * k)
+                    pp = np.frombuffer(blob, np.float64, k, 8 * k); ps = np.frombuffer(blob, np.float64, k, 16 * k)
                     counts[r] = px.size
                     gx[o:o + px.size] = px; gy[o:o + px.size] = py
                     gp[o:o + px.size] = pp; gs[o:o + px.size] = ps
@@ -611,8 +628,8 @@ def main():
 
     def sync():
         _lib.check(L.pk_device_synchronize(dev), "sync")
-        if dist:
-            dist.barrier()
+        if rdzv:
+            rdzv.barrier()
 
     for _ in range(a.warmup):
         step()
@@ -748,17 +765,15 @@ def main():
 
     n_local = int(x.size)
     per_rank_ms = [run_ms]
-    if dist:
-        import torch
-        pr = [None] * world
-        dist.all_gather_object(pr, float(run_ms))
-        per_rank_ms = [float(v) for v in pr]
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-        c = torch.tensor([n_local], dtype=torch.int64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        n_total = int(c[0])
+    rt_all = [rt]
+    if rdzv:
+        # (one exchange: per-rank step time, the timed region's length -- MAX over ranks is the job's --,
+        # candidates per rank, and what each rank's runtime says about itself)
+        got = rdzv.all_gather_obj([float(run_ms), float(elapsed), n_local, rt])
+        per_rank_ms = [float(g[0]) for g in got]
+        elapsed = max(float(g[1]) for g in got)
+        n_total = sum(int(g[2]) for g in got)
+        rt_all = [g[3] for g in got]
     else:
         n_total = n_local
 
@@ -821,21 +836,33 @@ def main():
                 "parallelism": "%s x%d, one %s gather of the scored pixels%s"
                                % ("batch-aligned candidate blocks of one chromosome" if strong
                                   else "chromosome-sharded", world,
-                                  {"rccl": "RCCL", "gloo": "gloo (RCCL unavailable)",
+                                  {"rccl": "RCCL", "host-tcp": "host-rendezvous (RCCL unavailable)",
                                           "none": "(single rank: no)"}[gather_mode],
                                   " (REHEARSAL: shared GPU)" if a.rehearse_shared_gpu else ""),
                 "gather": gather_mode,
                 "gathered_pixels": int(counts.sum()) if world > 1 else int(n_out),
             },
+            # `achieved` / `frac` lead with the WHOLE PATH (SURVEY 8d's own definition: candidates/s x B_alg /
+            # peak, per GPU): since the forest is cut in two, the dominant KERNEL (the head) walks only the
+            # trees in front of the cut, and pricing it with the path's bytes flatters it.  The brief's
+            # per-kernel recipe (B_alg x candidates per launch / the kernel's average launch time) is kept as
+            # `dominant_kernel_frac`, next to the same kernel charged with the whole forest stage
+            # (`dominant_kernel_frac_stage_time`: head + gap + tail) and credited with its own bytes only
+            # (`kernel_own_frac`).
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom + (" (forest_qr_kernel<..,1>: the head of the cut forest, %d of %d tree groups over every "
                                  "candidate; the tail -- forest_tail in kernel_ms_per_step -- is a launch of its own)"
                                  % (cut["group"], cut["of_groups"]) if (cut and dom == "forest") else ""),
-                "achieved": achieved,
+                "achieved": value / world * b_alg(F) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": value / world * b_alg(F) / 1e9 / HBM_PEAK_GBS,
+                "frac_is": "whole path: candidates/s x B_alg / peak (SURVEY 8d)",
+                "dominant_kernel_achieved": achieved,
+                "dominant_kernel_frac": achieved / HBM_PEAK_GBS,
+                "dominant_kernel_frac_stage_time": (alg_bytes_total / (kern[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                                    if kern[dom][0] > 0 else None),
                 "traffic": traffic,
                 # measured HBM rate of that kernel: PMC bytes per launch / its average duration
                 "traffic_GBs": (traffic / (dom_ms / dom_n * 1e-3) / 1e9) if (traffic and dom_n) else None,
@@ -854,8 +881,18 @@ def main():
             },
             # SURVEY 8d's definition: candidates/s x B_alg / peak (per GPU) -- the WHOLE path, not one kernel
             "roofline_whole_path_frac": value / world * b_alg(F) / 1e9 / HBM_PEAK_GBS,
+            # the same pass without the permission to stop early (rounds 1-4's headline), beside `value`
+            "full_evaluation_value": full["value"] if full else (value if a.full_evaluation else None),
             "early_exit_allowed": not a.full_evaluation,
             "forest_cut": cut,
+            # which runtime ran (rank 0; `runtimes_agree`: every rank reports the same versions and paths)
+            "hip_runtime_version": rt["hip_runtime_version"],
+            "hip_driver_version": rt["hip_driver_version"],
+            "rccl_version": rt["rccl_version"],
+            "rocm_libs": rt["rocm_libs"],
+            "rocm_dir_ldd": rt["rocm_dir_ldd"],
+            "product_runtime": rt["product_runtime"],
+            "runtimes_agree": all(r == rt for r in rt_all),
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in kern.items()},
             "whole_path_alg_GBs": value * b_alg(F) / 1e9,
             "upload_s": upload_s,
@@ -886,9 +923,9 @@ def main():
 
     if comm:
         L.pk_comm_destroy(comm)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv:
+        rdzv.barrier()
+        rdzv.close()
 
 
 def guarded_main():

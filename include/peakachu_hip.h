@@ -55,6 +55,11 @@ const char *pk_last_error(void);
 int pk_device_count(void);
 int pk_device_name(int device, char *buf, int buflen);
 int pk_device_synchronize(int device);
+/* which HIP this process really bound: hipRuntimeGetVersion / hipDriverGetVersion (no device
+ * needed; -1 where a query fails).  A process that had mapped another ROCm before loading this
+ * library -- a framework's bundled copy under the same sonames -- reports THAT copy here; bench.py
+ * prints both next to the paths found in /proc/self/maps. */
+int pk_runtime_versions(int *hip_runtime, int *hip_driver);
 
 /* ---- forest: the model object used at peakachu/scoreUtils.py:109 --------
  * (model.predict_proba; sklearn RandomForestClassifier trained at
@@ -290,6 +295,8 @@ pk_comm *pk_comm_create(int device, int nranks, int rank, const uint8_t id[128])
 void pk_comm_destroy(pk_comm *);
 /* ranks RCCL itself counts in the communicator (ncclCommCount), or PK_E_COMM */
 int pk_comm_ranks(pk_comm *);
+/* ncclGetVersion of the RCCL this process bound (no device, no communicator needed) */
+int pk_comm_version(int *rccl);
 /* No gather waits without bound: a rank polls its stream for PK_COMM_TIMEOUT seconds (environment,
  * default 120); when a peer went away between its "ready" and its send the wait runs out, the
  * communicator is aborted (ncclCommAbort), the call returns PK_E_COMM and so does every later call

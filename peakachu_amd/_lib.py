@@ -34,6 +34,7 @@ SIGNATURES = {
     "pk_device_count": (C.c_int, []),
     "pk_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "pk_device_synchronize": (C.c_int, [C.c_int]),
+    "pk_runtime_versions": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pk_forest_create": (_vp, [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _f64p,
                                _u8p, _f64p]),
     "pk_forest_destroy": (None, [_vp]),
@@ -96,6 +97,7 @@ SIGNATURES = {
     "pk_comm_create": (_vp, [C.c_int, C.c_int, C.c_int, _u8p]),
     "pk_comm_destroy": (None, [_vp]),
     "pk_comm_ranks": (C.c_int, [_vp]),
+    "pk_comm_version": (C.c_int, [C.POINTER(C.c_int)]),
     "pk_comm_gather_scored": (C.c_int, [_vp, _vp, _i64p, C.c_int64, _vp, _vp, _vp, _vp]),
     "pk_comm_gatherv_bytes": (C.c_int, [_vp, _vp, C.c_int64, _i64p, _vp, C.c_int64]),
 }
@@ -163,6 +165,63 @@ def require_device():
         raise PeakachuHipError("no HIP device visible; peakachu_amd needs an MI355X (gfx950) "
                                "and has no CPU fallback")
     return L
+
+
+ROCM_SONAMES = ("librccl.so", "libamdhip64.so", "libhsa-runtime64.so")
+
+
+def mapped_rocm_libs():
+    """Paths of the RCCL / HIP / HSA runtimes mapped into THIS process (/proc/self/maps), per
+    soname stem.  A soname is bound once per process: whoever maps a ROCm first -- e.g. the copy
+    a deep-learning framework bundles under the same sonames -- decides which one this library runs on."""
+    found = {k: [] for k in ROCM_SONAMES}
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                path = line.rstrip("\n").split(None, 5)[-1] if line.count("/") else ""
+                base = os.path.basename(path)
+                for k in ROCM_SONAMES:
+                    if base.startswith(k) and path not in found[k]:
+                        found[k].append(path)
+    except OSError:
+        pass
+    return found
+
+
+def expected_rocm_dir():
+    """The directory the loader resolves this library's ROCm dependencies from in a fresh process
+    (what `ldd libpeakachu_hip.so` names): read from the dynamic loader itself, in a child."""
+    import subprocess
+    try:
+        out = subprocess.run(["ldd", LIB_PATH], capture_output=True, text=True, timeout=30).stdout
+    except Exception:
+        return None
+    for line in out.splitlines():
+        if "libamdhip64.so" in line and "=>" in line:
+            path = line.split("=>", 1)[1].split("(")[0].strip()
+            if path and os.path.exists(path):
+                return os.path.dirname(os.path.realpath(path))
+    # (no usable ldd: where the Makefile links against)
+    cand = os.path.realpath(os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib"))
+    return cand if os.path.isdir(cand) else None
+
+
+def runtime_info():
+    """What bench.py stamps into its line: the versions the bound runtimes report, the paths they
+    were mapped from, and whether all of them lie where `ldd` resolves them (`product_runtime`)."""
+    L = load()
+    hr, hd, rv = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    L.pk_runtime_versions(C.byref(hr), C.byref(hd))
+    L.pk_comm_version(C.byref(rv))
+    libs = mapped_rocm_libs()
+    want = expected_rocm_dir()
+    paths = [p for v in libs.values() for p in v]
+    # (nothing to compare with -- no ldd, no /opt/rocm --: None = unknown, which refuses nothing)
+    ok = None if not (want and paths) else (all(len(v) <= 1 for v in libs.values()) and
+                                            all(os.path.dirname(os.path.realpath(p)) == want for p in paths))
+    return {"hip_runtime_version": hr.value, "hip_driver_version": hd.value, "rccl_version": rv.value,
+            "rocm_libs": {k: (v[0] if len(v) == 1 else v) for k, v in libs.items()},
+            "rocm_dir_ldd": want, "product_runtime": ok}
 
 
 # ------------------------------------------------------------------ handles

@@ -199,6 +199,16 @@ extern "C" int pk_device_name(int device, char *buf, int buflen)
     return PK_OK;
 }
 
+extern "C" int pk_runtime_versions(int *hip_runtime, int *hip_driver)
+{
+    if (!hip_runtime || !hip_driver) return PK_E_INVALID;
+    *hip_runtime = *hip_driver = -1;
+    if (hipRuntimeGetVersion(hip_runtime) != hipSuccess) *hip_runtime = -1;
+    if (hipDriverGetVersion(hip_driver) != hipSuccess) *hip_driver = -1;
+    (void)hipGetLastError();
+    return PK_OK;
+}
+
 extern "C" int pk_device_synchronize(int device)
 {
     PK_DEV_LOCK(device);

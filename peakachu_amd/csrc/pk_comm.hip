@@ -206,6 +206,18 @@ extern "C" int pk_comm_ranks(pk_comm *c)
     return n;
 }
 
+extern "C" int pk_comm_version(int *rccl)
+{
+    if (!rccl) return PK_E_INVALID;
+    *rccl = -1;
+    const ncclResult_t r = ncclGetVersion(rccl);
+    if (r != ncclSuccess) {
+        pk_set_error("ncclGetVersion failed: %s", ncclGetErrorString(r));
+        return PK_E_COMM;
+    }
+    return PK_OK;
+}
+
 extern "C" void pk_comm_destroy(pk_comm *c)
 {
     PK_DEV_LOCK(c ? c->device : 0);
