@@ -314,6 +314,11 @@ int pk_comm_gather_scored(pk_comm *, pk_cands *, int64_t *counts, int64_t cap,
 int pk_comm_gatherv_bytes(pk_comm *, const void *send, int64_t nbytes, int64_t *counts,
                           void *recv, int64_t cap);
 
+/* diagnostic, needs no device: the bound the forest kernels' early exit / cut tests `acc + remaining`
+ * against for threshold `thre`, a forest of T trees and at most `additions` terms still to add --
+ * thre * T less a proven rounding margin (csrc/pk_common.h: pk_prune_bound; tests/test_prune_bound.py). */
+double pk_debug_prune_bound(double thre, int T, int64_t additions);
+
 /* diagnostic, needs no device: the rank tables and the RANK image (4-byte nodes over
  * 16-bit rank codes) the default forest kernel walks, for `slots` tree slots and `ch`
  * walks per lane, so that tests can quantize and walk on the CPU.

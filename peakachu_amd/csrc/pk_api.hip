@@ -199,6 +199,8 @@ extern "C" int pk_device_name(int device, char *buf, int buflen)
     return PK_OK;
 }
 
+extern "C" double pk_debug_prune_bound(double thre, int T, int64_t additions) { return pk_prune_bound(thre, T, additions); }
+
 extern "C" int pk_runtime_versions(int *hip_runtime, int *hip_driver)
 {
     if (!hip_runtime || !hip_driver) return PK_E_INVALID;
@@ -1617,11 +1619,15 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
     // ~0.5 M candidates (two tiles per workgroup and more) it saves 7 % (0.6) to 35 % (0.9) of the
     // forest's time; a list of one or two tiles per workgroup never gains.  Only meaningful for thre >= 0.
     const bool prune_on = thre >= 0.0 && (cd->opt.early_exit || (cd->prune && thre >= 0.55 && cd->N >= (int64_t)1 << 19));
-    const double prune_sum = prune_on ? thre * (double)f->T : -INFINITY;
+    // (the bound every kernel tests against: thre * T less a margin that is PROVEN to cover the rounding of
+    // the additions still to come -- pk_prune_bound, pk_common.h; q_T: the rank image's trees, more than T
+    // when trees were cut into pieces)
+    const double exit_bound = pk_prune_bound(thre, f->T, f->q_T > f->T ? f->q_T : f->T);
+    const double prune_sum = prune_on ? exit_bound : -INFINITY;
     // The same permission, per CANDIDATE: the default forest kernel can be cut in two at a tree-group
     // boundary -- the head over everybody, the tail over the candidates whose sum could still exceed
     // thre * T -- which pays from the default threshold on (pk_forest_q.hip, q_pick_cut; long launches only)
-    const double split_sum = thre >= 0.0 && (cd->opt.early_exit || cd->prune) ? thre * (double)f->T : -INFINITY;
+    const double split_sum = thre >= 0.0 && (cd->opt.early_exit || cd->prune) ? exit_bound : -INFINITY;
     TR("run:enter");
     // A call that fails half-way may have left the record of an out-of-contract coordinate (word 65533
     // of the diagnostic buffer, coords_sanitize_kernel) behind: it belongs to THAT call and must not

@@ -448,8 +448,30 @@ int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
                       int blk, uint8_t *d_status, double *fea64_rows, bool any_coords = false,
                       bool scattered = false);  // scattered: consecutive candidates are rarely neighbours
 
+// The early-exit / cut decision of every forest kernel is `fl(acc + rem) < B`: acc = the candidate's
+// partial sum (bit for bit the reference's: same trees, same order), rem = the trees (or tree pieces)
+// still to come, each of which adds a value in [0, 1], B = this bound.  Claim: whoever passes the test
+// ends at fl(S / T) <= thre, i.e. is not reported by `p > thre` (peakachu/scoreUtils.py:110).  Proof, with
+// u = 2^-53, n = `additions` >= rem, M = 1 + (n + 4) * 2^-52 (exact in binary64 for n < 2^51):
+//   * round-to-nearest addition is monotone and fl(a + b) <= (a + b)(1 + u), so the final sequential
+//     sum S satisfies S <= (acc + rem)(1 + u)^rem (the real number acc + rem, every later term <= 1);
+//   * the test's own addition gives fl(acc + rem) >= (acc + rem)(1 - u);
+//   * B <= fl(thre * T) / M <= thre * T * (1 + u) / M (the quotient is rounded DOWN below);
+//   hence S < thre * T * (1 + u)^(rem + 1) / (M (1 - u)) <= thre * T, because (1 + u)^(n + 1) <= 1 + (n + 2) u
+//   <= M (1 - u) for every n < 2^26 (larger: no bound, nobody is decided); so S / T < thre as real numbers and, thre being a binary64 number and
+//   division being monotone, fl(S / T) <= thre.  tests/test_prune_bound.py checks the inequality in exact
+//   rational arithmetic for the forest sizes the library accepts and drives adversarial sums through it.
+// (A fixed 1e-12, as in rounds 1-5, states this only up to ~9 000 additions.)
+static inline double pk_prune_bound(double thre, int T, int64_t additions)
+{
+    if (additions < T) additions = T;
+    if (additions >= ((int64_t)1 << 26)) return -INFINITY;
+    const double M = 1.0 + (double)(additions + 4) * 0x1p-52;
+    return nextafter(thre * (double)T / M, -INFINITY);
+}
+
 // walk the forest over feature tiles of candidates [c0, c0+cn)
-// prune_sum: -inf (full evaluation) or thre*T: candidates whose sum provably cannot reach it
+// prune_sum: -inf (full evaluation) or pk_prune_bound(thre, T, ..): candidates whose sum provably cannot reach it
 // are dropped early (grouped LDS kernel only; their reported probability is 0)
 int pk_launch_forest(pk_device_ctx *, pk_forest *, const float *tiles, int blk,
                      const uint8_t *d_status, int64_t c0, int64_t cn, double *d_prob,

@@ -337,9 +337,9 @@ __global__ __launch_bounds__(LDS_C *SLOTS) void forest_lds_kernel(
             for (int j = 0; j < gt; j++) acc += val[j * LDS_C + cl];  // tree order
             if (prune) {
                 // every remaining tree adds at most 1.0: if even that cannot lift the
-                // sum to thre*T (1e-12 covers the rounding of at most T additions), the
+                // sum to the bound (pk_prune_bound, pk_common.h: thre*T less a proven rounding margin), the
                 // final p is <= thre and the pixel is not reported -- stop walking it
-                const bool out = (acc + (double)(T - tn)) * (1.0 + 1e-12) < prune_sum;
+                const bool out = (acc + (double)(T - tn)) < prune_sum;
                 if (out) {
                     decided[cl] = 1;
                     acc = 0.0;  // reported probability of a pruned candidate: 0

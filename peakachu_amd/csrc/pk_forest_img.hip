@@ -183,9 +183,9 @@ __global__ __launch_bounds__(IMG_C *SLOTS) void forest_img_kernel(
             for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * IMG_C + cl) * 8);  // tree order
             if (PRUNE) {
                 // every remaining tree adds at most 1.0: if even that cannot lift the sum to
-                // thre*T (1e-12 covers the rounding of at most T additions) the final p is
+                // the bound (pk_prune_bound, pk_common.h: thre*T less a proven rounding margin) the final p is
                 // <= thre and the pixel is not reported -- stop walking it
-                const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < prune_sum;
+                const bool out = (acc + (double)(T - (t0 + gt))) < prune_sum;
                 if (out) {
                     *LDS_AT(lds_i32, dec_off + 4 * cl) = 1;
                     acc = 0.0;  // reported probability of a pruned candidate: 0

@@ -374,7 +374,7 @@ __device__ __forceinline__ void q_park_tile(const int tid, const int lane, const
     bool open = false;
     unsigned my_i = 0;
     if (owner) {  // (whole waves: C is a multiple of 64)
-        open = valid && active && !((acc + sp.rem) * (1.0 + 1e-12) < prune_sum);
+        open = valid && active && !((acc + sp.rem) < prune_sum);
         const unsigned long long m = __ballot(open);
         if (m != 0ull) {
             unsigned pos = 0;
@@ -695,9 +695,9 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
                 for (int j = 0; j < gt; j++) acc += *LDS_AT(lds_f64, val_off + (j * C + tid) * 8);  // tree order
                 if (PRUNE) {
                     // every remaining tree adds at most 1.0: if even that cannot lift the sum to
-                    // thre*T (1e-12 covers the rounding of at most T additions) the final p is
+                    // the bound (pk_prune_bound, pk_common.h: thre*T less a proven rounding margin) the final p is
                     // <= thre and the pixel is not reported -- stop walking it
-                    const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < prune_sum;
+                    const bool out = (acc + (double)(T - (t0 + gt))) < prune_sum;
                     if (out) {
                         *LDS_AT(lds_i32, dec_off + 4 * tid) = 1;
                         acc = 0.0;  // reported probability of a pruned candidate: 0
@@ -1145,9 +1145,9 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
 #pragma unroll
                 for (int j = 0; j < 8; j++) acc += (j < gt) ? pv[j] : 0.0;
                 if (PRUNE) {
-                    // every remaining tree adds at most 1.0: if even that cannot lift the sum to thre*T
-                    // (1e-12 covers the rounding of at most T additions) the pixel is not reported
-                    const bool out = (acc + (double)(T - (t0 + gt))) * (1.0 + 1e-12) < A.prune_sum;
+                    // every remaining tree adds at most 1.0: if even that cannot lift the sum to the bound
+                    // (pk_prune_bound: thre*T less a proven rounding margin) the pixel is not reported
+                    const bool out = (acc + (double)(T - (t0 + gt))) < A.prune_sum;
                     if (out) {
                         *LDS_AT(lds_i32, dec_off + 4 * tid) = 1;
                         acc = 0.0;  // reported probability of a pruned candidate: 0
@@ -1222,7 +1222,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
             bool decided = false, open = false;
             unsigned my_i = 0;
             if (owner) {  // (waves 0-3, whole waves)
-                open = valid && active && !((acc + A.split_rem) * (1.0 + 1e-12) < A.prune_sum);
+                open = valid && active && !((acc + A.split_rem) < A.prune_sum);
                 decided = valid && !open;
                 const unsigned long long m = __ballot(open);
                 if (m != 0ull) {
@@ -1625,7 +1625,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
             bool open = false;
             unsigned my_i = 0;
             if (owner) {  // (waves 0 and 1: tile A, tile B)
-                open = active && !((acc + sp.rem) * (1.0 + 1e-12) < prune_sum);
+                open = active && !((acc + sp.rem) < prune_sum);
                 const unsigned long long m = __ballot(open);
                 if (m != 0ull) {
                     unsigned pos = 0;
