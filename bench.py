@@ -221,15 +221,10 @@ def cpu_baseline(Mf, exp_arr, w, fo, thre, x, y, batch, gpu_pixels=None, target_
 
 
 def source_sha():
-    """Hash of the kernel sources (tools/make_traffic.py stamps profiles/pmc.json with it)."""
-    import hashlib
-    h = hashlib.sha256()
-    src = os.path.join(ROOT, "peakachu_amd", "csrc")
-    for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(src, name), "rb").read())
-    return h.hexdigest()[:16]
+    """Hash of the kernel sources' token stream -- comments and layout do not change it
+    (tools/srchash.py; tools/make_traffic.py stamps profiles/pmc*.json with it)."""
+    from tools.srchash import source_sha as sha
+    return sha()
 
 
 def pmc_rooflines(dom, launches_per_step_live, pmc_file="pmc.json"):

@@ -85,3 +85,17 @@ def test_a_foreign_runtime_is_noticed_and_refused():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
     assert "refusing to measure another runtime" in r.stderr
+
+
+def test_profile_stamp_ignores_comments_and_layout():
+    """tools/srchash.py: the stamp of profiles/pmc*.json changes with the code, not with a note."""
+    sys.path.insert(0, ROOT)
+    from tools.srchash import normalised
+    code = 'int f(int a) { return a /* the input */ + 1; }  // adds one\nconst char *s = "// kept /* too */";\n'
+    same = 'int f(int a)\n{\n    return a + 1;   // a different note\n}\nconst char *s = "// kept /* too */";'
+    other = 'int f(int a) { return a + 2; }\nconst char *s = "// kept /* too */";'
+    assert normalised(code) == normalised(same) != normalised(other)
+    assert normalised('x = "a  b";') != normalised('x = "a b";')      # literals are code (inline asm)
+    import bench
+    from tools import make_traffic
+    assert bench.source_sha() == make_traffic.source_sha() and len(bench.source_sha()) == 16

@@ -27,14 +27,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def source_sha():
-    h = hashlib.sha256()
-    src = os.path.join(ROOT, "peakachu_amd", "csrc")
-    for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h")):
-            h.update(name.encode())
-            h.update(open(os.path.join(src, name), "rb").read())
-    return h.hexdigest()[:16]
+sys.path.insert(0, ROOT)
+from tools.srchash import source_sha  # noqa: E402  (token-stream hash: comments do not change it)
 
 
 def kclass(name):
