@@ -279,7 +279,11 @@ int pk_debug_forest_image(int T, int F, const int32_t *tree_off, const int32_t *
  * call: chunk i = src[i] (src_len[i] bytes as stored); inflate to chunk_bytes when `deflate`
  * (zlib, looked up at run time); un-shuffle with element size shuffle_es when > 1; bytes
  * [skip[i], skip[i] + take[i]) of the result go to dst[i].  Chunks run side by side on `threads`
- * host threads.  PK_E_UNSUPPORTED when no zlib can be found (the caller then inflates itself). */
+ * host threads.  dst[i] needs NO alignment (a slice may start anywhere in the caller's array);
+ * PK_E_INVALID for a slice outside the chunk, a missing pointer, a stored chunk shorter than
+ * chunk_bytes (no deflate) or one that does not inflate to exactly chunk_bytes (truncated or
+ * corrupt stream: nothing is written beyond dst[i] + take[i] in any case); PK_E_UNSUPPORTED when
+ * no zlib can be found (the caller then inflates itself). */
 int pk_host_unfilter_chunks(int n_chunks, const void *const *src, const int64_t *src_len, int deflate,
                             int shuffle_es, int64_t chunk_bytes, const int64_t *skip, const int64_t *take,
                             void *const *dst, int threads);

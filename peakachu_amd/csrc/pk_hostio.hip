@@ -8,6 +8,10 @@
 // read runs here: inflate (zlib's `uncompress`, resolved at run time from the libz the
 // interpreter itself is linked against -- no build-time dependency), un-shuffle, and the copy
 // of the wanted slice to its place, chunks side by side on host threads.
+//
+// No device code and no HIP call: the file needs the public header and pk_set_error only, so the
+// CPU test suite builds it with plain g++ under Address / UndefinedBehaviour / Thread sanitizers
+// (tests/test_hostio_sanitized.py, tests/native/test_hostio.cpp).
 #include <dlfcn.h>
 
 #include <atomic>
@@ -16,7 +20,9 @@
 #include <thread>
 #include <vector>
 
-#include "pk_common.h"
+#include "../../include/peakachu_hip.h"
+
+void pk_set_error(const char *fmt, ...);  // pk_api.hip (the test harness brings its own)
 
 namespace {
 
@@ -42,15 +48,19 @@ void unshuffle_slice(const unsigned char *src, int64_t n_el, int es, int64_t ski
     if (es == 8) {
         const unsigned char *p0 = src, *p1 = src + n_el, *p2 = src + 2 * n_el, *p3 = src + 3 * n_el,
                             *p4 = src + 4 * n_el, *p5 = src + 5 * n_el, *p6 = src + 6 * n_el, *p7 = src + 7 * n_el;
-        uint64_t *out = reinterpret_cast<uint64_t *>(dst);
-        for (int64_t e = e0; e < e1; e++)
-            out[e - e0] = (uint64_t)p0[e] | (uint64_t)p1[e] << 8 | (uint64_t)p2[e] << 16 | (uint64_t)p3[e] << 24 |
-                          (uint64_t)p4[e] << 32 | (uint64_t)p5[e] << 40 | (uint64_t)p6[e] << 48 | (uint64_t)p7[e] << 56;
+        // (memcpy stores: dst[i] carries no alignment requirement -- a slice may start anywhere in the
+        // caller's array; the compiler turns them into plain 8-byte moves)
+        for (int64_t e = e0; e < e1; e++) {
+            const uint64_t v = (uint64_t)p0[e] | (uint64_t)p1[e] << 8 | (uint64_t)p2[e] << 16 | (uint64_t)p3[e] << 24 |
+                               (uint64_t)p4[e] << 32 | (uint64_t)p5[e] << 40 | (uint64_t)p6[e] << 48 | (uint64_t)p7[e] << 56;
+            memcpy(dst + (e - e0) * 8, &v, 8);
+        }
     } else if (es == 4) {
         const unsigned char *p0 = src, *p1 = src + n_el, *p2 = src + 2 * n_el, *p3 = src + 3 * n_el;
-        uint32_t *out = reinterpret_cast<uint32_t *>(dst);
-        for (int64_t e = e0; e < e1; e++)
-            out[e - e0] = (uint32_t)p0[e] | (uint32_t)p1[e] << 8 | (uint32_t)p2[e] << 16 | (uint32_t)p3[e] << 24;
+        for (int64_t e = e0; e < e1; e++) {
+            const uint32_t v = (uint32_t)p0[e] | (uint32_t)p1[e] << 8 | (uint32_t)p2[e] << 16 | (uint32_t)p3[e] << 24;
+            memcpy(dst + (e - e0) * 4, &v, 4);
+        }
     } else {
         for (int64_t e = e0; e < e1; e++)
             for (int k = 0; k < es; k++) dst[(e - e0) * es + k] = src[(int64_t)k * n_el + e];
@@ -79,7 +89,7 @@ extern "C" int pk_host_unfilter_chunks(int n_chunks, const void *const *src, con
     }
     for (int i = 0; i < n_chunks; i++)
         if (skip[i] < 0 || take[i] < 0 || skip[i] + take[i] > chunk_bytes || skip[i] % es || take[i] % es ||
-            (!deflate && src_len[i] < chunk_bytes)) {
+            src_len[i] < 0 || (take[i] > 0 && (!src[i] || !dst[i])) || (!deflate && src_len[i] < chunk_bytes)) {
             pk_set_error("pk_host_unfilter_chunks: slice of chunk %d out of range", i);
             return PK_E_INVALID;
         }
