@@ -6,12 +6,19 @@ import numpy as np
 
 from . import io
 from .forest import load_model
-from .score_genome import build_chromosome, warm_imports
+from .score_genome import build_chromosome, join_warm, warm_imports
 
 
 def main(args):
+    warm = warm_imports(getattr(args, "device", 0))
+    try:
+        return _main(args)
+    finally:
+        join_warm(warm)   # (an early error must not tear the interpreter down under a thread inside hipInit)
+
+
+def _main(args):
     np.seterr(divide='ignore', invalid='ignore')
-    warm_imports(getattr(args, "device", 0))
     if os.path.exists(args.output):
         os.remove(args.output)
     model = load_model(args.model)

@@ -118,13 +118,31 @@ def warm_imports(device=0):
             import sklearn.isotonic  # noqa: F401
         except ImportError:
             pass
-    threading.Thread(target=work, name="pk-warm-imports", daemon=True).start()
+    t = threading.Thread(target=work, name="pk-warm-imports", daemon=True)
+    t.start()
+    return t
+
+
+def join_warm(thread, timeout=60.0):
+    """Before a driver returns -- normally or with an error (bad model path, unknown chromosome,
+    missing weight column: all of them can fail within milliseconds) -- the warm-up thread must be out
+    of the HIP runtime's initialisation: an interpreter that tears down libamdhip64's static objects
+    while a thread is still inside hipInit can hang or abort instead of showing the error."""
+    if thread is not None and thread.is_alive():
+        thread.join(timeout)
 
 
 def main(args):
+    warm = warm_imports(dist.rank_info()[1])
+    try:
+        return _main(args)
+    finally:
+        join_warm(warm)
+
+
+def _main(args):
     np.seterr(divide='ignore', invalid='ignore')
     rank, local_rank, world = dist.rank_info()
-    warm_imports(local_rank)
     if rank == 0 and os.path.exists(args.output):
         os.remove(args.output)
 
