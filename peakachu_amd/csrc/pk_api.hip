@@ -1426,6 +1426,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
     if (rc) return rc;
     ctx->split_k = 0;  // (the cut forest's counters: one per launch of this call)
     ctx->split_n = 0;
+    ctx->split_slack = 0;
     // the cut forest parks its candidates in the chunk's float tiles once they are quantized: not while
     // the extractor of the next chunk may be writing a tile buffer beside the forest
     if (overlap) split_sum = -INFINITY;
@@ -1666,7 +1667,7 @@ static int score_run_impl(pk_matrix *m, pk_forest *f, pk_cands *cd, int w, doubl
     if (ctx->split_k > 0) {
         long long parked = 0;
         memcpy(&parked, ctx->h_ret + 32, 8);
-        pk_forest_cut_feedback(f, ctx->split_n, parked, ctx->split_k);
+        pk_forest_cut_feedback(f, ctx->split_n, parked, ctx->split_slack);
     }
     cd->ret_inline = with_records && cd->n_out <= PK_RET_INLINE;
     const long long err = dbg3[2];

@@ -62,6 +62,7 @@ struct pk_device_ctx {
     unsigned *split_cnt = nullptr;  // device [PK_SPLIT_SLOTS], zeroed at the first cut launch of a call
     int split_k = 0;                // counters handed out in this call
     int64_t split_n = 0;            // candidates of this call's cut launches
+    int64_t split_slack = 0;  // slots the launches' workgroups may have reserved without filling them (half a block each)
 };
 #define PK_SPLIT_SLOTS 4096
 #define PK_RET_INLINE 8192
@@ -347,7 +348,7 @@ int pk_q_group(pk_q_out *out, const pk_q_layout &L);
 int pk_q_fixed_slots(const pk_q_out &out, int slots, pk_q_layout *L);
 int pk_q_max_tree_bytes(const pk_q_out &out);  // largest tree image, a multiple of 16  // (re)group the trees of `out` for a layout
 int pk_forest_q_plan(pk_forest *f);   // PK_OK when the rank image applies (built and uploaded)
-void pk_forest_cut_feedback(pk_forest *f, int64_t candidates, int64_t parked, int launches);  // after a call whose launches were cut
+void pk_forest_cut_feedback(pk_forest *f, int64_t candidates, int64_t parked, int64_t slack);  // after a call whose launches were cut
 void pk_forest_q_release(pk_forest *f);
 // split_sum: -inf, or thre * T when the run allows decided candidates to end at probability 0 and the
 // float tiles may be overwritten once they are quantized (the cut forest parks its candidates there)

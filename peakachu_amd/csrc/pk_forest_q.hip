@@ -2044,11 +2044,13 @@ static int q_pick_cut(pk_forest *f, double split_sum)
     return 0;
 }
 
-void pk_forest_cut_feedback(pk_forest *f, int64_t candidates, int64_t parked, int launches)
+void pk_forest_cut_feedback(pk_forest *f, int64_t candidates, int64_t parked, int64_t slack)
 {
     if (!f || candidates <= 0 || f->last_cut <= 0 || f->opt.forest_split_at > 0) return;
-    // (`parked` counts slots: up to one unfinished block of 256 per workgroup and launch is nobody)
-    parked -= (int64_t)launches * 65536;
+    // (`parked` counts SLOTS: a workgroup reserves a block -- 256, the two-tile kernel 128 -- and leaves on
+    // average half of its last one empty; `slack` = what the launches of this call booked for that: grid x
+    // block / 2 each, with the grid and the block size each launch really had)
+    parked -= slack;
     const double open = parked > 0 ? (double)parked / (double)candidates : 0.0;
     if (open > 0.5) f->cut_shift += 2;
     else if (open > 0.15) f->cut_shift += 1;
@@ -2076,7 +2078,7 @@ extern "C" int pk_debug_cut_policy(const int32_t *trees_in_front, int n_groups, 
         cuts[i] = cut;
         f.last_cut = cut;
         // (one launch; the slots of the unfinished blocks the feedback takes off are put on top)
-        pk_forest_cut_feedback(&f, candidates, (int64_t)(open_frac[i] * (double)candidates) + 65536, 1);
+        pk_forest_cut_feedback(&f, candidates, (int64_t)(open_frac[i] * (double)candidates) + 32768, 32768);
     }
     return PK_OK;
 }
@@ -2138,6 +2140,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
             gsp.st = reinterpret_cast<uint8_t *>(b + tiles_b + acc_b + idx_b);
             gsp.cnt = ctx->split_cnt + ctx->split_k++;
             ctx->split_n += cn;
+            ctx->split_slack += 128 * (int64_t)grid;
             gsp.rem = (double)f->q_T - (double)f->q_gtab_h[4 * (size_t)gcut];
             f->last_cut = gcut;
         }
@@ -2175,6 +2178,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
                 sp.st = reinterpret_cast<uint8_t *>(b + tiles_b + acc_b + idx_b);
                 sp.cnt = ctx->split_cnt + ctx->split_k++;
                 ctx->split_n += cn;
+                ctx->split_slack += 128 * (int64_t)grid;
                 sp.rem = (double)f->q_T - (double)f->q_gtab_h[4 * (size_t)cut];
                 grid_tail = grid;
             }
@@ -2293,6 +2297,7 @@ int pk_launch_forest_q_walk(pk_device_ctx *ctx, pk_forest *f, const uint8_t *d_s
                 sp.st = reinterpret_cast<uint8_t *>(b + tiles_b + acc_b + idx_b);
                 sp.cnt = ctx->split_cnt + ctx->split_k++;
                 ctx->split_n += cn;
+                ctx->split_slack += 64 * (int64_t)grid2;
                 sp.rem = (double)f->q_T - (double)f->q_gtab_h[4 * (size_t)cut];
             }
         }
