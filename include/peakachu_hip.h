@@ -234,7 +234,8 @@ int pk_get_gauss_taps(double *taps5);
  * options of pk_score_run (chunk, overlap, sub_chunk, early_exit).  Results never depend on
  * them; the route does.  (The reference has no such knobs: one code path, peakachu/scoreUtils.py:95-125.)
  * Read-only names report what ran: "stat_extract_clean" / "stat_extract_general" (process: launches of either
- * extractor), and per forest, once its first call has planned it, "stat_q_mode" (rank image: 0 narrow word, 1 wide,
+ * extractor), "stat_extract_strip" (launches of the clean extractor's LDS-staged variant, option extract_strip),
+ * and per forest, once its first call has planned it, "stat_q_mode" (rank image: 0 narrow word, 1 wide,
  * 2 the 12-bit rank word; -1 no rank image), "stat_q_rows" (rows of a rank tile), "stat_q_shape" (64-candidate blocks
  * per workgroup), "stat_q_trees" (trees of the image: the model's, or more when trees were cut into pieces). */
 int pk_set_option(const char *name, int64_t value);

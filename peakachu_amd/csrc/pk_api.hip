@@ -25,7 +25,7 @@ void pk_set_error(const char *fmt, ...)
 }
 
 static pk_options g_opt;
-std::atomic<int64_t> g_stat_extract_clean{0}, g_stat_extract_general{0};
+std::atomic<int64_t> g_stat_extract_clean{0}, g_stat_extract_general{0}, g_stat_extract_strip{0};
 // Locks (include/peakachu_hip.h, 'Threading'): one recursive lock PER DEVICE, taken by every entry
 // point for the device of its handle -- a device has one stream pair, one tile scratch and handles
 // with cached launch tables, so calls on one device are serialised; calls on different devices run
@@ -295,6 +295,8 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
         o.extract_pair = value != 0;
     } else if (!strcmp(name, "extract_row16")) {
         o.extract_row16 = value != 0;
+    } else if (!strcmp(name, "extract_strip")) {
+        o.extract_strip = value != 0;
     } else if (!strcmp(name, "extract_diag")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
         o.extract_diag = value;
@@ -357,6 +359,7 @@ static int64_t opt_read(const pk_options &o, const char *name)
     if (!strcmp(name, "forest_slots")) return o.forest_slots;
     if (!strcmp(name, "extract_pair")) return o.extract_pair;
     if (!strcmp(name, "extract_row16")) return o.extract_row16;
+    if (!strcmp(name, "extract_strip")) return o.extract_strip;
     if (!strcmp(name, "extract_diag")) return o.extract_diag;
     if (!strcmp(name, "extract_clean")) return o.extract_clean;
     if (!strcmp(name, "forest_warm")) return o.forest_warm;
@@ -394,6 +397,7 @@ extern "C" int64_t pk_get_option(const char *name)
     if (!name) return -1;
     if (!strcmp(name, "stat_extract_clean")) return g_stat_extract_clean;
     if (!strcmp(name, "stat_extract_general")) return g_stat_extract_general;
+    if (!strcmp(name, "stat_extract_strip")) return g_stat_extract_strip;
     std::lock_guard<std::mutex> lk(g_mu);
     return opt_read(g_opt, name);
 }

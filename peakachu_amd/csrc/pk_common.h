@@ -98,6 +98,8 @@ struct pk_options {
     int64_t extract_diag = 1;   // scattered candidate lists (w = 5, 6, clean matrices): a lane's loads in the order of its
                                 // window's diagonals (neighbours on a diagonal share a line of the band)
     int64_t extract_row16 = 1;  // w = 11 on clean matrices: four register-blocked windows per wave
+    int64_t extract_strip = 1;  // w = 5, 6, clean matrices, lists of neighbours: the wave's diagonal strip staged in LDS by
+                                // LDS-DMA (extract_pair_strip_kernel); 0 = the register-gather kernel
     int64_t forest_warm = 1;    // last tree group: pull the tile of workgroup id + N into this XCD's L2
                                 // (0 = off, 1 = N = number of CUs: the workgroup that follows on this XCD)
     int64_t early_exit = 0;     // pk_score_run: stop walking candidates that provably end at p <= thre
@@ -144,8 +146,9 @@ std::recursive_mutex &pk_device_mutex(int device);
 #define PK_DEV_LOCK(dev) std::lock_guard<std::recursive_mutex> api_lock__(pk_device_mutex(dev))
 pk_options pk_default_options();  // the DEFAULTS of new handles (pk_set_option), copied under their lock; no launch path reads them
 // launches of the two-lane extractor since load, by kernel (read-only options
-// "stat_extract_clean" / "stat_extract_general": lets tests see which one ran)
-extern std::atomic<int64_t> g_stat_extract_clean, g_stat_extract_general;
+// "stat_extract_clean" / "stat_extract_general": lets tests see which one ran; "stat_extract_strip": launches of
+// the LDS-staged variant of the clean kernel)
+extern std::atomic<int64_t> g_stat_extract_clean, g_stat_extract_general, g_stat_extract_strip;
 
 // ---------------------------------------------------------------- profiling
 // Brackets a kernel launch with HIP events on the library's stream when

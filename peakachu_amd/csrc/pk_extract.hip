@@ -466,6 +466,134 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 // The arithmetic order is unchanged; tests compare this kernel bit for bit with the
 // general one and with the CPU restatement of the reference.
 // ------------------------------------------------------------------------
+// Everything of a candidate pair behind the gather (shared by the register-gather kernel and the
+// LDS-staged one below): the two tests of utils.py:228-235, the sparsity filter, both blur passes,
+// the min-max scaling and the stores.  `win` = this lane's half window (quotients, or raw counts
+// when the window is not normalised), `acc` = lane A's sequential top-left sum, `centre` = the raw
+// centre cell; `ok` = the lane has a window (the filters below may still drop it), `st` = the lane of role A
+// writes its candidate's status byte (a lane that only shadows another one does not).  STORE_DROPPED: a lane
+// with `st` stores its features whether the filters drop it or not.
+template <int W, bool FEA64, bool STORE_DROPPED = false>
+__device__ __forceinline__ void pair_clean_finish(
+    double (&win)[2 * W + 1][W + 1], double acc, const double centre, bool ok, const bool st, const int role,
+    const unsigned lane_id,
+    const int64_t wave0, const int64_t local, const bool in_range, const int64_t c,
+    float *__restrict__ tiles, const int blk, uint8_t *__restrict__ status, double *__restrict__ fea64_rows)
+{
+    constexpr int S = 2 * W + 1;
+    constexpr int F = S * S;
+    constexpr int H = W + 1;
+    const int sgn = role ? -1 : 1;
+    const double acc_partner = lane_swap(acc);
+    acc = role ? acc_partner : acc;
+    const double ll_mean = acc / (double)(W * W);
+    ok = ok && (ll_mean > 0.0);
+    const double p2ll = centre / ll_mean;
+    ok = ok && (p2ll > 0.1);
+
+    // ---- utils.py:221-225 sparsity filter (quotient != 0 <=> count != 0), counted column by
+    // column on the way, and scipy gaussian_filter(sigma=1), axis 0: down each local column
+    int nnz = 0;
+#pragma unroll
+    for (int q = 0; q < H; q++) {
+        double col[S];
+        const bool mine = (q < W) || (role == 0);
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            col[i] = win[i][q];
+            nnz += (mine && col[i] != 0.0) ? 1 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            win[i][q] = PK_BLUR9(col[i], col[reflect_idx(i - 4, S)], col[reflect_idx(i + 4, S)],
+                                 col[reflect_idx(i - 3, S)], col[reflect_idx(i + 3, S)],
+                                 col[reflect_idx(i - 2, S)], col[reflect_idx(i + 2, S)],
+                                 col[reflect_idx(i - 1, S)], col[reflect_idx(i + 1, S)]);
+        }
+    }
+    nnz += lane_swap_i(nnz);
+    ok = ok && !((double)nnz < (double)F * 0.1);
+    // ---- axis 1 (see extract_pair_kernel)
+#pragma unroll
+    for (int ip = 0; ip <= W; ip++) {
+        const int ia = ip, ib = S - 1 - ip;
+        double ra[4], rb[4];
+#pragma unroll
+        for (int u = 1; u <= 4; u++) {
+            ra[u - 1] = lane_swap(win[ib][W - u]);
+            rb[u - 1] = lane_swap(win[ia][W - u]);
+        }
+        {
+            double out[H];
+            blur_row<W>(win[ia], ra, out);
+            if (ia != ib) {
+                double outb[H];
+                blur_row<W>(win[ib], rb, outb);
+#pragma unroll
+                for (int q = 0; q < H; q++) win[ib][q] = outb[q];
+            }
+#pragma unroll
+            for (int q = 0; q < H; q++) win[ia][q] = out[q];
+        }
+    }
+    // ---- utils.py:204-209 image_normalize
+    double mn = win[0][0], mx = win[0][0];
+#pragma unroll
+    for (int i = 0; i < S; i++) {
+#pragma unroll
+        for (int q = 0; q < H; q++) {
+            mn = __builtin_fmin(mn, win[i][q]);
+            mx = __builtin_fmax(mx, win[i][q]);
+        }
+    }
+    mn = __builtin_fmin(mn, lane_swap(mn));
+    mx = __builtin_fmax(mx, lane_swap(mx));
+    const double den = mx - mn;
+    const bool flat = !(den > 0.0);  // constant window: 0 / 0
+    // tile cell (e, tl) with e = gi * S + gj; B's e is F-1 minus A's.  Every feature is
+    // stored as soon as it is computed (its window register dies with it: keeping the
+    // floats for a grouped store cost 20 registers, the difference between one and two
+    // waves per SIMD at w = 6); A stores the shared centre column.
+    const int64_t first = wave0 / blk;  // the 32 candidates of a wave share a tile
+    char *tbase = reinterpret_cast<char *>(tiles + (size_t)first * F * blk);
+    const int tl = (int)(wave0 - first * blk) + (lane_id >> 1);
+    const int t0 = (tl + (role ? (F - 1) * blk : 0)) * 4;
+    const int sblk4 = sgn * blk * 4;
+    double *rp = FEA64 ? fea64_rows + (size_t)local * F : nullptr;
+#define PK_PUT(i_, q_, v_)                                                                      \
+    do {                                                                                        \
+        if ((STORE_DROPPED ? st : ok) && ((q_) < W || role == 0)) {                             \
+            *reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24((i_) * S + (q_), sblk4))) = \
+                (float)(v_); /* sklearn's float32 cast (RNE) */                                 \
+            if (FEA64) rp[role ? F - 1 - ((i_) * S + (q_)) : (i_) * S + (q_)] = (v_);           \
+        }                                                                                       \
+    } while (0)
+    if (flat) {
+        const double qn = (mn - mn) / den;  // the true division
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) PK_PUT(i, q, qn);
+        }
+    } else {
+        double r = __builtin_amdgcn_rcp(den);
+        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+                const double a = win[i][q] - mn;
+                const double m = a * r;
+                const double v = __builtin_fma(__builtin_fma(-den, m, a), r, m);
+                PK_PUT(i, q, v);
+            }
+        }
+    }
+#undef PK_PUT
+    if (st && role == 0) status[c] = ok ? (flat ? 2 : 1) : 0;
+}
+
 // (the body of the kernel, for wave `vblock` of `vgrid`)
 // DIAG (round 5, scattered candidate lists -- the list get_candidate makes holds one band pixel in ~50): a
 // lane's loads are issued DIAGONAL BY DIAGONAL of its window instead of column by column.  Neighbouring
@@ -483,7 +611,6 @@ __device__ __forceinline__ void extract_pair_clean_body(
     double *__restrict__ fea64_rows)
 {
     constexpr int S = 2 * W + 1;
-    constexpr int F = S * S;
     constexpr int H = W + 1;
     static_assert(W >= 4, "the row blur borrows 4 partner columns");
     const int role = lane_id & 1;
@@ -636,114 +763,8 @@ __device__ __forceinline__ void extract_pair_clean_body(
         }
     }
 #undef PK_CELL
-    const double acc_partner = lane_swap(acc);
-    acc = role ? acc_partner : acc;
-    const double ll_mean = acc / (double)(W * W);
-    ok = ok && (ll_mean > 0.0);
-    const double p2ll = centre / ll_mean;
-    ok = ok && (p2ll > 0.1);
-
-    // ---- utils.py:221-225 sparsity filter (quotient != 0 <=> count != 0), counted column by
-    // column on the way, and scipy gaussian_filter(sigma=1), axis 0: down each local column
-    int nnz = 0;
-#pragma unroll
-    for (int q = 0; q < H; q++) {
-        double col[S];
-        const bool mine = (q < W) || (role == 0);
-#pragma unroll
-        for (int i = 0; i < S; i++) {
-            col[i] = win[i][q];
-            nnz += (mine && col[i] != 0.0) ? 1 : 0;
-        }
-#pragma unroll
-        for (int i = 0; i < S; i++) {
-            win[i][q] = PK_BLUR9(col[i], col[reflect_idx(i - 4, S)], col[reflect_idx(i + 4, S)],
-                                 col[reflect_idx(i - 3, S)], col[reflect_idx(i + 3, S)],
-                                 col[reflect_idx(i - 2, S)], col[reflect_idx(i + 2, S)],
-                                 col[reflect_idx(i - 1, S)], col[reflect_idx(i + 1, S)]);
-        }
-    }
-    nnz += lane_swap_i(nnz);
-    ok = ok && !((double)nnz < (double)F * 0.1);
-    // ---- axis 1 (see extract_pair_kernel)
-#pragma unroll
-    for (int ip = 0; ip <= W; ip++) {
-        const int ia = ip, ib = S - 1 - ip;
-        double ra[4], rb[4];
-#pragma unroll
-        for (int u = 1; u <= 4; u++) {
-            ra[u - 1] = lane_swap(win[ib][W - u]);
-            rb[u - 1] = lane_swap(win[ia][W - u]);
-        }
-        {
-            double out[H];
-            blur_row<W>(win[ia], ra, out);
-            if (ia != ib) {
-                double outb[H];
-                blur_row<W>(win[ib], rb, outb);
-#pragma unroll
-                for (int q = 0; q < H; q++) win[ib][q] = outb[q];
-            }
-#pragma unroll
-            for (int q = 0; q < H; q++) win[ia][q] = out[q];
-        }
-    }
-    // ---- utils.py:204-209 image_normalize
-    double mn = win[0][0], mx = win[0][0];
-#pragma unroll
-    for (int i = 0; i < S; i++) {
-#pragma unroll
-        for (int q = 0; q < H; q++) {
-            mn = __builtin_fmin(mn, win[i][q]);
-            mx = __builtin_fmax(mx, win[i][q]);
-        }
-    }
-    mn = __builtin_fmin(mn, lane_swap(mn));
-    mx = __builtin_fmax(mx, lane_swap(mx));
-    const double den = mx - mn;
-    const bool flat = !(den > 0.0);  // constant window: 0 / 0
-    // tile cell (e, tl) with e = gi * S + gj; B's e is F-1 minus A's.  Every feature is
-    // stored as soon as it is computed (its window register dies with it: keeping the
-    // floats for a grouped store cost 20 registers, the difference between one and two
-    // waves per SIMD at w = 6); A stores the shared centre column.
-    const int64_t first = wave0 / blk;  // the 32 candidates of a wave share a tile
-    char *tbase = reinterpret_cast<char *>(tiles + (size_t)first * F * blk);
-    const int tl = (int)(wave0 - first * blk) + (lane_id >> 1);
-    const int t0 = (tl + (role ? (F - 1) * blk : 0)) * 4;
-    const int sblk4 = sgn * blk * 4;
-    double *rp = FEA64 ? fea64_rows + (size_t)local * F : nullptr;
-#define PK_PUT(i_, q_, v_)                                                                      \
-    do {                                                                                        \
-        if (ok && ((q_) < W || role == 0)) {                                                    \
-            *reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24((i_) * S + (q_), sblk4))) = \
-                (float)(v_); /* sklearn's float32 cast (RNE) */                                 \
-            if (FEA64) rp[role ? F - 1 - ((i_) * S + (q_)) : (i_) * S + (q_)] = (v_);           \
-        }                                                                                       \
-    } while (0)
-    if (flat) {
-        const double qn = (mn - mn) / den;  // the true division
-#pragma unroll
-        for (int i = 0; i < S; i++) {
-#pragma unroll
-            for (int q = 0; q < H; q++) PK_PUT(i, q, qn);
-        }
-    } else {
-        double r = __builtin_amdgcn_rcp(den);
-        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
-        r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
-#pragma unroll
-        for (int i = 0; i < S; i++) {
-#pragma unroll
-            for (int q = 0; q < H; q++) {
-                const double a = win[i][q] - mn;
-                const double m = a * r;
-                const double v = __builtin_fma(__builtin_fma(-den, m, a), r, m);
-                PK_PUT(i, q, v);
-            }
-        }
-    }
-#undef PK_PUT
-    if (in_range && role == 0) status[c] = ok ? (flat ? 2 : 1) : 0;
+    pair_clean_finish<W, FEA64>(win, acc, centre, ok, in_range, role, lane_id, wave0, local, in_range, c, tiles, blk, status,
+                                fea64_rows);
 }
 
 
@@ -756,6 +777,174 @@ __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) vo
 {
     extract_pair_clean_body<W, FEA64, DIAG>(blockIdx.x, gridDim.x, threadIdx.x, band, norm_off, ld, dlo, dhi, n,
                                             exp_len, xs, ys, c0, cn, tiles, blk, status, fea64_rows);
+}
+
+// ------------------------------------------------------------------------
+// Two lanes per candidate, clean matrices, lists of NEIGHBOURS: the wave's diagonal strip staged in LDS.
+//
+// The register-gather kernel above asks for every window cell with a load of its own: 92 + 25 vector-memory
+// instructions per wave, 60 KB through the CU's address path, a third of the wave's cycles waiting (PMC,
+// round 5: SQ_WAIT_INST_ANY 35 %, VALU issue 0.68), the LDS unused.  The windows of candidates that lie on
+// ONE diagonal d within ~50 rows of each other (the lists of the benchmark regime: every non-zero band
+// pixel, diagonal by diagonal) are the 4w+1 diagonals d-2w .. d+2w of the band over 64 consecutive rows.
+// A wave stages that strip in LDS by LDS-DMA (global_load_lds_dwordx4: whole lines, no VGPR, no ds_write
+// -- 17 instructions at w = 5) and every lane reads its window from there at constant offsets (ds_read
+// with immediates: no address arithmetic).
+//   * staging image: rows of 64 doubles (half a DMA instruction: lane l of an instruction fetches the 16
+//     bytes l & 31 of the instruction's row l >> 5), first double = the even row rs <= x0 - w (16-byte
+//     source alignment; pulled back so that rs + 64 stays inside the band row): quotient rows
+//     k = d-2w .. d+2w (raw counts when the window is not normalised), behind them the raw rows of the
+//     top-left blocks, k = d-(w-1) .. d+(w-1), and the candidates' own diagonal.  A row outside the band
+//     [dlo, dhi] is fetched from the nearest one inside and zeroed in LDS (scoreUtils.py:30-33: such
+//     cells are not stored; the last candidate diagonal's far corner);
+//   * a PASS handles the candidates of the wave that share the first open candidate's diagonal and fit
+//     its strip; a wave that needs more than one (the end of a diagonal, a gap of > ~50 rows) repeats.
+//     Lanes that are not members of a pass shadow its lead candidate and store nothing;
+//   * what was tried and not kept (EXPERIMENTS.md, round 6): a wave taking several batches with the next
+//     strip and the coordinates after next in flight behind the current batch (1.09-1.12 ms where one
+//     batch per wave takes 1.06: the partner wave of the SIMD already hides the latency, the look-ahead
+//     only adds instructions).
+// Arithmetic: pair_clean_finish, the same instructions as the register-gather kernel.
+// ------------------------------------------------------------------------
+template <int W>
+struct strip_layout {
+    static constexpr int ROW = 64;            // doubles per staged row
+    static constexpr int QD = 4 * W + 1;      // quotient rows
+    static constexpr int QI = (QD + 1) / 2;   // DMA instructions: two rows each (the last one: one row)
+    static constexpr int RI = W;              // raw rows: 2w-1 diagonals of the top-left blocks + the centre diagonal
+    static constexpr int Q_DOUBLES = QI * 2 * ROW;
+    static constexpr int DOUBLES = (QI + RI) * 2 * ROW;
+    static constexpr int MAXPOS = ROW - 1 - 2 * W;  // largest row position (x - w - rs) of a member
+};
+
+// LDS-DMA: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS lds_dst + lane * 16.  (M0 carries the LDS
+// address; nothing else in these kernels uses it: LDS instructions need no M0 on gfx9 and later.)
+__device__ __forceinline__ void strip_dma(unsigned voff, const char *sbase, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+template <int W, bool FEA64>
+__global__ __launch_bounds__(64, (!FEA64 ? 2 : 1)) void extract_pair_strip_kernel(
+    const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
+    const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
+    float *__restrict__ tiles, int blk, uint8_t *__restrict__ status, double *__restrict__ fea64_rows)
+{
+    using L = strip_layout<W>;
+    constexpr int S = 2 * W + 1;
+    constexpr int H = W + 1;
+    __shared__ __attribute__((aligned(1024))) double strip[L::DOUBLES];
+    const unsigned lds0 = (unsigned)(uintptr_t)strip;
+    const unsigned lane_id = threadIdx.x;
+    const int role = lane_id & 1;
+    // XCD-aware order (see extract_pair_clean_body): XCD x takes the x-th contiguous eighth of the waves
+    const unsigned per_xcd = gridDim.x >> 3;
+    const int64_t wave0 = (int64_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * 32;
+    if (wave0 >= cn) return;
+    const int64_t local = wave0 + (lane_id >> 1);
+    const bool in_range = local < cn;
+    const int64_t c = c0 + (in_range ? local : wave0);
+    const int xi = xs[c], yi = ys[c];
+    const bool valid = in_range && (xi - W >= 0 && yi + W + 1 <= n) && PK_OTHER_EDGES(xi, yi, W, n);
+    if (in_range && !valid && role == 0) status[c] = 0;
+    const char *bbase = reinterpret_cast<const char *>(band);
+    const unsigned ld8 = (unsigned)ld * 8u;
+    const unsigned dma_lo = (lane_id & 31u) * 16u;
+    const unsigned dma_off = dma_lo + (lane_id >> 5) * ld8;
+    auto clampk = [&](int k) { return k < dlo ? dlo : (k > dhi ? dhi : k); };
+
+    unsigned long long open = __ballot(valid);  // candidates still to do (both lanes of each)
+    while (open != 0ull) {
+        const int lead = __builtin_ctzll(open);
+        const int x0 = __builtin_amdgcn_readlane(xi, lead);
+        const int d0 = __builtin_amdgcn_readlane(yi - xi, lead);
+        // first staged row (even; the 64 rows stay inside the band row)
+        const int rs = ((x0 - W) & ~1) + L::ROW <= ld ? ((x0 - W) & ~1) : ld - L::ROW;
+        const bool normalise = max(iabs(d0 - 2 * W), iabs(d0 + 2 * W)) < exp_len;
+        const unsigned noff = normalise ? norm_off : 0u;
+        // ---- the strip around (x0, d0), on its way into LDS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a previous pass's reads have returned)
+#pragma unroll
+        for (int j = 0; j < L::QI - 1; j++) {
+            const int k0 = clampk(d0 - 2 * W + 2 * j), k1 = clampk(d0 - 2 * W + 2 * j + 1);
+            const unsigned off = noff + (unsigned)(((int64_t)(k0 - dlo) * ld + rs) * 8);
+            strip_dma(k1 != k0 ? dma_off : dma_lo, bbase + off, lds0 + (unsigned)j * 1024u);
+        }
+        if (lane_id < 32u) {  // the last quotient row: half an instruction
+            const int k0 = clampk(d0 + 2 * W);
+            strip_dma(dma_lo, bbase + (noff + (unsigned)(((int64_t)(k0 - dlo) * ld + rs) * 8)),
+                      lds0 + (unsigned)(L::QI - 1) * 1024u);
+        }
+#pragma unroll
+        for (int j = 0; j < L::RI - 1; j++) {
+            const int k0 = clampk(d0 - (W - 1) + 2 * j), k1 = clampk(d0 - (W - 1) + 2 * j + 1);
+            const unsigned off = (unsigned)(((int64_t)(k0 - dlo) * ld + rs) * 8);
+            strip_dma(k1 != k0 ? dma_off : dma_lo, bbase + off, lds0 + (unsigned)(L::QI + j) * 1024u);
+        }
+        {   // last raw instruction: lower half = diagonal d + w - 1 of the blocks, upper half = the candidates' own
+            // diagonal (the base; the lower half's offset from it is not negative)
+            const int kc = clampk(d0), kt = clampk(d0 + W - 1);
+            const unsigned coff = (unsigned)(((int64_t)(kc - dlo) * ld + rs) * 8);
+            strip_dma(dma_lo + (lane_id < 32u ? (unsigned)(kt - kc) * ld8 : 0u), bbase + coff,
+                      lds0 + (unsigned)(L::QI + L::RI - 1) * 1024u);
+        }
+        // members of this pass: same diagonal, row position inside the strip
+        const int pos = xi - W - rs;
+        const bool mem = ((open >> lane_id) & 1ull) && yi - xi == d0 && pos >= 0 && pos <= L::MAXPOS;
+        open &= ~__ballot(mem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (d0 - 2 * W < dlo || d0 + 2 * W > dhi) {
+            // rows outside the band hold a neighbour's values: they read as zero (absent cells)
+            for (int r = 0; r < L::QD; r++) {
+                const int k = d0 - 2 * W + r;
+                if (k < dlo || k > dhi) strip[r * L::ROW + lane_id] = 0.0;
+            }
+            for (int r = 0; r < 2 * W; r++) {
+                const int k = r < 2 * W - 1 ? d0 - (W - 1) + r : d0;
+                if (k < dlo || k > dhi) strip[L::Q_DOUBLES + r * L::ROW + lane_id] = 0.0;
+            }
+        }
+        // lanes that are not members shadow the lead candidate.  Every read below is base + constant: the
+        // two roles (lane B holds the window rotated by 180 degrees) read in separate, masked groups
+        const double *sp = strip + ((mem ? xi : x0) - W - rs);
+        double win[S][H];
+        double acc = 0.0, centre;
+        centre = sp[L::Q_DOUBLES + (2 * W - 1) * L::ROW + W];
+        if (role == 0) {
+            if (normalise) {
+#pragma unroll
+                for (int i = 0; i < W; i++) {
+#pragma unroll
+                    for (int q = 0; q < W; q++) acc += sp[L::Q_DOUBLES + (q - i + W - 1) * L::ROW + i];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+#pragma unroll
+                for (int i = 0; i < S; i++) win[i][q] = sp[(q - i + 2 * W) * L::ROW + i];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+#pragma unroll
+                for (int i = 0; i < S; i++) win[i][q] = sp[(i - q + 2 * W) * L::ROW + 2 * W - i];
+            }
+        }
+        if (!normalise) {  // the window holds the raw counts themselves
+            centre = win[W][W];
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+#pragma unroll
+                for (int q = 0; q < W; q++) acc += win[i][q];
+            }
+        }
+        // (w = 5 also stores the features of a member the filters drop -- into its own cells of the tile, which
+        // nobody reads: its status byte says so.  The stores then form one block the compiler schedules freely:
+        // 1.075 ms against 1.150 with a branch around every store; at w = 6, where registers are scarce, the
+        // branches win, 2.07 against 2.18: profiles/r06_strip_store_ab.log)
+        pair_clean_finish<W, FEA64, (W <= 5 && !FEA64)>(win, acc, centre, mem, mem, role, lane_id, wave0, local, in_range, c,
+                                                        tiles, blk, status, fea64_rows);
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -1285,7 +1474,22 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
                        norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,   \
                        tiles, blk, d_status, fea64_rows)
             const bool diag = (scattered || m->opt.extract_diag == 2) && !fea64_rows && m->opt.extract_diag != 0;  // (2: always)
-            if (w == 5) {
+            // lists of neighbours (the benchmark regime): the wave's diagonal strip staged in LDS
+            if (m->opt.extract_strip && !diag) {
+                const unsigned sgrid = (grid + 7u) & ~7u;
+                g_stat_extract_strip++;
+#define PK_STRIP(WW, FF)                                                                                          \
+    hipLaunchKernelGGL((extract_pair_strip_kernel<WW, FF>), dim3(sgrid), dim3(64), 0, st, m->band, norm_off, (int)m->ld, \
+                       m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn, tiles, blk, d_status, fea64_rows)
+                if (w == 5) {
+                    if (fea64_rows) PK_STRIP(5, true);
+                    else PK_STRIP(5, false);
+                } else {
+                    if (fea64_rows) PK_STRIP(6, true);
+                    else PK_STRIP(6, false);
+                }
+#undef PK_STRIP
+            } else if (w == 5) {
                 if (diag) PK_CLEAN_D(5);
                 else if (fea64_rows) PK_CLEAN(5, true);
                 else PK_CLEAN(5, false);

@@ -24,12 +24,13 @@ def hip_matrix(Mf, exp_arr, w, upper, options=None):
                           -2 * w + 1, upper + 2 * w - 1, options=options)
 
 
-@pytest.mark.parametrize("pair", [1, 0])
+@pytest.mark.parametrize("pair", [1, 0, 2])
 @pytest.mark.parametrize("name", ["g1_extract_w5.npz", "g1_extract_w6.npz", "g1_extract_w11.npz",
                                   "g1_extract_w5_balanced.npz"])
 def test_extract_golden(hip_lib, name, pair):
-    """Both extract kernels for w=5/6 (two lanes per candidate, one lane per
-    candidate) and the LDS kernel for w=11."""
+    """The extract kernels for w=5/6 (two lanes per candidate with the strip staged in LDS -- the default --,
+    two lanes per candidate gathering into registers [pair = 2], one lane per candidate [0]) and the LDS
+    kernel for w=11."""
     _extract_golden(name, pair)
 
 
@@ -46,8 +47,11 @@ def _extract_golden(name, pair=1):
     assert gio.digest(Mf) == str(z["Mf_sha"])
     ok = z["x"] <= z["y"]
     x, y = z["x"][ok], z["y"][ok]
-    hm = hip_matrix(Mf, z["exp_arr"], w, upper, options={"extract_pair": pair})
+    strip0 = L.pk_get_option(b"stat_extract_strip")
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper, options={"extract_pair": 1 if pair else 0, "extract_strip": 0 if pair == 2 else 1})
     f64, f32, keep = hm.extract(w, x, y, want64=True, want32=True)
+    if w in (5, 6) and "balanced" in name:   # (integer counts of the other fixtures qualify as well; this one must)
+        assert (L.pk_get_option(b"stat_extract_strip") > strip0) == (pair == 1)
     assert np.array_equal(np.stack([x[keep], y[keep]], 1), z["clist"])
     assert np.array_equal(gio.bits(f64), gio.bits(z["fea"]))
     assert np.array_equal(f32, z["fea"].astype(np.float32))

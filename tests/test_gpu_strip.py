@@ -1,0 +1,120 @@
+"""The LDS-staged extractor (csrc/pk_extract.hip: extract_pair_strip_kernel; option extract_strip, default on for
+lists of neighbours on clean matrices at w = 5, 6) against the register-gather kernel and the CPU oracle:
+Chromosome.getwindow's arithmetic (peakachu/scoreUtils.py:70-93, utils.py:180-237) on lists that are dense,
+gappy, shuffled, that change diagonal inside a wave, hug the matrix edges and the band's last diagonal (whose
+far window corner lies outside the stored band: scoreUtils.py:30-33), normalised and not.  Bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_io as gio
+from oracle import oracle_np as onp
+from peakachu_amd import _lib, synth, utils
+from peakachu_amd.forest import FlatForest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lists(x, y, rng):
+    out = {"all": (x, y), "every3rd": (x[::3].copy(), y[::3].copy()), "every47th": (x[::47].copy(), y[::47].copy())}
+    p = rng.permutation(x.size)
+    out["shuffled"] = (x[p].copy(), y[p].copy())
+    nblk = x.size // 100   # runs of 100 neighbours in random order: the diagonal changes inside a wave
+    idx = (rng.permutation(nblk)[:, None] * 100 + np.arange(100)[None, :]).ravel()
+    out["runs"] = (x[idx].copy(), y[idx].copy())
+    out["tail"] = (x[-77:].copy(), y[-77:].copy())
+    out["one"] = (x[1234:1235].copy(), y[1234:1235].copy())
+    return out
+
+
+def _matrix(Mf, e, w, upper, strip):
+    Mc = utils.canonical_csr(Mf)
+    return _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, Mc.shape[0], e, -2 * w + 1, upper + 2 * w - 1,
+                          options={"extract_strip": strip})
+
+
+@pytest.mark.parametrize("w", [5, 6])
+@pytest.mark.parametrize("shape", [(700, 80, 60), (2050, 40, 40), (130, 40, 30)])
+def test_staged_features_equal_the_oracles(w, shape):
+    """float64 features and survivor lists through pk_extract on every list shape, against the oracle and against
+    the register-gather kernel; the counter shows which kernel ran."""
+    n, band, upper = shape
+    L = _lib.load()
+    M, _ = synth.synth_band(n, band, seed=n + w)
+    upper = min(upper, n - 2 * w)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, 0, upper)   # from the main diagonal on: d < 2w, windows off the matrix
+    rng = np.random.default_rng(n * 10 + w)
+    hs, hr = _matrix(Mf, e, w, upper, 1), _matrix(Mf, e, w, upper, 0)
+    try:
+        for name, (lx, ly) in _lists(x, y, rng).items():
+            before = L.pk_get_option(b"stat_extract_strip")
+            f64, _, keep = hs.extract(w, lx, ly)
+            assert L.pk_get_option(b"stat_extract_strip") > before, name
+            before = L.pk_get_option(b"stat_extract_strip")
+            g64, _, keep_r = hr.extract(w, lx, ly)
+            assert L.pk_get_option(b"stat_extract_strip") == before
+            fea, keep_o = onp.extract(Mf, e, w, lx, ly)
+            assert np.array_equal(keep, keep_o) and np.array_equal(keep_r, keep_o), name
+            assert np.array_equal(gio.bits(f64), gio.bits(fea)), name
+            assert np.array_equal(gio.bits(g64), gio.bits(fea)), name
+        assert (y - x == upper).any() and (x < w).any()   # the band's last diagonal and edge windows were there
+    finally:
+        hs.close(); hr.close()
+
+
+@pytest.mark.parametrize("w", [5, 6])
+def test_staged_windows_that_are_not_normalised(w):
+    """distance_normaize_core leaves a window unnormalised when its largest |col-row| is outside exp_arr
+    (peakachu/utils.py:191-192): the staged kernel then stages raw counts; candidates on both sides of the
+    boundary, neighbours on their diagonals."""
+    n, band, upper = 400, 90, 70
+    M, _ = synth.synth_band(n, band, seed=w)
+    e_short = utils.calculate_expected(M, upper + 2 * w, raw=True)[:40 + 2 * w].copy()
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    sel = (y - x > 30 - 2 * w) & (y - x < 52)
+    x, y = x[sel], y[sel]
+    hs = _matrix(Mf, e_short, w, upper, 1)
+    try:
+        f64, _, keep = hs.extract(w, x, y)
+    finally:
+        hs.close()
+    fea, keep_o = onp.extract(Mf, e_short, w, x, y)
+    assert np.array_equal(keep, keep_o) and keep.size > 1000
+    assert np.array_equal(gio.bits(f64), gio.bits(fea))
+    d = (y - x)[keep]
+    assert (d + 2 * w >= e_short.size).any() and (d + 2 * w < e_short.size).any()
+
+
+@pytest.mark.parametrize("w", [5, 6])
+def test_scoring_through_the_staged_extractor(w):
+    """pk_score_run with either extractor: status and probability of EVERY candidate and the scored pixels,
+    bit for bit the same and the oracle's (several chunks, a batch rule in between)."""
+    n, band, upper = 3000, 120, 100
+    M, _ = synth.synth_band(n, band, seed=5 + w)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, 0, upper)
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w%d_t100.npz" % w))
+    hf = _lib.HipForest(fo)
+    got = {}
+    try:
+        for strip in (1, 0):
+            hm = _matrix(Mf, e, w, upper, strip)
+            cd = _lib.HipCands(x, y, options={"chunk": 65536})
+            cd.run(hm, hf, w, 0.4, 10000)
+            st, pr = cd.fetch_all()
+            got[strip] = (st.copy(), pr.copy(), cd.fetch())
+            cd.close(); hm.close()
+    finally:
+        hf.close()
+    assert np.array_equal(got[1][0], got[0][0]) and np.array_equal(gio.bits(got[1][1]), gio.bits(got[0][1]))
+    fod = {k: getattr(fo, k) for k in FlatForest.FIELDS}
+    rx, ry, rp, rs = onp.score(Mf, e, w, fod, 0.4, x, y, batch=10000, threads=0)
+    ox, oy, op, osig = got[1][2]
+    assert rx.size > 100 and np.array_equal(ox, rx) and np.array_equal(oy, ry)
+    assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
