@@ -296,7 +296,8 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
     } else if (!strcmp(name, "extract_row16")) {
         o.extract_row16 = value != 0;
     } else if (!strcmp(name, "extract_strip")) {
-        o.extract_strip = value != 0;
+        if (value < 0 || value > 2) return PK_E_INVALID;
+        o.extract_strip = value;
     } else if (!strcmp(name, "extract_diag")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
         o.extract_diag = value;
@@ -1134,6 +1135,27 @@ static int coords_scattered(int64_t N, const int32_t *x, const int32_t *y)
     return next * 4 < pairs ? 1 : 0;
 }
 
+// Are the list's batches of 32 consecutive candidates -- what a wave of the extractor takes -- runs on ONE
+// diagonal within ~50 rows ("every non-zero pixel of the band": yes; a band with many empty pixels, a shuffled
+// or strided list: no)?  Up to 2 048 batches spread over the list; nine in ten must be.  Decides whether the
+// extractor stages a wave's strip of the band in LDS (one pass per batch) -- never a result.
+static int coords_dense(int64_t N, const int32_t *x, const int32_t *y)
+{
+    if (N < 1 || !x || !y) return 0;
+    const int64_t nb = (N + 31) / 32;
+    const int64_t step = nb / 2048 > 0 ? nb / 2048 : 1;
+    int64_t seen = 0, good = 0;
+    for (int64_t b = 0; b < nb; b += step) {
+        const int64_t i0 = b * 32, i1 = i0 + 32 < N ? i0 + 32 : N;
+        bool ok = true;
+        for (int64_t i = i0 + 1; i < i1 && ok; i++)
+            ok = y[i] - x[i] == y[i0] - x[i0] && x[i] > x[i - 1] && x[i] - x[i0] <= 50;
+        seen++;
+        good += ok ? 1 : 0;
+    }
+    return good * 10 >= seen * 9 ? 1 : 0;
+}
+
 extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y)
 {
     PK_DEV_LOCK(device);
@@ -1168,6 +1190,7 @@ extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, co
         return nullptr;
     }
     c->scattered = coords_scattered(N, x, y);
+    c->dense = coords_dense(N, x, y);
     return c;
 }
 
@@ -1525,7 +1548,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
             for (int64_t s0 = 0; !rc && s0 < cn; s0 += sub) {
                 const int64_t sn = cn - s0 < sub ? cn - s0 : sub;
                 rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0 + s0, sn, tiles, blk, cd->status,
-                                       nullptr, false, cd->scattered > 0);
+                                       nullptr, false, cd->scattered > 0, cd->dense > 0);
                 if (!rc) rc = pk_launch_quant_q(ctx, ctx->stream, f, tiles, s0 / 128, sn);
             }
             if (!rc)
@@ -1539,7 +1562,7 @@ static int run_pipeline(pk_device_ctx *ctx, pk_matrix *m, pk_forest *f, pk_cands
             continue;
         }
         rc = pk_launch_extract(ctx, st_ext, m, w, cd->x, cd->y, c0, cn, tiles, blk, cd->status,
-                               nullptr, false, cd->scattered > 0);
+                               nullptr, false, cd->scattered > 0, cd->dense > 0);
         if (rc) return rc;
         if (overlap) {
             PK_HIP(hipEventRecord(ctx->ev_ext[buf], st_ext));
@@ -1769,6 +1792,7 @@ extern "C" int pk_score(pk_matrix *m, pk_forest *f, int w, double thre, int64_t 
     }
     cd->opt = m->opt;  // (a call without a candidate handle: the matrix handle's pipeline options)
     cd->scattered = coords_scattered(N, x, y);
+    cd->dense = coords_dense(N, x, y);
     cd->prune = 1;     // pk_score hands back the scored pixels only: what a decided candidate's probability reads is invisible
     rc = score_run_impl(m, f, cd, w, thre, batch, n_out, true);
     if (deferred) {
@@ -1842,7 +1866,7 @@ extern "C" int pk_extract(pk_matrix *m, int w, int64_t N, const int32_t *x, cons
     for (int64_t c0 = 0; !rc && c0 < N; c0 += chunk) {
         const int64_t cn = N - c0 < chunk ? N - c0 : chunk;
         rc = pk_launch_extract(ctx, ctx->stream, m, w, cd->x, cd->y, c0, cn, ctx->fea_tiles, blk,
-                               cd->status, d_rows, any_coords);
+                               cd->status, d_rows, any_coords, false, cd->dense > 0);
         if (rc) break;
         if (hipMemcpyAsync(h_rows.data(), d_rows, (size_t)cn * F * 8, hipMemcpyDeviceToHost,
                            ctx->stream) != hipSuccess ||

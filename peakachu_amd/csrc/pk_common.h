@@ -98,8 +98,9 @@ struct pk_options {
     int64_t extract_diag = 1;   // scattered candidate lists (w = 5, 6, clean matrices): a lane's loads in the order of its
                                 // window's diagonals (neighbours on a diagonal share a line of the band)
     int64_t extract_row16 = 1;  // w = 11 on clean matrices: four register-blocked windows per wave
-    int64_t extract_strip = 1;  // w = 5, 6, clean matrices, lists of neighbours: the wave's diagonal strip staged in LDS by
-                                // LDS-DMA (extract_pair_strip_kernel); 0 = the register-gather kernel
+    int64_t extract_strip = 1;  // w = 5, 6, clean matrices: the wave's diagonal strip staged in LDS by LDS-DMA
+                                // (extract_pair_strip_kernel): 1 = for lists whose batches are runs on one diagonal
+                                // (coords_dense), 2 = for every list, 0 = never (the register-gather kernel)
     int64_t forest_warm = 1;    // last tree group: pull the tile of workgroup id + N into this XCD's L2
                                 // (0 = off, 1 = N = number of CUs: the workgroup that follows on this XCD)
     int64_t early_exit = 0;     // pk_score_run: stop walking candidates that provably end at p <= thre
@@ -428,6 +429,7 @@ struct pk_cands {
     int64_t n_batches_cap;
     int prune;             // pk_cands_set_prune: exact early termination for this list's runs
     int scattered;         // 1: consecutive candidates are rarely neighbours on a diagonal (get_candidate's lists)
+    int dense;             // 1: the batches of 32 consecutive candidates are runs on one diagonal (coords_dense)
     // pk_score (host buffers): coordinates still on the host; run_pipeline uploads chunk k + 1 on the
     // second stream while chunk k is being scored (nullptr: everything is on the device already)
     const int32_t *h_x = nullptr, *h_y = nullptr;
@@ -450,7 +452,8 @@ int pk_extract_upload_taps(const double *taps5);  // into the current device's c
 int pk_launch_extract(pk_device_ctx *, hipStream_t st, const pk_matrix *, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
                       int blk, uint8_t *d_status, double *fea64_rows, bool any_coords = false,
-                      bool scattered = false);  // scattered: consecutive candidates are rarely neighbours
+                      bool scattered = false,   // scattered: consecutive candidates are rarely neighbours
+                      bool dense = false);      // dense: a wave's 32 candidates are a run on one diagonal
 
 // The early-exit / cut decision of every forest kernel is `fl(acc + rem) < B`: acc = the candidate's
 // partial sum (bit for bit the reference's: same trees, same order), rem = the trees (or tree pieces)

@@ -1438,7 +1438,7 @@ int pk_extract_upload_taps(const double *taps5)
 
 int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, int w,
                       const int32_t *d_x, const int32_t *d_y, int64_t c0, int64_t cn, float *tiles,
-                      int blk, uint8_t *d_status, double *fea64_rows, bool any_coords, bool scattered)
+                      int blk, uint8_t *d_status, double *fea64_rows, bool any_coords, bool scattered, bool dense)
 {
     if (cn <= 0) return PK_OK;
     pk_prof_scope prof(ctx, PK_K_EXTRACT, st);
@@ -1475,7 +1475,7 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
                        tiles, blk, d_status, fea64_rows)
             const bool diag = (scattered || m->opt.extract_diag == 2) && !fea64_rows && m->opt.extract_diag != 0;  // (2: always)
             // lists of neighbours (the benchmark regime): the wave's diagonal strip staged in LDS
-            if (m->opt.extract_strip && !diag) {
+            if (m->opt.extract_strip == 2 || (m->opt.extract_strip == 1 && dense && !diag)) {
                 const unsigned sgrid = (grid + 7u) & ~7u;
                 g_stat_extract_strip++;
 #define PK_STRIP(WW, FF)                                                                                          \

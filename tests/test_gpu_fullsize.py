@@ -98,7 +98,8 @@ def test_config2_properties(config2):
                      dict(forest_q=0), dict(forest_q=0, forest_slots=5),
                      dict(forest_q=0, forest_img=0),
                      dict(forest_q=0, forest_img=0, forest_slots=4),
-                     dict(forest_lds=0), dict(extract_pair=0), dict(overlap=1), dict(overlap=1, chunk=65536),
+                     dict(forest_lds=0), dict(extract_pair=0), dict(extract_strip=0), dict(extract_strip=2, chunk=1000003),
+                     dict(overlap=1), dict(overlap=1, chunk=65536),
                      dict(sub_chunk=262144), dict(sub_chunk=100000, chunk=1000000)):
             with handle_options(opts, c["hm"], c["hf"]):
                 cd2 = _lib.HipCands(x, y, options=opts)
@@ -123,13 +124,24 @@ def test_config2_properties(config2):
     assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
     assert np.array_equal(st != 0, st_ref != 0)
     assert np.array_equal(gio.bits(pr), gio.bits(pr_ref))
+    # the headline AS bench.py RUNS IT: the whole list, default options, with the permission Chromosome.score gives
+    # (decided candidates may end at probability 0), which cuts the forest in two -- against the oracle's pixels
+    cdp = _lib.HipCands(x, y)
+    cdp.set_prune(True)
+    for _ in range(3):     # (the cut places itself by what the first calls show)
+        assert cdp.run(c["hm"], c["hf"], w, 0.5) == n1
+    assert c["hf"].get_option("stat_split_group") > 0, "the forest was not cut"
+    px, py, pp, ps = cdp.fetch()
+    cdp.close()
+    assert np.array_equal(px, rx) and np.array_equal(py, ry)
+    assert np.array_equal(gio.bits(pp), gio.bits(rp)) and np.array_equal(gio.bits(ps), gio.bits(rs))
 
 
 def test_config4_full_parity_trained_forest(hip_lib):
     """configs[3]: 5 kb map (60 000 bins, 800-bin band, upper = 800), the TRAINED w=5
-    forest, every 4th band pixel (8.7 M candidates): scored pixels and per-candidate
-    status / probability bit-exact against the oracle on all host cores."""
-    w, n, band, upper, stride = 5, 60000, 800, 800, 4
+    forest, EVERY band pixel (34.9 M candidates; rounds 3-5: every 4th): scored pixels and per-candidate
+    status / probability bit-exact against the oracle on all host cores (about half a minute of them)."""
+    w, n, band, upper, stride = 5, 60000, 800, 800, 1
     M, _ = synth.synth_band(n, band, seed=4)
     e = utils.calculate_expected(M, upper + 2 * w, raw=True)
     Mf = utils.band_filter(M, w, upper)

@@ -66,6 +66,28 @@ def test_score_chromosome_chr21_on_an_hg19_shaped_map(genome, tmp_path):
     assert got.count(b"\n") > 300
 
 
+def test_score_chromosome_chr1_at_the_default_upper(hip_lib, tmp_path):
+    """The CLI's DEFAULT -u 300 on the genome's largest chromosome (chr1 of hg19: 24 926 bins) over a map whose
+    band is wider than upper + 2w (320 bins), weights on: bedpe bytes against the oracle chain.  (The genome-wide
+    tests above run -u 100 on a 120-bin band to keep their CPU chain short.)"""
+    from peakachu_amd import synth
+    work = str(tmp_path / "chr1")
+    man = gs.synthesize(work, band=320, seed=11, chroms=synth.HG19_CHROMS[:1])
+    assert man["chroms"][0]["name"] == "chr1" and man["chroms"][0]["bins"] == 24926
+    if gs.have_h5py_writer():
+        path = os.path.join(work, "chr1.cool")
+        gs.write_cool(work, path, level=1)
+    else:
+        path = os.path.join(work, "chr1.pkmap.npz")
+        gs.write_pkmap(man, work, path)
+    out, ref = str(tmp_path / "gpu.bedpe"), str(tmp_path / "oracle.bedpe")
+    _cli(["score_chromosome", "-p", path, "-m", MODEL, "-O", out, "-C", "chr1"])   # -l 6 -u 300, weight: the defaults
+    T = gs.oracle_bedpe(man, work, MODEL, "weight", 6, 300, 0.5, ref, only=[0])
+    got = open(out, "rb").read()
+    assert got == open(ref, "rb").read()
+    assert T["candidates_total"] > 50000 and got.count(b"\n") > 1000   # not vacuous
+
+
 def _same_chromosome(A, B, thre=0.3):
     import numpy as np
     bits = lambda a: np.ascontiguousarray(a, np.float64).view(np.uint64)

@@ -48,7 +48,7 @@ def _extract_golden(name, pair=1):
     ok = z["x"] <= z["y"]
     x, y = z["x"][ok], z["y"][ok]
     strip0 = L.pk_get_option(b"stat_extract_strip")
-    hm = hip_matrix(Mf, z["exp_arr"], w, upper, options={"extract_pair": 1 if pair else 0, "extract_strip": 0 if pair == 2 else 1})
+    hm = hip_matrix(Mf, z["exp_arr"], w, upper, options={"extract_pair": 1 if pair else 0, "extract_strip": 0 if pair == 2 else 2})
     f64, f32, keep = hm.extract(w, x, y, want64=True, want32=True)
     if w in (5, 6) and "balanced" in name:   # (integer counts of the other fixtures qualify as well; this one must)
         assert (L.pk_get_option(b"stat_extract_strip") > strip0) == (pair == 1)

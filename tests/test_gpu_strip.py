@@ -32,7 +32,7 @@ def _lists(x, y, rng):
 def _matrix(Mf, e, w, upper, strip):
     Mc = utils.canonical_csr(Mf)
     return _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, Mc.shape[0], e, -2 * w + 1, upper + 2 * w - 1,
-                          options={"extract_strip": strip})
+                          options={"extract_strip": strip})   # 2: every list, 0: never, 1: lists of runs only
 
 
 @pytest.mark.parametrize("w", [5, 6])
@@ -48,7 +48,7 @@ def test_staged_features_equal_the_oracles(w, shape):
     Mf = utils.band_filter(M, w, upper)
     x, y = synth.all_band_pixels(Mf, 0, upper)   # from the main diagonal on: d < 2w, windows off the matrix
     rng = np.random.default_rng(n * 10 + w)
-    hs, hr = _matrix(Mf, e, w, upper, 1), _matrix(Mf, e, w, upper, 0)
+    hs, hr = _matrix(Mf, e, w, upper, 2), _matrix(Mf, e, w, upper, 0)
     try:
         for name, (lx, ly) in _lists(x, y, rng).items():
             before = L.pk_get_option(b"stat_extract_strip")
@@ -78,7 +78,7 @@ def test_staged_windows_that_are_not_normalised(w):
     x, y = synth.all_band_pixels(Mf, w + 1, upper)
     sel = (y - x > 30 - 2 * w) & (y - x < 52)
     x, y = x[sel], y[sel]
-    hs = _matrix(Mf, e_short, w, upper, 1)
+    hs = _matrix(Mf, e_short, w, upper, 2)
     try:
         f64, _, keep = hs.extract(w, x, y)
     finally:
@@ -103,7 +103,7 @@ def test_scoring_through_the_staged_extractor(w):
     hf = _lib.HipForest(fo)
     got = {}
     try:
-        for strip in (1, 0):
+        for strip in (2, 0):
             hm = _matrix(Mf, e, w, upper, strip)
             cd = _lib.HipCands(x, y, options={"chunk": 65536})
             cd.run(hm, hf, w, 0.4, 10000)
@@ -112,9 +112,37 @@ def test_scoring_through_the_staged_extractor(w):
             cd.close(); hm.close()
     finally:
         hf.close()
-    assert np.array_equal(got[1][0], got[0][0]) and np.array_equal(gio.bits(got[1][1]), gio.bits(got[0][1]))
+    assert np.array_equal(got[2][0], got[0][0]) and np.array_equal(gio.bits(got[2][1]), gio.bits(got[0][1]))
     fod = {k: getattr(fo, k) for k in FlatForest.FIELDS}
     rx, ry, rp, rs = onp.score(Mf, e, w, fod, 0.4, x, y, batch=10000, threads=0)
-    ox, oy, op, osig = got[1][2]
+    ox, oy, op, osig = got[2][2]
     assert rx.size > 100 and np.array_equal(ox, rx) and np.array_equal(oy, ry)
     assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
+
+
+def test_the_library_stages_lists_of_runs_only():
+    """Default option (extract_strip = 1): a list whose batches of 32 are runs on one diagonal goes through the
+    staged kernel, a strided, a shuffled or a Poisson-thinned one through the register-gather kernel (a wave
+    would need a pass per run).  The route only: results are equal either way (tests above)."""
+    w, n, band, upper = 5, 3000, 120, 100
+    L = _lib.load()
+    M, _ = synth.synth_band(n, band, seed=3)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, w + 1, upper)
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w5_t100.npz"))
+    hf, hm = _lib.HipForest(fo), _matrix(Mf, e, w, upper, 1)
+    rng = np.random.default_rng(0)
+    keep = rng.random(x.size) < 0.93           # a band with 7 % empty pixels: still runs
+    p = rng.permutation(x.size)
+    try:
+        for name, lx, ly, want in (("all", x, y, True), ("thinned 7 %", x[keep], y[keep], True),
+                                   ("every 4th", x[::4], y[::4], False), ("shuffled", x[p], y[p], False),
+                                   ("one in 50", x[::50], y[::50], False), ("short", x[:20], y[:20], True)):
+            cd = _lib.HipCands(lx.copy(), ly.copy())
+            before = L.pk_get_option(b"stat_extract_strip")
+            cd.run(hm, hf, w, 0.5)
+            assert (L.pk_get_option(b"stat_extract_strip") > before) == want, name
+            cd.close()
+    finally:
+        hm.close(); hf.close()
