@@ -1367,7 +1367,11 @@ __global__ __launch_bounds__(Q_THREADS) __attribute__((amdgpu_num_vgpr(PK_QR_VGP
     A.split_rem = sp.rem;
     // the role of this wave, once: rank tile = wave & 1, position among the waves of its SIMD = wave >> 2
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef PK_QR_FOLD_TEST   // (timing experiment, WRONG results: every wave runs the body of rank tile 0 -- four role copies)
+    switch ((wave >> 2) << 1) {
+#else
     switch (((wave >> 2) << 1) | (wave & 1)) {
+#endif
     case 0: qr_body<HALF1, PRUNE, NR, 0, 0, SPLIT>(A); break;
     case 1: qr_body<HALF1, PRUNE, NR, HALF1, 0, SPLIT>(A); break;
     case 2: qr_body<HALF1, PRUNE, NR, 0, 1, SPLIT>(A); break;
