@@ -68,7 +68,7 @@ def main():
             e = e[: max(3, e.size // 2)].copy()   # too short: windows far from the diagonal stay unnormalised
         Mf = utils.band_filter(M, w, upper)
         x, y = synth.all_band_pixels(Mf, w + 1, upper)
-        keep = rng.random(x.size) < 0.6
+        keep = rng.random(x.size) < float(rng.choice([0.6, 0.6, 0.93, 1.0]))   # thinned lists, and lists of runs
         x, y = x[keep], y[keep]
         x = np.r_[x, [0, 1, n - w - 2]].astype(np.int32)
         y = np.r_[y, [w + 2, w + 3, n - 1]].astype(np.int32)
@@ -91,6 +91,8 @@ def main():
             opts["extract_clean"] = 0
         if rng.random() < 0.15:
             opts["extract_row16"] = 0
+        if rng.random() < 0.4:     # the LDS-staged extractor: never / on every list (default: lists of runs only)
+            opts["extract_strip"] = int(rng.choice([0, 2, 2]))
         if rng.random() < 0.15:
             opts["early_exit"] = 1
         if rng.random() < 0.4:     # the forest cut in two (pk_score always allows it): any length, any cut
