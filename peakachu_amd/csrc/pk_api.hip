@@ -294,7 +294,8 @@ static int opt_assign(pk_options &o, const char *name, int64_t value)
     } else if (!strcmp(name, "extract_pair")) {
         o.extract_pair = value != 0;
     } else if (!strcmp(name, "extract_row16")) {
-        o.extract_row16 = value != 0;
+        if (value < 0 || value > 2) return PK_E_INVALID;
+        o.extract_row16 = value;  // (2: one wave per workgroup, the form of rounds 3-5)
     } else if (!strcmp(name, "extract_strip")) {
         if (value < 0 || value > 2) return PK_E_INVALID;
         o.extract_strip = value;

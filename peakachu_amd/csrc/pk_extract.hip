@@ -1000,8 +1000,16 @@ struct row16_geom {
     static constexpr int TS = F + ((16 - F % 32) + 32) % 32;  // window stride in LDS, 16 (mod 32) doubles
 };
 
-template <int W, bool FEA64>
-__global__ __launch_bounds__(64, 2) void extract_row16_clean_kernel(
+// WAVES = 4 (round 6, the scoring path): four waves = sixteen consecutive candidates per workgroup.  A wave's
+// feature stores are 16-byte pieces (its four candidates) of sixteen different lines per instruction -- a quarter
+// of the kernel's time (ablation: profiles/r06_w11_ab.log); here every wave parks its float features in
+// its own (by then dead) transpose buffer and, behind one barrier, the workgroup writes rows of sixteen
+// candidates: 64 contiguous bytes per feature, four lines per store instruction: 3.07 -> 2.88 ms on configs[4].
+// (Tried on top and not kept: the wave's strip of the band staged in LDS like extract_pair_strip_kernel's -- 18
+// global_load_lds_dwordx4 for FOUR candidates cost more than the 58 per-lane loads they replace: 3.53 ms;
+// profiles/r06_w11_ab.log.)
+template <int W, bool FEA64, int WAVES = 1>
+__global__ __launch_bounds__(64 * WAVES, 2) void extract_row16_clean_kernel(
     const double *__restrict__ band, unsigned norm_off, int ld, int dlo, int dhi, int n, int exp_len,
     const int32_t *__restrict__ xs, const int32_t *__restrict__ ys, int64_t c0, int64_t cn,
     float *__restrict__ tiles, int blk, uint8_t *__restrict__ status,
@@ -1011,19 +1019,40 @@ __global__ __launch_bounds__(64, 2) void extract_row16_clean_kernel(
     constexpr int S = G::S, F = G::F, NS = G::NS, TS = G::TS;
     static_assert(S > 16 && S <= 32 && NS == 2, "two column slots per lane");
     static_assert(W >= 4, "reflect folds once");
-    __shared__ double T[4 * TS];
-    const unsigned lane = threadIdx.x, q = lane >> 4, l = lane & 15;
+    static_assert(WAVES == 1 || (WAVES == 4 && !FEA64), "the workgroup form is the scoring path's");
+    constexpr int REG = 4 * TS;  // a wave's LDS region: its four window buffers (transposes)
+    __shared__ double T[WAVES * REG];
+    __shared__ unsigned char okf[16];
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, l = lane & 15;
+    const unsigned wv = WAVES == 1 ? 0u : (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // XCD-aware order (see the w = 5 kernel): XCD x takes the x-th contiguous eighth
     const unsigned per_xcd = gridDim.x >> 3;
-    const int64_t wave0 = (int64_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * 4;
+    const int64_t wg0 = (int64_t)((blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3)) * (4 * WAVES);
+    const int64_t wave0 = wg0 + 4 * wv;
     const int64_t local = wave0 + q;
     const bool in_range = local < cn;
     const int64_t c = c0 + (in_range ? local : 0);
     const int xi = xs[c], yi = ys[c];
     bool ok = in_range && (xi - W >= 0 && yi + W + 1 <= n) && PK_OTHER_EDGES(xi, yi, W, n);
     const unsigned long long okmask = __ballot(ok);
+    // the workgroup's write-out (WAVES = 4): thread t takes candidate t & 15 of the sixteen and, per trip, feature
+    // 16 * trip + (t >> 4) -- a wave stores four features x sixteen candidates, 64 contiguous bytes each
+    auto write_out = [&]() {
+        const unsigned t = threadIdx.x, c16 = t & 15u, fsub = t >> 4;
+        const bool ok16 = okf[c16] != 0;
+        const int64_t first = wg0 / blk;  // (the sixteen share a tile: blk is a multiple of 16)
+        float *tp16 = tiles + (size_t)first * F * blk + (int)(wg0 - first * blk) + c16;
+        const float *O = reinterpret_cast<const float *>(T + (c16 >> 2) * REG) + (c16 & 3u);
+        if (ok16)
+            for (int f = (int)fsub; f < F; f += 16) tp16[(size_t)f * blk] = O[f * 4];
+    };
     if (okmask == 0ull) {  // wave-uniform
         if (in_range && l == 0) status[c] = 0;
+        if constexpr (WAVES > 1) {
+            if (l == 0) okf[wv * 4 + q] = 0;
+            __syncthreads();
+            write_out();
+        }
         return;
     }
     // rows without a window shadow the first valid one of the wave (every load stays in range)
@@ -1126,7 +1155,7 @@ __global__ __launch_bounds__(64, 2) void extract_row16_clean_kernel(
     for (int o = 8; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o, 16);
     ok = ok && !((double)nnz < (double)F * 0.1);
     // ---- gaussian_filter(sigma=1), axis 0: down each column, straight into the transpose buffer
-    double *Tq = T + q * TS;
+    double *Tq = T + wv * REG + q * TS;
 #pragma unroll
     for (int s = 0; s < NS; s++) {
 #pragma unroll
@@ -1138,7 +1167,9 @@ __global__ __launch_bounds__(64, 2) void extract_row16_clean_kernel(
             if (jv[s]) Tq[i * S + jj[s]] = v;
         }
     }
-    __syncthreads();  // (one wave: orders this wave's LDS writes before its reads)
+    // (orders this wave's LDS writes before its reads: every window buffer is its wave's own)
+    if constexpr (WAVES == 1) __syncthreads();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // ---- axis 1: lane l now owns window ROWS l and l + 16
     double outv[NS][S];
     double mn = __builtin_inf(), mx = -__builtin_inf();
@@ -1186,7 +1217,11 @@ __global__ __launch_bounds__(64, 2) void extract_row16_clean_kernel(
             const double a = outv[s][j] - mn;
             const double m = a * r;
             const double v = flat ? qn : __builtin_fma(__builtin_fma(-den, m, a), r, m);
-            if (ok && jv[s]) {
+            if constexpr (WAVES > 1) {
+                // parked for the workgroup's write-out: [feature][4 candidates of this wave] floats over the wave's
+                // window buffers (every read of them is behind this wave: the rows were taken above)
+                if (jv[s]) reinterpret_cast<float *>(T + wv * REG)[(jj[s] * S + j) * 4 + q] = (float)v;
+            } else if (ok && jv[s]) {
                 const int f = jj[s] * S + j;
                 tp[(size_t)f * blk] = (float)v;  // sklearn's float32 cast (RNE)
                 if (FEA64) rp[f] = v;
@@ -1194,6 +1229,11 @@ __global__ __launch_bounds__(64, 2) void extract_row16_clean_kernel(
         }
     }
     if (in_range && l == 0) status[c] = ok ? (flat ? 2 : 1) : 0;
+    if constexpr (WAVES > 1) {
+        if (l == 0) okf[wv * 4 + q] = ok ? 1 : 0;
+        __syncthreads();
+        write_out();
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -1535,8 +1575,13 @@ int pk_launch_extract(pk_device_ctx *ctx, hipStream_t st, const pk_matrix *m, in
             g_stat_extract_clean++;
             const unsigned norm_off = (unsigned)((const char *)m->norm - (const char *)m->band);
             const unsigned grid4 = (unsigned)(((cn + 3) / 4 + 7) & ~(int64_t)7);
+            const unsigned grid16 = (unsigned)(((cn + 15) / 16 + 7) & ~(int64_t)7);
             if (fea64_rows)
                 hipLaunchKernelGGL((extract_row16_clean_kernel<11, true>), dim3(grid4), dim3(64), 0, st, m->band,
+                                   norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,
+                                   tiles, blk, d_status, fea64_rows);
+            else if (blk % 16 == 0 && m->opt.extract_row16 != 2)   // (option value 2: the one-wave form)
+                hipLaunchKernelGGL((extract_row16_clean_kernel<11, false, 4>), dim3(grid16), dim3(256), 0, st, m->band,
                                    norm_off, (int)m->ld, m->dlo, m->dhi, m->n, m->exp_len, d_x, d_y, c0, cn,
                                    tiles, blk, d_status, fea64_rows);
             else

@@ -146,3 +146,41 @@ def test_the_library_stages_lists_of_runs_only():
             cd.close()
     finally:
         hm.close(); hf.close()
+
+
+def test_w11_workgroup_stores_equal_the_one_wave_kernel():
+    """w = 11 (23 x 23 windows; four windows per wave): since round 6 four waves form a workgroup and write the
+    features of their sixteen candidates together, 64 contiguous bytes per feature (option extract_row16 = 1;
+    2 = the one-wave kernel of rounds 3-5).  Status and probability of every candidate, bit for bit, on lists
+    whose last workgroup is partly filled and whose waves have windows off the matrix; scored pixels = the oracle's."""
+    w, n, band, upper = 11, 900, 90, 60
+    M, _ = synth.synth_band(n, band, seed=17)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    Mf = utils.band_filter(M, w, upper)
+    x, y = synth.all_band_pixels(Mf, 0, upper)
+    fo = FlatForest.load(os.path.join(ROOT, "peakachu_amd", "data", "forest_w11_t500.npz"))
+    hf = _lib.HipForest(fo)
+    Mc = utils.canonical_csr(Mf)
+    rng = np.random.default_rng(2)
+    p = rng.permutation(x.size)[:5000]
+    try:
+        for name, lx, ly in (("all", x, y), ("odd tail", x[:1003], y[:1003]), ("seven", x[40:47], y[40:47]),
+                             ("shuffled", x[p], y[p])):
+            got = {}
+            for form in (1, 2):
+                hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e, -2 * w + 1, upper + 2 * w - 1,
+                                    options={"extract_row16": form})
+                cd = _lib.HipCands(lx.copy(), ly.copy())
+                cd.run(hm, hf, w, 0.5)
+                st, pr = cd.fetch_all()
+                got[form] = (st.copy(), pr.copy(), cd.fetch())
+                cd.close(); hm.close()
+            assert np.array_equal(got[1][0], got[2][0]) and np.array_equal(gio.bits(got[1][1]), gio.bits(got[2][1])), name
+            if name == "all":
+                fod = {k: getattr(fo, k) for k in FlatForest.FIELDS}
+                rx, ry, rp, rs = onp.score(Mf, e, w, fod, 0.5, lx, ly, threads=0)
+                ox, oy, op, osig = got[1][2]
+                assert rx.size > 10 and np.array_equal(ox, rx) and np.array_equal(oy, ry)
+                assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
+    finally:
+        hf.close()
