@@ -486,6 +486,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # (dmabuf IPC: what RCCL needs between processes on this pool; read when the runtime initialises, so before
+    # the library is loaded -- the launchers set it too)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if a.gpus != world:
         if "WORLD_SIZE" not in os.environ and a.gpus > 1:
             # started bare (`python bench.py --gpus N`): become the launcher.  The ranks are
