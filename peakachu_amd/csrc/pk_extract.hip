@@ -11,9 +11,12 @@
 //    wave of 64 candidates that are consecutive along one diagonal -- the
 //    reference's candidate order -- every one of the (2w+1)^2 window-cell
 //    loads is a contiguous 512-byte read;
-//  * one candidate per lane, the whole window in VGPRs (242 for w=5, 338 for
-//    w=6; a wave owns its SIMD's 512-register file), fully unrolled so every
-//    register index is static; no LDS, no barriers;
+//  * the window lives in VGPRs, fully unrolled so every register index is static: two lanes
+//    per candidate at w = 5, 6 (extract_pair_*: each lane half the window, DPP swaps for the
+//    row blur), one lane per candidate in the first kernel (extract_reg_kernel);
+//  * for lists of neighbours on clean matrices the wave's strip of the band is staged in LDS
+//    by LDS-DMA and the window read from there (extract_pair_strip_kernel, round 6: the
+//    default of the benchmark regime); scattered lists gather straight from the band;
 //  * the arithmetic order is scipy's / numba's exactly and the file is built
 //    with -ffp-contract=off: no FMA contraction, IEEE division;
 //  * float32 features leave in [tile][F][BLK] order so the store of feature
