@@ -319,6 +319,12 @@ int pk_comm_gather_scored(pk_comm *, pk_cands *, int64_t *counts, int64_t cap,
 int pk_comm_gatherv_bytes(pk_comm *, const void *send, int64_t nbytes, int64_t *counts,
                           void *recv, int64_t cap);
 
+/* diagnostic, needs no device: how the library classifies a candidate list when it is made (the route of the
+ * extractor, never a result): bit 0 = consecutive candidates are rarely neighbours on a diagonal (get_candidate's
+ * lists: loads in the order of the window's diagonals), bit 1 = the batches of 32 consecutive candidates are runs
+ * on one diagonal ("every non-zero pixel of the band": the wave's strip of the band is staged in LDS). */
+int pk_debug_classify_coords(int64_t N, const int32_t *x, const int32_t *y);
+
 /* diagnostic, needs no device: the bound the forest kernels' early exit / cut tests `acc + remaining`
  * against for threshold `thre`, a forest of T trees and at most `additions` terms still to add --
  * thre * T less a proven rounding margin (csrc/pk_common.h: pk_prune_bound; tests/test_prune_bound.py). */

@@ -91,6 +91,7 @@ SIGNATURES = {
                                          _u32p, _f32p, C.c_int64, _u64p, C.POINTER(C.c_int64),
                                          C.c_int64, _i32p, C.POINTER(C.c_int32), _i32p, C.c_int32, _i32p]),
     "pk_debug_prune_bound": (C.c_double, [C.c_double, C.c_int, C.c_int64]),
+    "pk_debug_classify_coords": (C.c_int, [C.c_int64, _i32p, _i32p]),
     "pk_debug_cut_policy": (C.c_int, [_i32p, C.c_int, C.c_double, C.c_int, _f64p, C.c_int, _i32p]),
     "pk_host_unfilter_chunks": (C.c_int, [C.c_int, _vp, _i64p, C.c_int, C.c_int, C.c_int64, _i64p, _i64p, _vp,
                                           C.c_int]),

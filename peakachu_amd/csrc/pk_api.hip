@@ -1157,6 +1157,13 @@ static int coords_dense(int64_t N, const int32_t *x, const int32_t *y)
     return good * 10 >= seen * 9 ? 1 : 0;
 }
 
+// (include/peakachu_hip.h: what the two samplers above say about a list, without a device)
+extern "C" int pk_debug_classify_coords(int64_t N, const int32_t *x, const int32_t *y)
+{
+    if (N < 0 || (N > 0 && (!x || !y))) return PK_E_INVALID;
+    return (coords_scattered(N, x, y) ? 1 : 0) | (coords_dense(N, x, y) ? 2 : 0);
+}
+
 extern "C" pk_cands *pk_cands_create(int device, int64_t N, const int32_t *x, const int32_t *y)
 {
     PK_DEV_LOCK(device);

@@ -118,3 +118,35 @@ def test_host_chunk_pipeline_inflates_and_unshuffles():
         rc = L.pk_host_unfilter_chunks(1, C.cast(src, C.c_void_p), lens, 1, es, n_el * es, np.array([es * 999], np.int64),
                                        np.array([es * 2], np.int64), C.cast(dst, C.c_void_p), 1)
         assert rc == _lib.PK_E_INVALID
+
+
+def test_candidate_lists_are_classified_by_shape():
+    """pk_debug_classify_coords (no device): what decides the extractor's route when a list is made -- bit 1:
+    batches of 32 consecutive candidates are runs on one diagonal (the strip of the band is staged in LDS),
+    bit 0: consecutive candidates are rarely neighbours (loads in the order of the window's diagonals).
+    Shapes only: get_candidate's order is diagonal by diagonal, row ascending (peakachu/scoreUtils.py:46-68)."""
+    from peakachu_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    n = 4000
+    xs, ys = [], []
+    for d in range(6, 60):                      # every pixel of the band, diagonal by diagonal
+        x = np.arange(0, n - d, dtype=np.int32)
+        xs.append(x); ys.append(x + d)
+    x, y = np.concatenate(xs), np.concatenate(ys)
+
+    def kind(px, py):
+        return L.pk_debug_classify_coords(px.size, np.ascontiguousarray(px, np.int32), np.ascontiguousarray(py, np.int32))
+
+    assert kind(x, y) == 2
+    keep = rng.random(x.size) < 0.93            # seven per cent of the pixels empty: still runs
+    assert kind(x[keep], y[keep]) == 2
+    keep = rng.random(x.size) < 0.5             # half empty: a batch spans ~64 rows -- neither
+    assert kind(x[keep], y[keep]) == 0
+    assert kind(x[::4], y[::4]) == 1            # strided: scattered, no runs
+    keep = rng.random(x.size) < 0.02            # the Poisson-thinned kind
+    assert kind(x[keep], y[keep]) == 1
+    p = rng.permutation(x.size)
+    assert kind(x[p], y[p]) == 1
+    assert kind(x[:20], y[:20]) == 2            # a short run
+    assert kind(x[:0], y[:0]) == 0
