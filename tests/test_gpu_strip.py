@@ -184,3 +184,34 @@ def test_w11_workgroup_stores_equal_the_one_wave_kernel():
                 assert np.array_equal(gio.bits(op), gio.bits(rp)) and np.array_equal(gio.bits(osig), gio.bits(rs))
     finally:
         hf.close()
+
+
+@pytest.mark.parametrize("w", [5, 6])
+def test_staged_windows_that_reach_outside_a_narrow_band(w):
+    """A matrix handle whose stored band [dlo, dhi] is NARROWER than the windows of its candidates reach on both
+    sides (pk_matrix_create takes any band; cells outside it are absent: they read 0, peakachu/scoreUtils.py:81):
+    the staged kernel fetches such rows from a neighbour inside the band and zeroes them in LDS -- here for most
+    rows of most windows, not only the far corner of the last diagonal."""
+    from scipy import sparse
+    n, band, upper = 900, 70, 50
+    M, _ = synth.synth_band(n, band, seed=40 + w)
+    e = utils.calculate_expected(M, upper + 2 * w, raw=True)
+    dlo, dhi = 3, upper - 4                      # the main diagonal's neighbourhood and the far band are not stored
+    C = sparse.coo_matrix(M)
+    keep = (C.col - C.row >= dlo) & (C.col - C.row <= dhi)
+    Mn = sparse.csr_matrix((C.data[keep], (C.row[keep], C.col[keep])), shape=M.shape)
+    Mc = utils.canonical_csr(Mn)
+    x, y = synth.all_band_pixels(Mn, dlo, dhi)
+    x, y = np.ascontiguousarray(x, np.int32), np.ascontiguousarray(y, np.int32)
+    got = {}
+    for strip in (2, 0):
+        hm = _lib.HipMatrix(Mc.indptr, Mc.indices, Mc.data, n, e, dlo, dhi, options={"extract_strip": strip})
+        try:
+            got[strip] = hm.extract(w, x, y)
+        finally:
+            hm.close()
+    fea, keep_o = onp.extract(Mn, e, w, x, y)
+    for strip in (2, 0):
+        f64, _, keep_g = got[strip]
+        assert np.array_equal(keep_g, keep_o) and keep_o.size > 1000, strip
+        assert np.array_equal(gio.bits(f64), gio.bits(fea)), strip
