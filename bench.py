@@ -268,6 +268,25 @@ def pmc_rooflines(dom, launches_per_step_live, pmc_file="pmc.json"):
     return traffic, issue, lds
 
 
+def pmc_path_traffic(kern, steps, pmc_file="pmc.json"):
+    """HBM bytes of a whole STEP from the committed PMC passes: per kernel class (extract, quantizer, forest head,
+    forest tail) the measured bytes per launch x the launches this run made per step.  None when the kernel
+    sources changed since the passes (or a class was not measured)."""
+    path = os.path.join(ROOT, "profiles", pmc_file)
+    try:
+        P = json.load(open(path))
+        if P.get("source_sha") != source_sha():
+            return None
+        total = 0.0
+        for cls, pmc_cls in (("extract", "extract"), ("quant", "quant"), ("forest", "forest"), ("forest_tail", "forest_tail")):
+            launches = kern[cls][1] / float(steps)
+            if launches > 0:
+                total += P[pmc_cls]["hbm_bytes_per_launch"] * launches
+        return total
+    except Exception:
+        return None
+
+
 def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, steps, pmc_file=None):
     """One of the non-headline BASELINE.json configurations, measured the same way in the same
     process (device-resident candidates, pk_score_run, HIP-event kernel times), a few steps
@@ -316,9 +335,14 @@ def extra_config(L, dev, name, n, band, w, upper, forest_spec, thre, batch, step
             "value": value, "unit": "candidates/s", "steps": steps, "ms_per_step": el / steps * 1e3,
             "candidates": int(x.size), "scored_pixels": int(n_out), "early_exit_allowed": True, "forest_cut": cut,
             "kernel_ms_per_step": {k: v[0] / steps for k, v in kern.items()},
+            # (as in the headline: `achieved` / `frac` = the whole path, the per-kernel recipe beside it)
             "roofline": {"bound": "hbm", "kernel": dom + (" (head of the cut forest)" if (cut and dom == "forest") else ""),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "achieved": value * b_alg(F) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": value * b_alg(F) / 1e9 / HBM_PEAK_GBS,
+                         "frac_is": "whole path: candidates/s x B_alg / peak (SURVEY 8d)",
+                         "dominant_kernel_achieved": achieved, "dominant_kernel_frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_path_traffic(kern, steps, pmc_file) if pmc_file else None,
+                         "dominant_kernel_traffic": traffic,
                          "alg_bytes_per_candidate": b_alg(F),
                          "avg_launch_ms": dom_ms / dom_n if dom_n else None, "launches": dom_n,
                          "candidates_per_launch": float(x.size) * steps / dom_n if dom_n else None,
@@ -788,11 +812,12 @@ def main():
         # HBM bytes per launch of the dominant kernel and its binding rooflines, from the
         # committed PMC passes (profiles/pmc.json); only valid for the default workload and
         # reported as stale (traffic = null) when the kernel sources changed since
-        traffic = issue_roof = lds_roof = None
+        traffic = issue_roof = lds_roof = path_traffic = None
         default_workload = (w == 5 and a.n == 30000 and a.band == 200 and a.stride == 1 and not a.forest
                             and not a.opt and world == 1)
         if default_workload and dom_n:
             traffic, issue_roof, lds_roof = pmc_rooflines(dom, dom_n / a.steps)
+            path_traffic = pmc_path_traffic(kern, a.steps)
         fst = fo.stats()
         out = {
             "metric": "candidate pixels scored/sec",
@@ -861,7 +886,13 @@ def main():
                 "dominant_kernel_frac": achieved / HBM_PEAK_GBS,
                 "dominant_kernel_frac_stage_time": (alg_bytes_total / (kern[dom][0] * 1e-3) / 1e9 / HBM_PEAK_GBS
                                                     if kern[dom][0] > 0 else None),
-                "traffic": traffic,
+                # HBM bytes the PMC counters saw (the guide's recipe, profiles/pmc.json): `traffic` = the whole
+                # path's per STEP, beside the algorithmic bytes of a step it is to be read against;
+                # `dominant_kernel_traffic` = that kernel's per launch
+                "traffic": path_traffic,
+                "alg_bytes_per_step": float(n_local) * b_alg(F),
+                "traffic_per_candidate": (path_traffic / n_local) if path_traffic else None,
+                "dominant_kernel_traffic": traffic,
                 # measured HBM rate of that kernel: PMC bytes per launch / its average duration
                 "traffic_GBs": (traffic / (dom_ms / dom_n * 1e-3) / 1e9) if (traffic and dom_n) else None,
                 "alg_bytes_per_candidate": b_alg(F),
