@@ -476,6 +476,9 @@ __global__ __launch_bounds__(64, (W <= 5 ? PK_EXTRACT_OCC : 1)) void extract_pai
 // centre cell; `ok` = the lane has a window (the filters below may still drop it), `st` = the lane of role A
 // writes its candidate's status byte (a lane that only shadows another one does not).  STORE_DROPPED: a lane
 // with `st` stores its features whether the filters drop it or not.
+// A feature is written once and read once, by the quantizer: non-temporal stores keep the 1.5 GB of a chunk's
+// float tiles from displacing the band in the L2 (and the quantizer behind runs faster: profiles/r06_ab_nontemporal.log)
+#define PK_TILE_STORE(p_, v_) __builtin_nontemporal_store((v_), (p_))
 template <int W, bool FEA64, bool STORE_DROPPED = false>
 __device__ __forceinline__ void pair_clean_finish(
     double (&win)[2 * W + 1][W + 1], double acc, const double centre, bool ok, const bool st, const int role,
@@ -566,8 +569,8 @@ __device__ __forceinline__ void pair_clean_finish(
 #define PK_PUT(i_, q_, v_)                                                                      \
     do {                                                                                        \
         if ((STORE_DROPPED ? st : ok) && ((q_) < W || role == 0)) {                             \
-            *reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24((i_) * S + (q_), sblk4))) = \
-                (float)(v_); /* sklearn's float32 cast (RNE) */                                 \
+            PK_TILE_STORE(reinterpret_cast<float *>(tbase + (unsigned)(t0 + __mul24((i_) * S + (q_), sblk4))), \
+                          (float)(v_)); /* sklearn's float32 cast (RNE) */                      \
             if (FEA64) rp[role ? F - 1 - ((i_) * S + (q_)) : (i_) * S + (q_)] = (v_);           \
         }                                                                                       \
     } while (0)
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(64, (!FEA64 ? 2 : 1)) void extract_pair_strip_kerne
     const int64_t local = wave0 + (lane_id >> 1);
     const bool in_range = local < cn;
     const int64_t c = c0 + (in_range ? local : wave0);
-    const int xi = xs[c], yi = ys[c];
+    const int xi = __builtin_nontemporal_load(xs + c), yi = __builtin_nontemporal_load(ys + c);  // (read once)
     const bool valid = in_range && (xi - W >= 0 && yi + W + 1 <= n) && PK_OTHER_EDGES(xi, yi, W, n);
     if (in_range && !valid && role == 0) status[c] = 0;
     const char *bbase = reinterpret_cast<const char *>(band);
@@ -1047,7 +1050,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void extract_row16_clean_kernel(
         float *tp16 = tiles + (size_t)first * F * blk + (int)(wg0 - first * blk) + c16;
         const float *O = reinterpret_cast<const float *>(T + (c16 >> 2) * REG) + (c16 & 3u);
         if (ok16)
-            for (int f = (int)fsub; f < F; f += 16) tp16[(size_t)f * blk] = O[f * 4];
+            for (int f = (int)fsub; f < F; f += 16) PK_TILE_STORE(tp16 + (size_t)f * blk, O[f * 4]);
     };
     if (okmask == 0ull) {  // wave-uniform
         if (in_range && l == 0) status[c] = 0;

@@ -137,8 +137,12 @@ __global__ __launch_bounds__(1024) void quantize_tiles_kernel(
 #pragma unroll
         for (int k = 0; k < TP; k++) {
             const int kk = (tile64 && t + k >= n_tiles) ? 0 : k;  // (single tiles: nothing behind the last one)
-            x[2 * k] = src[(size_t)kk * kstride];
-            x[2 * k + 1] = src[(size_t)kk * kstride + 64];
+            // (non-temporal: the float tile is read once and the rank tile written once -- 1.5 GB per chunk that
+            // would otherwise push the lookup tables and the next kernel's working set out of the L2; with the
+            // extractor's stores marked the same way the quantizer runs 0.81 -> 0.71 ms per step of config 2:
+            // profiles/r06_ab_nontemporal.log)
+            x[2 * k] = __builtin_nontemporal_load(src + (size_t)kk * kstride);
+            x[2 * k + 1] = __builtin_nontemporal_load(src + (size_t)kk * kstride + 64);
         }
         q_codes<2 * TP>(x, code, thr, lut, lo, inv, shift);
         // dword j of a row holds the codes of candidates j (low half) and j + 64 (high
@@ -150,8 +154,8 @@ __global__ __launch_bounds__(1024) void quantize_tiles_kernel(
             for (int k = 0; k < TP; k++) {
                 if (t + k >= n_tiles) break;
                 unsigned short *d16 = qtiles + ((size_t)(t + k) * 2 * F + f) * 64 + lane;
-                d16[0] = (unsigned short)code[2 * k];
-                d16[(size_t)F * 64] = (unsigned short)code[2 * k + 1];
+                __builtin_nontemporal_store((unsigned short)code[2 * k], d16);
+                __builtin_nontemporal_store((unsigned short)code[2 * k + 1], d16 + (size_t)F * 64);
             }
             continue;
         }
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(1024) void quantize_tiles_kernel(
 #pragma unroll
         for (int k = 0; k < TP; k++) {
             if (t + k >= n_tiles) break;
-            dst[k * out_stride] = code[2 * k] | (code[2 * k + 1] << 16);
+            __builtin_nontemporal_store(code[2 * k] | (code[2 * k + 1] << 16), dst + k * out_stride);
         }
     }
 }
@@ -315,10 +319,10 @@ __device__ __forceinline__ double q_walk_one(unsigned root, int depth, unsigned 
 #define Q_PF_LOADX(q)                                                                           \
     if constexpr ((q) < PFN) {                                                                  \
         if ((q) < 3) {                                                                          \
-            if ((q) * ld_stride < ld_lo) pf##q = pf_src[min(ld_i0 + (q) * ld_stride, ld_lo - 1)];  \
+            if ((q) * ld_stride < ld_lo) pf##q = __builtin_nontemporal_load(pf_src + min(ld_i0 + (q) * ld_stride, ld_lo - 1)); \
         } else {                                                                                \
             const int r_ = (q) * ld_stride - ld_shift;                                          \
-            if (r_ < ld_hi) pf##q = pf_src[ld_base + min(ld_i0 + r_, ld_hi - 1)];               \
+            if (r_ < ld_hi) pf##q = __builtin_nontemporal_load(pf_src + ld_base + min(ld_i0 + r_, ld_hi - 1)); \
         }                                                                                       \
     }
 #define Q_PF_STORE(q)                                                          \
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
             const int nu = halves * (HB >> 4);
             for (int i = tid; i < nu; i += THREADS) {
                 const int o = i << 4;
-                *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = src[i];
+                *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = __builtin_nontemporal_load(src + i);
             }
         }
         // walk c of a lane = candidate lane + 64 (NCH * sub + c) of the workgroup
@@ -812,10 +816,18 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q_kernel(
 #define QR_LD_U(R, ptr) asm volatile("global_load_dwordx4 " R ", %0, %1" ::"v"(voff), "s"(ptr))
 // a row behind a test of its bit (the tile's rows, once per tile): the test is inside the assembly --
 // as a C++ `if` the compiler lays every conditional load out of line (two taken branches per load)
+// (a rank tile is read once: fetched non-temporally it does not push the band -- which the next chunk's extractor
+// reads again -- and the tree image out of the L2 / Infinity Cache: forest 2.11 -> 2.08 and the extractor behind it
+// 1.04 -> 0.98 ms per step of config 2, profiles/r06_ab_nontemporal.log)
+#ifndef PK_QR_TILE_PLAIN
+#define QR_TILE_POLICY " nt"
+#else
+#define QR_TILE_POLICY ""
+#endif
 #define QR_LD_ASM(bit, R, ptr)                                                              \
     asm volatile("s_bitcmp1_b32 %0, " #bit "\n\t"                                           \
                  "s_cbranch_scc0 .Lqr" #bit "_%=\n\t"                                       \
-                 "global_load_dwordx4 " R ", %1, %2\n"                                      \
+                 "global_load_dwordx4 " R ", %1, %2" QR_TILE_POLICY "\n"                     \
                  ".Lqr" #bit "_%=:" ::"s"(mask),                                            \
                  "v"(voff), "s"(ptr)                                                        \
                  : "scc")
@@ -1034,7 +1046,7 @@ __device__ __forceinline__ void qr_body(const qr_args &A)
             const int nu = halves * upt;
             for (int i = tid; i < nu; i += THREADS) {
                 const int o = i << 4;
-                *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = src[i];
+                *LDS_AT(lds_u4, o < HB ? o : o - HB + HALF1) = __builtin_nontemporal_load(src + i);
             }
             // first group: global -> registers -> LDS
             qr_issue<0, 8, NR>(A.img_b + (size_t)g_cur.z * 16, voff);
@@ -1457,8 +1469,8 @@ __global__ __launch_bounds__(Q_THREADS) void forest_q2_kernel(
 #define Q2_TILES_LD(k)                                                       \
     v4u ta##k = {0u, 0u, 0u, 0u};                                            \
     if (tid + (k) * THREADS < upt) {                                         \
-        ta##k = src[tid + (k) * THREADS];                                    \
-        if (has_b) tb##k = src[upt + tid + (k) * THREADS];                   \
+        ta##k = __builtin_nontemporal_load(src + tid + (k) * THREADS);       \
+        if (has_b) tb##k = __builtin_nontemporal_load(src + upt + tid + (k) * THREADS); \
     }
 #define Q2_TILES_ST(k) \
     if (tid + (k) * THREADS < upt) *LDS_AT(lds_u4, (tid + (k) * THREADS) << 4) = ta##k;
