@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64, (!FEA64 ? (W <= 5 ? PK_CLEAN_OCC5 : 2) : 1)) vo
 // ONE diagonal d within ~50 rows of each other (the lists of the benchmark regime: every non-zero band
 // pixel, diagonal by diagonal) are the 4w+1 diagonals d-2w .. d+2w of the band over 64 consecutive rows.
 // A wave stages that strip in LDS by LDS-DMA (global_load_lds_dwordx4: whole lines, no VGPR, no ds_write
-// -- 17 instructions at w = 5) and every lane reads its window from there at constant offsets (ds_read
+// -- 16 instructions at w = 5) and every lane reads its window from there at constant offsets (ds_read
 // with immediates: no address arithmetic).
 //   * staging image: rows of 64 doubles (half a DMA instruction: lane l of an instruction fetches the 16
 //     bytes l & 31 of the instruction's row l >> 5), first double = the even row rs <= x0 - w (16-byte
